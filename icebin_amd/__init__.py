@@ -1,0 +1,8 @@
+"""icebin_amd: MI355X-native implementation of IceBin's conservative-regridding hot path.
+
+Python surface mirrors pylib/_icebin.pyx (GCMRegridder, RegridMatrices) and
+ibmisc.linear_Weighted; all compute goes through libicebin_hip.so (include/icebin_hip.h).
+"""
+from ._capi import IcebinHipError, device_count  # noqa: F401
+from .linear import SparseSet, linear_Weighted, set_tuning  # noqa: F401
+from .regrid import GCMRegridder, RegridMatrices, from_synthetic  # noqa: F401

@@ -1,0 +1,676 @@
+// assemble.hip -- K2-K4: regrid-matrix assembly on gfx950 (COO -> CSR, weights, scaling).
+//
+// Replaces, for IceRegridder_L0 exchange grids, the whole of compute_AEvI /
+// compute_IvAE / compute_EvA (RegridMatrices_Dynamic.cpp:50-332): the Ur-matrix
+// generators GvAp / GvI / GvEp (IceRegridder_L0.cpp:100-214), spsparse's
+// first-seen dense numbering (MakeDenseEigenT ... ADD_DENSE), Eigen's
+// setFromTriplets, the sparse*diag*sparse products, sum(), and the diagonal
+// scalings.  For an L0 exchange grid every exchange cell x has exactly one
+// atmosphere cell and one ice cell, so each product collapses to a keyed sum
+//     T[r,c] = sum over x ASCENDING of  fl( fl(lhs_x * sinv_x) * rhs_x )
+// (the order and rounding of Eigen's conservative sparse product, see
+// oracle/icebin_oracle.c), which is computed here as: emit contributions in x
+// order -> stable radix sort by (row_d, col_d) -> sequential sum per segment.
+// Row sums run sequentially along CSR rows (ascending column) and column sums
+// along a stable by-column reordering (ascending row): the orders of spsparse
+// sum().  All of it is index/byte work bound by HBM traffic; no float atomics,
+// no FMA contraction (this file is compiled with -ffp-contract=off), so the
+// CSR structure, dims, wM, Mw and M are bit-identical to the oracle.
+#include "assemble.h"
+#include "prims.h"
+
+namespace ibh {
+
+// ---- workspace arena: bump allocator over a few big hipMalloc blocks, reused across builds ----
+struct Arena {
+    struct Block { char *p; size_t cap, used; };
+    std::vector<Block> blocks;
+    ~Arena() { for (auto &b : blocks) (void)hipFree(b.p); }
+    void reset() { for (auto &b : blocks) b.used = 0; }
+    template <class T>
+    T *get(size_t n) {
+        size_t bytes = ((n ? n : 1) * sizeof(T) + 255) & ~size_t(255);
+        for (auto &b : blocks)
+            if (b.cap - b.used >= bytes) { char *p = b.p + b.used; b.used += bytes; return reinterpret_cast<T *>(p); }
+        size_t cap = bytes > (size_t(64) << 20) ? bytes : (size_t(64) << 20);
+        Block nb{nullptr, cap, bytes};
+        IBH_HIP(hipMalloc(reinterpret_cast<void **>(&nb.p), cap));
+        blocks.push_back(nb);
+        return reinterpret_cast<T *>(nb.p);
+    }
+};
+static Arena &arena() { static thread_local Arena a; return a; }
+void release_workspace() {
+    Arena &a = arena();
+    for (auto &b : a.blocks) (void)hipFree(b.p);
+    a.blocks.clear();
+}
+
+enum { LIST_AP = 0, LIST_I = 1, LIST_EP = 2 };
+enum { KEY_A = 0, KEY_I = 1, KEY_E = 2, KEY_X = 3 };
+enum { FAM_AEVI = 0, FAM_IVAE = 1, FAM_EVA = 2 };
+// contribution formulas: t = fl(fl(lhs * sinv) * rhs)
+enum { TERM_PLAIN_A = 0,   // a                       (AvX, XvA)
+       TERM_PLAIN_E,       // vE                      (EvX, XvE)
+       TERM_A_A,           // lhs=a,  sinv=1/a,  rhs=a    (AvI, IvA), needs x in GvAp and GvI
+       TERM_E_A,           // lhs=vE, sinv=1/a,  rhs=a    (EvI needs GvI; EvA needs GvAp)
+       TERM_A_E };         // lhs=a,  sinv=1/rs, rhs=vE   (IvE needs GvI; AvE needs GvAp)
+
+struct MatSpec {
+    const char *name;
+    int family;
+    int row_list, row_key, col_list, col_key;
+    int term;
+    int need_list;     // extra list the contributing x must belong to (LIST_AP / LIST_I), -1 none
+    int epx;           // contributions per x: 1 or 2 (2 when GvEp entries are enumerated)
+};
+static const MatSpec SPECS[] = {
+    // name  family    rows               cols               term          need     epx
+    {"AvI", FAM_AEVI, LIST_AP, KEY_A, LIST_I,  KEY_I, TERM_A_A,     LIST_I,  1},
+    {"EvI", FAM_AEVI, LIST_EP, KEY_E, LIST_I,  KEY_I, TERM_E_A,     LIST_I,  2},
+    {"AvX", FAM_AEVI, LIST_AP, KEY_A, LIST_AP, KEY_X, TERM_PLAIN_A, -1,      1},
+    {"EvX", FAM_AEVI, LIST_EP, KEY_E, LIST_EP, KEY_X, TERM_PLAIN_E, -1,      2},
+    {"IvA", FAM_IVAE, LIST_I,  KEY_I, LIST_AP, KEY_A, TERM_A_A,     LIST_I,  1},
+    {"IvE", FAM_IVAE, LIST_I,  KEY_I, LIST_EP, KEY_E, TERM_A_E,     LIST_I,  2},
+    {"XvA", FAM_IVAE, LIST_AP, KEY_X, LIST_AP, KEY_A, TERM_PLAIN_A, -1,      1},
+    {"XvE", FAM_IVAE, LIST_EP, KEY_X, LIST_EP, KEY_E, TERM_PLAIN_E, -1,      2},
+    {"EvA", FAM_EVA,  LIST_EP, KEY_E, LIST_AP, KEY_A, TERM_E_A,     LIST_AP, 2},
+    {"AvE", FAM_EVA,  LIST_AP, KEY_A, LIST_EP, KEY_E, TERM_A_E,     LIST_AP, 2},
+};
+
+struct RgView {
+    const int32_t *exi;
+    const double *area, *em, *hc;
+    const double *ratioA;   // by sparse A index; 0 = A cell not realised
+    long nX, nA;
+    int nhc, interp;
+    long sA, sHC;
+};
+
+// ---- per-exchange-cell generators (device restatement of IceRegridder_L0.cpp:100-214) ----------
+struct XCell {
+    long iA, iI;
+    double a;
+    bool unmasked, inAp, inI;
+    int nep;            // GvEp entries actually emitted (0..2)
+    long iE[2];
+    double vE[2];
+    double rsE;         // sum(GvEp row x): one entry -> v, two -> fl(v0 + v1)
+    bool range_error;
+};
+
+__device__ __forceinline__ int dev_lower_bound(const double *__restrict__ xp, int n, double xx) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (xp[mid] < xx) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool WITH_EP>
+__device__ __forceinline__ XCell load_cell(const RgView &rg, long x) {
+    XCell c;
+    c.iA = rg.exi[2 * x];
+    c.iI = rg.exi[2 * x + 1];
+    c.a = rg.area[x];
+    const double e = rg.em[c.iI];
+    c.unmasked = !(e != e);                       // !std::isnan, IceRegridder_L0.cpp:121,186,208
+    c.inAp = c.unmasked && c.a > 0;               // :208-209
+    c.inI = c.unmasked && c.a != 0;               // :186-187 (+ include_zero=false)
+    c.nep = 0;
+    c.rsE = 0.0;
+    c.range_error = false;
+    if (WITH_EP && c.unmasked) {
+        const double elevation = e < 0.0 ? 0.0 : e;          // std::max(elev, 0.0), :123
+        if (rg.interp == 0) {                                // Z_INTERP, :127-145
+            int i1 = dev_lower_bound(rg.hc, rg.nhc, elevation);
+            if (i1 <= 0) i1 = 1;
+            if (i1 >= rg.nhc) { c.range_error = true; return c; }      // :84-85
+            const int i0 = i1 - 1;
+            const double ratio = (elevation - rg.hc[i0]) / (rg.hc[i1] - rg.hc[i0]);
+            const double w0 = 1.0 - ratio, w1 = ratio;
+            if (w0 != 0) {
+                const double v = c.a * w0;
+                if (v != 0) { c.iE[c.nep] = c.iA * rg.sA + (long)i0 * rg.sHC; c.vE[c.nep] = v; c.nep++; }
+            }
+            if (w1 != 0) {
+                const double v = c.a * w1;
+                if (v != 0) { c.iE[c.nep] = c.iA * rg.sA + (long)i1 * rg.sHC; c.vE[c.nep] = v; c.nep++; }
+            }
+        } else {                                             // ELEV_CLASS_INTERP, :146-150 + nearest_1d :43-67
+            const int n = rg.nhc;
+            int i1 = dev_lower_bound(rg.hc, n, elevation);
+            int ih;
+            if (i1 <= 0) ih = 0;
+            else if (i1 >= n) ih = n - 1;
+            else {
+                const int i0 = i1 - 1;
+                const double d0 = fabs(elevation - rg.hc[i0]), d1 = fabs(rg.hc[i1] - elevation);
+                ih = d0 <= d1 ? i0 : i1;
+            }
+            if (c.a != 0) { c.iE[0] = c.iA * rg.sA + (long)ih * rg.sHC; c.vE[0] = c.a; c.nep = 1; }
+        }
+        if (c.nep == 1) c.rsE = c.vE[0];
+        else if (c.nep == 2) c.rsE = c.vE[0] + c.vE[1];
+    }
+    return c;
+}
+
+// entries of `list` at cell c: count and sparse keys of kind `key`
+__device__ __forceinline__ int list_entries(const XCell &c, long x, int list, int key, long keys[2]) {
+    int n;
+    if (list == LIST_AP) n = c.inAp ? 1 : 0;
+    else if (list == LIST_I) n = c.inI ? 1 : 0;
+    else n = c.nep;
+    for (int j = 0; j < n; ++j)
+        keys[j] = key == KEY_A ? c.iA : key == KEY_I ? c.iI : key == KEY_X ? x : c.iE[j];
+    // an X key is emitted once per list entry; duplicates are harmless to first-seen numbering
+    return n;
+}
+
+// ---- dense numbering (spsparse::SparseSet::add_dense in emission order) ------------------------
+__global__ void k_fill_i32(int32_t *p, size_t n, int32_t v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_iota_i32(int32_t *p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int32_t)i;
+}
+__global__ void k_scatter_existing(int32_t *tab, const int64_t *to_sparse, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) tab[to_sparse[i]] = i;
+}
+
+template <bool WITH_EP>
+__global__ void k_number_first(RgView rg, int list, int key, const int32_t *__restrict__ tab,
+                               uint32_t *__restrict__ first, int *__restrict__ err_x) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= rg.nX) return;
+    const XCell c = load_cell<WITH_EP>(rg, x);
+    if (WITH_EP && c.range_error) { atomicMin(err_x, (int)x); return; }
+    long keys[2];
+    const int n = list_entries(c, x, list, key, keys);
+    for (int j = 0; j < n; ++j) {
+        const uint32_t p = (uint32_t)(2 * x + j);
+        // the plain read only filters: first[] decreases monotonically, a stale value costs one extra atomic
+        if (tab[keys[j]] < 0 && first[keys[j]] > p) atomicMin(&first[keys[j]], p);
+    }
+}
+template <bool WITH_EP>
+__global__ void k_number_flag(RgView rg, int list, int key, const int32_t *__restrict__ tab,
+                              const uint32_t *__restrict__ first, uint32_t *__restrict__ flag) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= rg.nX) return;
+    const XCell c = load_cell<WITH_EP>(rg, x);
+    long keys[2];
+    const int n = (WITH_EP && c.range_error) ? 0 : list_entries(c, x, list, key, keys);
+    uint32_t f0 = 0, f1 = 0;
+    if (n > 0 && tab[keys[0]] < 0 && first[keys[0]] == (uint32_t)(2 * x)) f0 = 1;
+    if (n > 1 && tab[keys[1]] < 0 && first[keys[1]] == (uint32_t)(2 * x + 1)) f1 = 1;
+    flag[2 * x] = f0;
+    flag[2 * x + 1] = f1;
+}
+template <bool WITH_EP>
+__global__ void k_number_assign(RgView rg, int list, int key, int32_t *__restrict__ tab,
+                                const uint32_t *__restrict__ first, const uint32_t *__restrict__ rank, int base,
+                                int64_t *__restrict__ to_sparse) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= rg.nX) return;
+    const XCell c = load_cell<WITH_EP>(rg, x);
+    long keys[2];
+    const int n = (WITH_EP && c.range_error) ? 0 : list_entries(c, x, list, key, keys);
+    for (int j = 0; j < n; ++j) {
+        // first[] still holds the winner; tab is only written at the winner's key
+        if (first[keys[j]] == (uint32_t)(2 * x + j)) {
+            const int id = base + (int)rank[2 * x + j];
+            tab[keys[j]] = id;
+            to_sparse[id] = keys[j];
+        }
+    }
+}
+
+struct DeviceSet {
+    int32_t *tab = nullptr;       // [sparse_extent] sparse -> dense (-1 missing)
+    int64_t *to_sparse = nullptr; // [capacity] dense -> sparse
+    int n_old = 0, n = 0;
+};
+
+// Number `set` through the entries of `list` (keys of kind `key`), appending new keys first-seen.
+static DeviceSet number_set(const RgView &rg, ibh_sparse_set *set, int64_t sparse_extent, int list, int key,
+                            int64_t max_new, int *d_err, hipStream_t st) {
+    Arena &A = arena();
+    set->sparse_extent = sparse_extent;                       // set_sparse_extent, RegridMatrices_Dynamic.cpp:69-72
+    DeviceSet ds;
+    ds.n_old = set->dense_extent();
+    if (set->identity) {
+        IBH_CHECK(ds.n_old <= sparse_extent, "identity dims larger than sparse extent");
+    } else {
+        for (int64_t s : set->to_sparse)
+            IBH_CHECK(s >= 0 && s < sparse_extent, "dims entry %ld outside sparse extent %ld", (long)s, (long)sparse_extent);
+    }
+    if (max_new > sparse_extent - ds.n_old) max_new = sparse_extent - ds.n_old;
+    ds.tab = A.get<int32_t>((size_t)sparse_extent);
+    const int64_t cap = (int64_t)ds.n_old + max_new;
+    ds.to_sparse = A.get<int64_t>((size_t)cap);
+    const int T = 256;
+    if (set->identity) {
+        hipLaunchKernelGGL(k_fill_i32, dim3(ceil_div(sparse_extent, T)), dim3(T), 0, st, ds.tab, (size_t)sparse_extent, -1);
+        hipLaunchKernelGGL(k_iota_i32, dim3(ceil_div(ds.n_old, T)), dim3(T), 0, st, ds.tab, (size_t)ds.n_old);
+    } else {
+        hipLaunchKernelGGL(k_fill_i32, dim3(ceil_div(sparse_extent, T)), dim3(T), 0, st, ds.tab, (size_t)sparse_extent, -1);
+    }
+    if (ds.n_old) {
+        IBH_HIP(hipMemcpyAsync(ds.to_sparse, set->to_sparse.data(), sizeof(int64_t) * (size_t)ds.n_old,
+                               hipMemcpyHostToDevice, st));
+        if (!set->identity)
+            hipLaunchKernelGGL(k_scatter_existing, dim3(ceil_div(ds.n_old, T)), dim3(T), 0, st, ds.tab, ds.to_sparse, ds.n_old);
+    }
+    ds.n = ds.n_old;
+    if (set->identity && ds.n_old == sparse_extent) return ds;   // nothing can be new
+    uint32_t *first = A.get<uint32_t>((size_t)sparse_extent);
+    uint32_t *flag = A.get<uint32_t>((size_t)(2 * rg.nX));
+    uint32_t *d_total = A.get<uint32_t>(1);
+    IBH_HIP(hipMemsetAsync(first, 0xFF, sizeof(uint32_t) * (size_t)sparse_extent, st));
+    const dim3 grid(ceil_div(rg.nX, T));
+    const bool ep = list == LIST_EP;
+    if (ep) hipLaunchKernelGGL(k_number_first<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, d_err);
+    else hipLaunchKernelGGL(k_number_first<false>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, d_err);
+    if (ep) hipLaunchKernelGGL(k_number_flag<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, flag);
+    else hipLaunchKernelGGL(k_number_flag<false>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, flag);
+    exclusive_scan_u32(flag, flag, (size_t)(2 * rg.nX), d_total, st);
+    uint32_t n_new = 0;
+    IBH_HIP(hipMemcpyAsync(&n_new, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    IBH_HIP(hipStreamSynchronize(st));
+    IBH_CHECK((int64_t)n_new <= max_new, "internal: more new keys (%u) than reserved (%ld)", n_new, (long)max_new);
+    IBH_CHECK((int64_t)ds.n_old + n_new < (1ll << 31), "dense extent overflows int32");
+    if (ep) hipLaunchKernelGGL(k_number_assign<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, flag, ds.n_old, ds.to_sparse);
+    else hipLaunchKernelGGL(k_number_assign<false>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, flag, ds.n_old, ds.to_sparse);
+    IBH_HIP(hipGetLastError());
+    ds.n = ds.n_old + (int)n_new;
+    if (n_new) {
+        set->to_sparse.resize((size_t)ds.n);
+        IBH_HIP(hipMemcpyAsync(set->to_sparse.data() + ds.n_old, ds.to_sparse + ds.n_old, sizeof(int64_t) * n_new,
+                               hipMemcpyDeviceToHost, st));
+        IBH_HIP(hipStreamSynchronize(st));
+        set->identity = false;
+        set->to_dense_map.clear();
+    }
+    return ds;
+}
+
+// ---- contributions ---------------------------------------------------------------------------
+__device__ __forceinline__ int contributions(const XCell &c, long x, const MatSpec &s, long rkey[2], long ckey[2],
+                                             double t[2]) {
+    if (s.need_list == LIST_I && !c.inI) return 0;
+    if (s.need_list == LIST_AP && !c.inAp) return 0;
+    switch (s.term) {
+        case TERM_PLAIN_A:
+            if (!c.inAp) return 0;
+            rkey[0] = s.row_key == KEY_X ? x : c.iA; ckey[0] = s.col_key == KEY_X ? x : c.iA; t[0] = c.a;
+            return 1;
+        case TERM_PLAIN_E:
+            for (int j = 0; j < c.nep; ++j) {
+                rkey[j] = s.row_key == KEY_X ? x : c.iE[j]; ckey[j] = s.col_key == KEY_X ? x : c.iE[j]; t[j] = c.vE[j];
+            }
+            return c.nep;
+        case TERM_A_A: {
+            if (!c.inAp) return 0;
+            const double sinv = 1.0 / c.a;
+            const double l = c.a * sinv;
+            rkey[0] = s.row_key == KEY_A ? c.iA : c.iI; ckey[0] = s.col_key == KEY_A ? c.iA : c.iI; t[0] = l * c.a;
+            return 1;
+        }
+        case TERM_E_A: {      // rows E; cols I (EvI) or A (EvA)
+            const double sinv = 1.0 / c.a;
+            for (int j = 0; j < c.nep; ++j) {
+                const double l = c.vE[j] * sinv;
+                rkey[j] = c.iE[j]; ckey[j] = s.col_key == KEY_A ? c.iA : c.iI; t[j] = l * c.a;
+            }
+            return c.nep;
+        }
+        default: {            // TERM_A_E: cols E; rows I (IvE) or A (AvE)
+            if (c.nep == 0) return 0;
+            const double sinv = 1.0 / c.rsE;
+            const double l = c.a * sinv;
+            for (int j = 0; j < c.nep; ++j) {
+                rkey[j] = s.row_key == KEY_A ? c.iA : c.iI; ckey[j] = c.iE[j]; t[j] = l * c.vE[j];
+            }
+            return c.nep;
+        }
+    }
+}
+
+template <bool WITH_EP>
+__global__ void k_contrib_count(RgView rg, MatSpec s, uint32_t *__restrict__ cnt) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= rg.nX) return;
+    const XCell c = load_cell<WITH_EP>(rg, x);
+    long rk[2], ck[2]; double t[2];
+    cnt[x] = (WITH_EP && c.range_error) ? 0u : (uint32_t)contributions(c, x, s, rk, ck, t);
+}
+template <bool WITH_EP>
+__global__ void k_contrib_emit(RgView rg, MatSpec s, const uint32_t *__restrict__ pos, const int32_t *__restrict__ rtab,
+                               const int32_t *__restrict__ ctab, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx,
+                               double *__restrict__ term) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= rg.nX) return;
+    const XCell c = load_cell<WITH_EP>(rg, x);
+    if (WITH_EP && c.range_error) return;
+    long rk[2], ck[2]; double t[2];
+    const int n = contributions(c, x, s, rk, ck, t);
+    const uint32_t p = pos[x];
+    for (int j = 0; j < n; ++j) {
+        keys[p + j] = ((uint64_t)(uint32_t)rtab[rk[j]] << 32) | (uint32_t)ctab[ck[j]];
+        idx[p + j] = p + j;
+        term[p + j] = t[j];
+    }
+}
+
+// ---- sorted contributions -> unique CSR entries ------------------------------------------------
+__global__ void k_head_flags(const uint64_t *__restrict__ keys, size_t n, uint32_t *__restrict__ head) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) head[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1u : 0u;
+}
+// One thread per segment head: sequential sum in sorted (== emission) order, first term assigned.
+__global__ void k_segment_sum(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
+                              const double *__restrict__ term, size_t n, const uint32_t *__restrict__ upos,
+                              int32_t *__restrict__ row, int32_t *__restrict__ col, double *__restrict__ val) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t key = keys[k];
+    if (k != 0 && keys[k - 1] == key) return;
+    double s = term[idx[k]];
+    for (size_t m = k + 1; m < n && keys[m] == key; ++m) s = s + term[idx[m]];
+    const uint32_t u = upos[k];
+    row[u] = (int32_t)(key >> 32);
+    col[u] = (int32_t)(key & 0xffffffffu);
+    val[u] = s;
+}
+__global__ void k_rowptr(const int32_t *__restrict__ row, long nnz, int nrow, int32_t *__restrict__ rowptr) {
+    const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nnz) return;
+    const int r = row[u];
+    const int prev = u > 0 ? row[u - 1] : -1;
+    for (int q = prev + 1; q <= r; ++q) rowptr[q] = (int32_t)u;
+    if (u == nnz - 1)
+        for (int q = r + 1; q <= nrow; ++q) rowptr[q] = (int32_t)nnz;
+}
+// spsparse sum(M,0,'+'): along each CSR row in ascending column order
+__global__ void k_row_sums(const int32_t *__restrict__ rowptr, const double *__restrict__ val, int nrow,
+                           double *__restrict__ rs) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    double s = 0.0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) s = s + val[k];
+    rs[r] = s;
+}
+__global__ void k_col_keys(const int32_t *__restrict__ col, long nnz, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+    const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < nnz) { keys[u] = (uint64_t)(uint32_t)col[u]; idx[u] = (uint32_t)u; }
+}
+// spsparse sum(M,1,'+'): along each column in ascending row order (stable by-column order)
+__global__ void k_col_sums(const uint64_t *__restrict__ ckeys, const uint32_t *__restrict__ idx,
+                           const double *__restrict__ val, long nnz, double *__restrict__ cs) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const uint64_t c = ckeys[k];
+    if (k != 0 && ckeys[k - 1] == c) return;
+    double s = 0.0;
+    for (long m = k; m < nnz && ckeys[m] == c; ++m) s = s + val[idx[m]];
+    cs[c] = s;
+}
+
+// ---- weights and scaling (RegridMatrices_Dynamic.cpp:100-146, 201-233, 290-329) ----------------
+__device__ __forceinline__ double ratio_of(const RgView &rg, int keykind, int64_t sparse) {
+    long iA = sparse;
+    if (keykind == KEY_E) iA = rg.sHC >= rg.sA ? (sparse % rg.sHC) / rg.sA : sparse / rg.sA;
+    return rg.ratioA[iA];
+}
+struct FinalizeArgs {
+    int family, scale, correctA, row_key, col_key;
+    int nrow, ncol;
+    const int64_t *row_s, *col_s;     // dense -> sparse
+    const double *rs, *cs;
+    double *wM, *Mw, *rowmul, *colmul; // rowmul/colmul: per-row / per-column factors applied to T
+};
+__global__ void k_weights(RgView rg, FinalizeArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.nrow) {
+        const double rs = a.rs[i];
+        double wM, mul = 1.0;
+        if (a.family == FAM_AEVI) {
+            if (a.correctA) {
+                const double r = ratio_of(rg, a.row_key, a.row_s[i]);
+                wM = r * rs;                                   // :112-115
+                if (a.scale) mul = (1.0 / r) * (1.0 / rs);     // :118-122
+            } else {
+                wM = rs;                                       // :135-136
+                if (a.scale) mul = 1.0 / rs;                   // :140
+            }
+        } else if (a.family == FAM_IVAE) {
+            wM = rs;                                           // :201
+            if (a.scale) mul = 1.0 / rs;                       // :218,228
+        } else {
+            if (a.correctA) {
+                const double r = ratio_of(rg, a.row_key, a.row_s[i]);
+                wM = r * rs;                                   // :303-304
+                if (a.scale) mul = 1.0 / wM;                   // :313
+            } else {
+                wM = rs;                                       // :321
+                if (a.scale) mul = 1.0 / rs;                   // :324
+            }
+        }
+        a.wM[i] = wM;
+        a.rowmul[i] = mul;
+    }
+    if (i < a.ncol) {
+        const double cs = a.cs[i];
+        double Mw = cs, cm = 1.0;                              // :100, :226, :322
+        if (a.correctA && a.family != FAM_AEVI) {
+            const double r = ratio_of(rg, a.col_key, a.col_s[i]);
+            Mw = r * cs;                                       // :214-215, :309-310
+            cm = r;                                            // * sApvA, :220,223,315,317
+        }
+        a.Mw[i] = Mw;
+        a.colmul[i] = cm;
+    }
+}
+// M = [diag(rowmul)] * T [* diag(colmul)], each product separately rounded, in the reference's order
+__global__ void k_scale(const int32_t *__restrict__ row, const int32_t *__restrict__ col, double *__restrict__ val,
+                        long nnz, const double *__restrict__ rowmul, const double *__restrict__ colmul,
+                        int apply_row, int apply_col) {
+    const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nnz) return;
+    double v = val[u];
+    if (apply_row) v = rowmul[row[u]] * v;
+    if (apply_col) v = v * colmul[col[u]];
+    val[u] = v;
+}
+
+// ---- shared: sorted (row,col,idx) contributions -> Weighted CSR ---------------------------------
+struct Triplets { uint64_t *keys, *keys_alt; uint32_t *idx, *idx_alt; double *term; size_t n; };
+
+static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, int ncol, int32_t **row_out,
+                                         hipStream_t st) {
+    Arena &A = arena();
+    const int T = 256;
+    w->nrow = nrow; w->ncol = ncol;
+    w->rowptr.alloc((size_t)nrow + 1);
+    if (t.n == 0) {
+        w->nnz = 0;
+        w->rowptr.zero(st);
+        w->colind.alloc(0); w->val.alloc(0);
+        *row_out = nullptr;
+        return;
+    }
+    KeyField fields[2] = {{0, bits_for((uint64_t)ncol)}, {32, bits_for((uint64_t)nrow)}};
+    KeyField nz[2]; int nf = 0;
+    for (auto &f : fields) if (f.nbits > 0) nz[nf++] = f;
+    if (radix_sort_pairs(t.keys, t.keys_alt, t.idx, t.idx_alt, t.n, nz, nf, st)) {
+        std::swap(t.keys, t.keys_alt); std::swap(t.idx, t.idx_alt);
+    }
+    uint32_t *head = A.get<uint32_t>(t.n);
+    uint32_t *d_total = A.get<uint32_t>(1);
+    hipLaunchKernelGGL(k_head_flags, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, head);
+    exclusive_scan_u32(head, head, t.n, d_total, st);
+    uint32_t nnz = 0;
+    IBH_HIP(hipMemcpyAsync(&nnz, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    IBH_HIP(hipStreamSynchronize(st));
+    IBH_CHECK(nnz < (1u << 31), "nnz overflows int32");
+    w->nnz = nnz;
+    w->colind.alloc(nnz); w->val.alloc(nnz);
+    int32_t *row = A.get<int32_t>(nnz);
+    hipLaunchKernelGGL(k_segment_sum, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.idx, t.term, t.n, head, row,
+                       w->colind.p, w->val.p);
+    hipLaunchKernelGGL(k_rowptr, dim3(ceil_div(nnz, T)), dim3(T), 0, st, row, (long)nnz, nrow, w->rowptr.p);
+    IBH_HIP(hipGetLastError());
+    *row_out = row;
+}
+
+static void compute_max_row(ibh_weighted *w, hipStream_t st) {
+    (void)st; w->max_row_nnz = 0;   // dispatch uses the mean row length only
+}
+
+// ---- RegridMatrices_Dynamic::matrix_d ----------------------------------------------------------
+void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_sparse_set *dim0, ibh_sparse_set *dim1,
+                     int scale, int correctA, const double sigma[3], ibh_weighted **out) {
+    IBH_CHECK(rm && spec_name && out, "null argument");
+    if (sigma && sigma[0] != 0)      // RegridParams::smooth(), RegridMatrices.hpp:31
+        fail(IBH_ENOTIMPL, "smoothing (sigma != 0) is outside the hot-path scope of this build (SURVEY.md 8f)");
+    const MatSpec *sp = nullptr;
+    for (const auto &s : SPECS) if (!strcmp(s.name, spec_name)) sp = &s;
+    if (!sp) fail(IBH_ENOKEY, "unknown regrid matrix '%s' (expected one of AvI IvA AvX XvA EvI IvE EvX XvE EvA AvE)", spec_name);
+    const ibh_regridder *g = rm->rg;
+    const bool uses_ep = sp->row_list == LIST_EP || sp->col_list == LIST_EP;
+    if (uses_ep && g->nhc == 0) fail(IBH_EINVAL, "IceRegridder_L0::GvEp(): hcdefs is zero-length!");   // IceRegridder_L0.cpp:108-109
+    hipStream_t st = nullptr;
+    Arena &A = arena();
+    A.reset();
+
+    RgView rg{g->ex_indices.p, g->ex_area.p, rm->elevmaskI.p, g->hcdefs.p, g->A_ratio_s.p, g->nX, g->nA,
+              g->nhc, g->interp_style, g->hc_stride_A, g->hc_stride_HC};
+
+    std::unique_ptr<ibh_weighted> w(new ibh_weighted);
+    IBH_HIP(hipGetDevice(&w->device));
+    ibh_sparse_set *dims[2] = {dim0, dim1};
+    for (int k = 0; k < 2; ++k) {
+        if (!dims[k]) { dims[k] = new ibh_sparse_set; w->owns[k] = true; }
+        w->dims[k] = dims[k];
+    }
+    w->conservative = 1;              // :63, :167 (no smoothing), :258
+    w->scaled = scale;                // :421
+
+    auto extent_of = [&](int key) -> int64_t {
+        return key == KEY_A ? g->nA : key == KEY_E ? g->nA * (int64_t)g->nhc : key == KEY_I ? g->nI : g->nX;
+    };
+    int *d_err = A.get<int>(1);
+    const int big = 0x7fffffff;
+    IBH_HIP(hipMemcpyAsync(d_err, &big, sizeof(int), hipMemcpyHostToDevice, st));
+
+    // dense numbering in the reference's order: the A/E-side Ur matrix is densified first
+    // (RegridMatrices_Dynamic.cpp:75-81, 178-183, 270-277), then the other one.
+    // (each user-visible set is numbered by exactly one Ur matrix, so the order between the two
+    // sets is immaterial; rows first.)
+    DeviceSet rset, cset;
+    auto do_rows = [&] { rset = number_set(rg, dims[0], extent_of(sp->row_key), sp->row_list, sp->row_key,
+                                           (sp->row_list == LIST_EP ? 2 : 1) * g->nX, d_err, st); };
+    auto do_cols = [&] { cset = number_set(rg, dims[1], extent_of(sp->col_key), sp->col_list, sp->col_key,
+                                           (sp->col_list == LIST_EP ? 2 : 1) * g->nX, d_err, st); };
+    do_rows(); do_cols();
+    int err_x = big;
+    IBH_HIP(hipMemcpyAsync(&err_x, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    IBH_HIP(hipStreamSynchronize(st));
+    if (err_x != big) {
+        // message of linterp_1d_b, IceRegridder_L0.cpp:84-85
+        std::vector<int32_t> ij(2);
+        IBH_HIP(hipMemcpy(ij.data(), g->ex_indices.p + 2 * (size_t)err_x, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        double e = 0;
+        IBH_HIP(hipMemcpy(&e, rm->elevmaskI.p + ij[1], sizeof(double), hipMemcpyDeviceToHost));
+        fail(IBH_ERANGE, "Elevation %g out of bounds (%g, %g)", e < 0 ? 0.0 : e, g->hcdefs_h.front(), g->hcdefs_h.back());
+    }
+    const int nrow = rset.n, ncol = cset.n;
+
+    // contributions in emission (x) order
+    const int T = 256;
+    const dim3 grid(ceil_div(g->nX, T));
+    uint32_t *cnt = A.get<uint32_t>((size_t)g->nX);
+    uint32_t *d_total = A.get<uint32_t>(1);
+    if (uses_ep) hipLaunchKernelGGL(k_contrib_count<true>, grid, dim3(T), 0, st, rg, *sp, cnt);
+    else hipLaunchKernelGGL(k_contrib_count<false>, grid, dim3(T), 0, st, rg, *sp, cnt);
+    exclusive_scan_u32(cnt, cnt, (size_t)g->nX, d_total, st);
+    uint32_t ncontrib = 0;
+    IBH_HIP(hipMemcpyAsync(&ncontrib, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    IBH_HIP(hipStreamSynchronize(st));
+    Triplets t;
+    t.n = ncontrib;
+    t.keys = A.get<uint64_t>(t.n); t.keys_alt = A.get<uint64_t>(t.n);
+    t.idx = A.get<uint32_t>(t.n); t.idx_alt = A.get<uint32_t>(t.n);
+    t.term = A.get<double>(t.n);
+    if (t.n) {
+        if (uses_ep) hipLaunchKernelGGL(k_contrib_emit<true>, grid, dim3(T), 0, st, rg, *sp, cnt, rset.tab, cset.tab, t.keys, t.idx, t.term);
+        else hipLaunchKernelGGL(k_contrib_emit<false>, grid, dim3(T), 0, st, rg, *sp, cnt, rset.tab, cset.tab, t.keys, t.idx, t.term);
+    }
+    int32_t *row = nullptr;
+    build_csr_from_contributions(w.get(), t, nrow, ncol, &row, st);
+    const long nnz = w->nnz;
+
+    // weights
+    double *rs = A.get<double>((size_t)nrow), *cs = A.get<double>((size_t)ncol);
+    double *rowmul = A.get<double>((size_t)nrow), *colmul = A.get<double>((size_t)ncol);
+    w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
+    if (nrow) hipLaunchKernelGGL(k_row_sums, dim3(ceil_div(nrow, T)), dim3(T), 0, st, w->rowptr.p, w->val.p, nrow, rs);
+    if (ncol) IBH_HIP(hipMemsetAsync(cs, 0, sizeof(double) * (size_t)ncol, st));
+    if (nnz) {
+        uint64_t *ck = A.get<uint64_t>((size_t)nnz), *ck2 = A.get<uint64_t>((size_t)nnz);
+        uint32_t *ci = A.get<uint32_t>((size_t)nnz), *ci2 = A.get<uint32_t>((size_t)nnz);
+        hipLaunchKernelGGL(k_col_keys, dim3(ceil_div(nnz, T)), dim3(T), 0, st, w->colind.p, nnz, ck, ci);
+        KeyField f{0, bits_for((uint64_t)ncol)};
+        if (f.nbits > 0 && radix_sort_pairs(ck, ck2, ci, ci2, (size_t)nnz, &f, 1, st)) { std::swap(ck, ck2); std::swap(ci, ci2); }
+        hipLaunchKernelGGL(k_col_sums, dim3(ceil_div(nnz, T)), dim3(T), 0, st, ck, ci, w->val.p, nnz, cs);
+    }
+    FinalizeArgs fa{sp->family, scale, correctA, sp->row_key, sp->col_key, nrow, ncol, rset.to_sparse, cset.to_sparse,
+                    rs, cs, w->wM.p, w->Mw.p, rowmul, colmul};
+    const int nmax = nrow > ncol ? nrow : ncol;
+    if (nmax) hipLaunchKernelGGL(k_weights, dim3(ceil_div(nmax, T)), dim3(T), 0, st, rg, fa);
+    const int apply_row = scale ? 1 : 0;
+    const int apply_col = (correctA && sp->family != FAM_AEVI) ? 1 : 0;
+    if (nnz && (apply_row || apply_col))
+        hipLaunchKernelGGL(k_scale, dim3(ceil_div(nnz, T)), dim3(T), 0, st, row, w->colind.p, w->val.p, nnz, rowmul, colmul,
+                           apply_row, apply_col);
+    IBH_HIP(hipGetLastError());
+    IBH_HIP(hipStreamSynchronize(st));
+    compute_max_row(w.get(), st);
+    *out = w.release();
+}
+
+// ---- ibh_weighted_from_coo: Eigen setFromTriplets on device -----------------------------------
+__global__ void k_coo_keys(const int32_t *__restrict__ row, const int32_t *__restrict__ col, size_t n,
+                           uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) { keys[k] = ((uint64_t)(uint32_t)row[k] << 32) | (uint32_t)col[k]; idx[k] = (uint32_t)k; }
+}
+void weighted_from_coo_device(ibh_weighted *w, int nrow, int ncol, int64_t n, const int32_t *row, const int32_t *col,
+                              const double *val) {
+    hipStream_t st = nullptr;
+    Arena &A = arena();
+    A.reset();
+    Triplets t;
+    t.n = (size_t)n;
+    t.keys = A.get<uint64_t>(t.n); t.keys_alt = A.get<uint64_t>(t.n);
+    t.idx = A.get<uint32_t>(t.n); t.idx_alt = A.get<uint32_t>(t.n);
+    t.term = A.get<double>(t.n);
+    int32_t *drow = A.get<int32_t>(t.n), *dcol = A.get<int32_t>(t.n);
+    if (n) {
+        IBH_HIP(hipMemcpyAsync(drow, row, sizeof(int32_t) * t.n, hipMemcpyHostToDevice, st));
+        IBH_HIP(hipMemcpyAsync(dcol, col, sizeof(int32_t) * t.n, hipMemcpyHostToDevice, st));
+        IBH_HIP(hipMemcpyAsync(t.term, val, sizeof(double) * t.n, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_coo_keys, dim3(ceil_div(n, 256)), dim3(256), 0, st, drow, dcol, t.n, t.keys, t.idx);
+    }
+    int32_t *r = nullptr;
+    build_csr_from_contributions(w, t, nrow, ncol, &r, st);
+    IBH_HIP(hipStreamSynchronize(st));
+}
+
+}  // namespace ibh

@@ -1,0 +1,402 @@
+// capi.hip -- extern "C" entry points declared in include/icebin_hip.h.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "assemble.h"
+#include "common.h"
+
+namespace ibh {
+
+static thread_local std::string g_last_error;
+void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
+void fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+static void require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        fail(IBH_ENODEVICE, "no HIP device available (%s); libicebin_hip has no CPU fallback",
+             e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+}
+
+static void check_weighted_device(const ibh_weighted *w) {
+    IBH_CHECK(w != nullptr, "null Weighted handle");
+    int dev = -1;
+    IBH_HIP(hipGetDevice(&dev));
+    IBH_CHECK(dev == w->device, "Weighted handle belongs to device %d, current device is %d", w->device, dev);
+}
+
+static void make_identity(ibh_sparse_set *s, int64_t n) {
+    s->sparse_extent = n;
+    s->to_sparse.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) s->to_sparse[(size_t)i] = i;
+    s->identity = true;
+}
+
+__global__ void k_max_row(const int32_t *rowptr, int nrow, int *out) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrow) atomicMax(out, rowptr[r + 1] - rowptr[r]);
+}
+
+}  // namespace ibh
+
+using namespace ibh;
+
+extern "C" {
+
+const char *ibh_last_error(void) { return g_last_error.c_str(); }
+int ibh_version(void) { return 100; }
+
+int ibh_device_count(int *count) {
+    return guarded([&] {
+        IBH_CHECK(count != nullptr, "null argument");
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        *count = e == hipSuccess ? n : 0;
+    });
+}
+int ibh_set_device(int device) {
+    return guarded([&] { IBH_HIP(hipSetDevice(device)); });
+}
+
+// ---- SparseSet -----------------------------------------------------------------------------
+int ibh_sparse_set_create(int64_t sparse_extent, ibh_sparse_set **out) {
+    return guarded([&] {
+        IBH_CHECK(out != nullptr, "null argument");
+        auto *s = new ibh_sparse_set;
+        s->sparse_extent = sparse_extent;
+        *out = s;
+    });
+}
+int ibh_sparse_set_create_identity(int64_t n, ibh_sparse_set **out) {
+    return guarded([&] {
+        IBH_CHECK(out != nullptr && n >= 0 && n < (1ll << 31), "bad identity set size %ld", (long)n);
+        auto *s = new ibh_sparse_set;
+        make_identity(s, n);
+        *out = s;
+    });
+}
+int ibh_sparse_set_from_array(int64_t sparse_extent, const int64_t *to_sparse, int32_t n, ibh_sparse_set **out) {
+    return guarded([&] {
+        IBH_CHECK(out != nullptr && n >= 0 && (n == 0 || to_sparse != nullptr), "bad arguments");
+        std::unique_ptr<ibh_sparse_set> s(new ibh_sparse_set);
+        s->sparse_extent = sparse_extent;
+        s->to_sparse.assign(to_sparse, to_sparse + n);
+        s->to_dense_map.reserve((size_t)n * 2);
+        for (int32_t i = 0; i < n; ++i) {
+            IBH_CHECK(to_sparse[i] >= 0 && (sparse_extent < 0 || to_sparse[i] < sparse_extent),
+                      "sparse index %ld outside extent %ld", (long)to_sparse[i], (long)sparse_extent);
+            IBH_CHECK(s->to_dense_map.emplace(to_sparse[i], i).second, "duplicate sparse index %ld", (long)to_sparse[i]);
+        }
+        *out = s.release();
+    });
+}
+int ibh_sparse_set_destroy(ibh_sparse_set *s) { delete s; return IBH_OK; }
+int ibh_sparse_set_sparse_extent(const ibh_sparse_set *s, int64_t *out) {
+    return guarded([&] { IBH_CHECK(s && out, "null argument"); *out = s->sparse_extent; });
+}
+int ibh_sparse_set_dense_extent(const ibh_sparse_set *s, int32_t *out) {
+    return guarded([&] { IBH_CHECK(s && out, "null argument"); *out = s->dense_extent(); });
+}
+int ibh_sparse_set_to_sparse(const ibh_sparse_set *s, int64_t *out) {
+    return guarded([&] {
+        IBH_CHECK(s && (out || s->to_sparse.empty()), "null argument");
+        std::copy(s->to_sparse.begin(), s->to_sparse.end(), out);
+    });
+}
+
+// ---- Regridder -----------------------------------------------------------------------------
+int ibh_regridder_create(const ibh_regridder_desc *d, ibh_regridder **out) {
+    return guarded([&] {
+        IBH_CHECK(d && out, "null argument");
+        require_device();
+        IBH_CHECK(d->nX >= 0 && d->nX < (1ll << 31) - 1, "nX=%ld out of range", (long)d->nX);
+        IBH_CHECK(d->nI > 0 && d->nI < (1ll << 31), "nI=%ld out of range", (long)d->nI);
+        IBH_CHECK(d->nA > 0 && d->nA < (1ll << 31), "nA=%ld out of range", (long)d->nA);
+        IBH_CHECK(d->nA_dense >= 0 && d->nhc >= 0, "negative size");
+        IBH_CHECK(d->nA * (int64_t)(d->nhc > 0 ? d->nhc : 1) < (1ll << 31), "nE = nA*nhc overflows int32 dense ids");
+        IBH_CHECK(d->nX == 0 || (d->ex_indices && d->ex_area), "null exchange grid arrays");
+        IBH_CHECK(d->nA_dense == 0 || (d->A_to_sparse && d->A_native_area && d->A_proj_area), "null A grid arrays");
+        IBH_CHECK(d->interp_style == 0 || d->interp_style == 1, "unknown interp_style %d", d->interp_style);
+        if (d->nhc > 0) {
+            IBH_CHECK(d->hcdefs != nullptr, "null hcdefs");
+            for (int k = 1; k < d->nhc; ++k) IBH_CHECK(d->hcdefs[k] > d->hcdefs[k - 1], "hcdefs must be ascending");
+            const bool hc_slowest = d->hc_stride_A == 1 && d->hc_stride_HC == d->nA;
+            const bool hc_fastest = d->hc_stride_HC == 1 && d->hc_stride_A == d->nhc;
+            IBH_CHECK(hc_slowest || hc_fastest,
+                      "indexingHC strides (%ld,%ld) are neither (1,nA) nor (nhc,1)", (long)d->hc_stride_A, (long)d->hc_stride_HC);
+        }
+        std::unique_ptr<ibh_regridder> g(new ibh_regridder);
+        IBH_HIP(hipGetDevice(&g->device));
+        g->nX = d->nX; g->nI = d->nI; g->nA = d->nA; g->nA_dense = d->nA_dense; g->nhc = d->nhc;
+        g->interp_style = d->interp_style; g->hc_stride_A = d->hc_stride_A; g->hc_stride_HC = d->hc_stride_HC;
+        g->A_to_sparse.assign(d->A_to_sparse, d->A_to_sparse + d->nA_dense);
+        g->A_native.assign(d->A_native_area, d->A_native_area + d->nA_dense);
+        g->A_proj.assign(d->A_proj_area, d->A_proj_area + d->nA_dense);
+        g->hcdefs_h.assign(d->hcdefs, d->hcdefs + d->nhc);
+        // ratio native/proj by sparse A index (the diagonal of sApvA, IceRegridder.cpp:41-48)
+        std::vector<double> ratio((size_t)d->nA, 0.0);
+        for (int32_t id = 0; id < d->nA_dense; ++id) {
+            const int64_t s = d->A_to_sparse[id];
+            IBH_CHECK(s >= 0 && s < d->nA, "A_to_sparse[%d]=%ld outside [0,%ld)", id, (long)s, (long)d->nA);
+            IBH_CHECK(ratio[(size_t)s] == 0.0, "duplicate atmosphere cell %ld", (long)s);
+            const double r = d->A_native_area[id] / d->A_proj_area[id];
+            IBH_CHECK(std::isfinite(r) && r > 0, "atmosphere cell %ld: native/proj area ratio %g is not positive", (long)s, r);
+            ratio[(size_t)s] = r;
+        }
+        for (int64_t x = 0; x < d->nX; ++x) {
+            const int32_t iA = d->ex_indices[2 * x], iI = d->ex_indices[2 * x + 1];
+            IBH_CHECK(iA >= 0 && iA < d->nA && iI >= 0 && iI < d->nI, "exchange cell %ld: (iA,iI)=(%d,%d) out of range", (long)x, iA, iI);
+            IBH_CHECK(ratio[(size_t)iA] != 0.0, "exchange cell %ld overlaps atmosphere cell %d, which is not in agridA", (long)x, iA);
+        }
+        g->ex_indices.upload(d->ex_indices, (size_t)(2 * d->nX));
+        g->ex_area.upload(d->ex_area, (size_t)d->nX);
+        g->hcdefs.upload(d->hcdefs, (size_t)d->nhc);
+        g->A_ratio_s.upload(ratio.data(), ratio.size());
+        IBH_HIP(hipStreamSynchronize(nullptr));
+        *out = g.release();
+    });
+}
+int ibh_regridder_destroy(ibh_regridder *rg) { delete rg; return IBH_OK; }
+int ibh_regridder_sizes(const ibh_regridder *g, int64_t *nA, int64_t *nE, int64_t *nI, int64_t *nX, int32_t *nhc) {
+    return guarded([&] {
+        IBH_CHECK(g != nullptr, "null argument");
+        if (nA) *nA = g->nA;
+        if (nE) *nE = g->nA * (int64_t)g->nhc;      // GCMRegridder.hpp:273
+        if (nI) *nI = g->nI;
+        if (nX) *nX = g->nX;
+        if (nhc) *nhc = g->nhc;
+    });
+}
+int ibh_regridder_wA(const ibh_regridder *g, int native, double fill, double *out) {
+    return guarded([&] {
+        IBH_CHECK(g && out, "null argument");
+        std::fill(out, out + g->nA, fill);
+        const auto &areas = native ? g->A_native : g->A_proj;
+        for (int32_t id = 0; id < g->nA_dense; ++id) out[g->A_to_sparse[(size_t)id]] = areas[(size_t)id];
+    });
+}
+
+// ---- RegridMatrices ------------------------------------------------------------------------
+int ibh_regrid_matrices_create(const ibh_regridder *rg, const double *elevmaskI, int64_t n, int scale, int correctA,
+                               const double sigma[3], ibh_regrid_matrices **out) {
+    return guarded([&] {
+        IBH_CHECK(rg && elevmaskI && out, "null argument");
+        // np_to_blitz shape check {nI}, icebin_cython.cpp:231
+        IBH_CHECK(n == rg->nI, "elevmaskI has %ld elements, the ice grid has nI=%ld", (long)n, (long)rg->nI);
+        int dev = -1;
+        IBH_HIP(hipGetDevice(&dev));
+        IBH_CHECK(dev == rg->device, "regridder belongs to device %d, current device is %d", rg->device, dev);
+        std::unique_ptr<ibh_regrid_matrices> rm(new ibh_regrid_matrices);
+        rm->rg = rg;
+        rm->scale = scale; rm->correctA = correctA;
+        if (sigma) for (int k = 0; k < 3; ++k) rm->sigma[k] = sigma[k];
+        rm->elevmaskI.upload(elevmaskI, (size_t)n);
+        IBH_HIP(hipStreamSynchronize(nullptr));
+        *out = rm.release();
+    });
+}
+int ibh_regrid_matrices_destroy(ibh_regrid_matrices *rm) { delete rm; return IBH_OK; }
+
+int ibh_regrid_matrices_matrix_d(const ibh_regrid_matrices *rm, const char *spec, ibh_sparse_set *dim0,
+                                 ibh_sparse_set *dim1, int scale, int correctA, const double sigma[3],
+                                 ibh_weighted **out) {
+    return guarded([&] {
+        IBH_CHECK(rm && spec && out, "null argument");
+        IBH_CHECK(dim0 == nullptr || dim0 != dim1, "dims[0] and dims[1] must be distinct sets");
+        assemble_matrix(rm, spec, dim0, dim1, scale, correctA, sigma, out);
+    });
+}
+int ibh_regrid_matrices_matrix(const ibh_regrid_matrices *rm, const char *spec, ibh_weighted **out) {
+    return guarded([&] {
+        IBH_CHECK(rm && spec && out, "null argument");
+        assemble_matrix(rm, spec, nullptr, nullptr, rm->scale, rm->correctA, rm->sigma, out);
+    });
+}
+
+// ---- Weighted ------------------------------------------------------------------------------
+static std::unique_ptr<ibh_weighted> new_loaded(int32_t nrow, int32_t ncol, const double *wM, const double *Mw,
+                                                int conservative, int scaled) {
+    require_device();
+    IBH_CHECK(nrow >= 0 && ncol >= 0, "negative shape");
+    IBH_CHECK((nrow == 0 || wM) && (ncol == 0 || Mw), "null weight vector");
+    std::unique_ptr<ibh_weighted> w(new ibh_weighted);
+    IBH_HIP(hipGetDevice(&w->device));
+    w->nrow = nrow; w->ncol = ncol;
+    w->conservative = conservative; w->scaled = scaled;
+    for (int k = 0; k < 2; ++k) { w->dims[k] = new ibh_sparse_set; w->owns[k] = true; }
+    make_identity(w->dims[0], nrow);
+    make_identity(w->dims[1], ncol);
+    w->wM.upload(wM, (size_t)nrow);
+    w->Mw.upload(Mw, (size_t)ncol);
+    return w;
+}
+
+int ibh_weighted_from_coo(int32_t nrow, int32_t ncol, int64_t nnz, const int32_t *row, const int32_t *col,
+                          const double *val, const double *wM, const double *Mw, int conservative, int scaled,
+                          ibh_weighted **out) {
+    return guarded([&] {
+        IBH_CHECK(out != nullptr && nnz >= 0 && nnz < (1ll << 31), "bad nnz %ld", (long)nnz);
+        IBH_CHECK(nnz == 0 || (row && col && val), "null triplet arrays");
+        for (int64_t k = 0; k < nnz; ++k)
+            IBH_CHECK(row[k] >= 0 && row[k] < nrow && col[k] >= 0 && col[k] < ncol,
+                      "triplet %ld: (%d,%d) outside %d x %d", (long)k, row[k], col[k], nrow, ncol);
+        auto w = new_loaded(nrow, ncol, wM, Mw, conservative, scaled);
+        weighted_from_coo_device(w.get(), nrow, ncol, nnz, row, col, val);
+        *out = w.release();
+    });
+}
+int ibh_weighted_from_csr(int32_t nrow, int32_t ncol, const int32_t *rowptr, const int32_t *colind, const double *val,
+                          const double *wM, const double *Mw, int conservative, int scaled, ibh_weighted **out) {
+    return guarded([&] {
+        IBH_CHECK(out && rowptr, "null argument");
+        IBH_CHECK(rowptr[0] == 0, "rowptr[0] must be 0");
+        for (int32_t r = 0; r < nrow; ++r) IBH_CHECK(rowptr[r + 1] >= rowptr[r], "rowptr not monotone at row %d", r);
+        const int64_t nnz = rowptr[nrow];
+        IBH_CHECK(nnz == 0 || (colind && val), "null CSR arrays");
+        for (int64_t k = 0; k < nnz; ++k) IBH_CHECK(colind[k] >= 0 && colind[k] < ncol, "colind[%ld]=%d outside [0,%d)", (long)k, colind[k], ncol);
+        auto w = new_loaded(nrow, ncol, wM, Mw, conservative, scaled);
+        w->nnz = nnz;
+        w->rowptr.upload(rowptr, (size_t)nrow + 1);
+        w->colind.upload(colind, (size_t)nnz);
+        w->val.upload(val, (size_t)nnz);
+        IBH_HIP(hipStreamSynchronize(nullptr));
+        *out = w.release();
+    });
+}
+int ibh_weighted_destroy(ibh_weighted *w) { delete w; return IBH_OK; }
+
+int ibh_weighted_shape(const ibh_weighted *w, int32_t *nrow, int32_t *ncol, int64_t *nnz) {
+    return guarded([&] {
+        IBH_CHECK(w != nullptr, "null argument");
+        if (nrow) *nrow = w->nrow;
+        if (ncol) *ncol = w->ncol;
+        if (nnz) *nnz = w->nnz;
+    });
+}
+int ibh_weighted_flags(const ibh_weighted *w, int *conservative, int *scaled) {
+    return guarded([&] {
+        IBH_CHECK(w != nullptr, "null argument");
+        if (conservative) *conservative = w->conservative;
+        if (scaled) *scaled = w->scaled;
+    });
+}
+int ibh_weighted_dim(const ibh_weighted *w, int k, int64_t *sparse_extent, int32_t *dense_extent) {
+    return guarded([&] {
+        IBH_CHECK(w && (k == 0 || k == 1), "bad argument");
+        if (sparse_extent) *sparse_extent = w->dims[k]->sparse_extent;
+        if (dense_extent) *dense_extent = k == 0 ? w->nrow : w->ncol;
+    });
+}
+int ibh_weighted_dim_to_sparse(const ibh_weighted *w, int k, int64_t *out) {
+    return guarded([&] {
+        IBH_CHECK(w && (k == 0 || k == 1), "bad argument");
+        // a shared dims set may have grown after this matrix was built: report this matrix's extent
+        const int32_t n = k == 0 ? w->nrow : w->ncol;
+        IBH_CHECK(n == 0 || out, "null output");
+        std::copy(w->dims[k]->to_sparse.begin(), w->dims[k]->to_sparse.begin() + n, out);
+    });
+}
+int ibh_weighted_get_wM(const ibh_weighted *w, double *out) {
+    return guarded([&] { check_weighted_device(w); w->wM.download(out, (size_t)w->nrow); });
+}
+int ibh_weighted_get_Mw(const ibh_weighted *w, double *out) {
+    return guarded([&] { check_weighted_device(w); w->Mw.download(out, (size_t)w->ncol); });
+}
+int ibh_weighted_get_csr(const ibh_weighted *w, int32_t *rowptr, int32_t *colind, double *val) {
+    return guarded([&] {
+        check_weighted_device(w);
+        if (rowptr) w->rowptr.download(rowptr, (size_t)w->nrow + 1);
+        if (colind) w->colind.download(colind, (size_t)w->nnz);
+        if (val) w->val.download(val, (size_t)w->nnz);
+    });
+}
+int ibh_weighted_get_coo(const ibh_weighted *w, int32_t *row, int32_t *col, double *val) {
+    return guarded([&] {
+        check_weighted_device(w);
+        if (row) {
+            std::vector<int32_t> rp((size_t)w->nrow + 1);
+            w->rowptr.download(rp.data(), rp.size());
+            for (int32_t r = 0; r < w->nrow; ++r)
+                for (int32_t k = rp[(size_t)r]; k < rp[(size_t)r + 1]; ++k) row[k] = r;
+        }
+        if (col) w->colind.download(col, (size_t)w->nnz);
+        if (val) w->val.download(val, (size_t)w->nnz);
+    });
+}
+
+int ibh_weighted_apply_device(const ibh_weighted *w, const double *dA, int32_t nvar, int64_t lda, double *dB,
+                              int64_t ldb, double fill, int force_conservation, void *stream) {
+    return guarded([&] {
+        check_weighted_device(w);
+        IBH_CHECK(nvar >= 0 && (nvar == 0 || (dA && dB)), "bad arguments");
+        spmm_launch(w, dA, nvar, lda, dB, ldb, fill, force_conservation, static_cast<hipStream_t>(stream));
+    });
+}
+int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nvar, int64_t lda, double *B_b,
+                            int64_t ldb, double fill, int force_conservation) {
+    return guarded([&] {
+        check_weighted_device(w);
+        IBH_CHECK(nvar >= 0 && (nvar == 0 || (A_b && B_b)), "bad arguments");
+        IBH_CHECK(lda >= w->ncol && ldb >= w->nrow, "leading dimensions too small");
+        if (nvar == 0) return;
+        DevBuf<double> dA((size_t)nvar * (size_t)w->ncol), dB((size_t)nvar * (size_t)w->nrow);
+        IBH_HIP(hipMemcpy2DAsync(dA.p, sizeof(double) * (size_t)w->ncol, A_b, sizeof(double) * (size_t)lda,
+                                 sizeof(double) * (size_t)w->ncol, (size_t)nvar, hipMemcpyHostToDevice, nullptr));
+        spmm_launch(w, dA.p, nvar, w->ncol, dB.p, w->nrow, fill, force_conservation, nullptr);
+        IBH_HIP(hipMemcpy2DAsync(B_b, sizeof(double) * (size_t)ldb, dB.p, sizeof(double) * (size_t)w->nrow,
+                                 sizeof(double) * (size_t)w->nrow, (size_t)nvar, hipMemcpyDeviceToHost, nullptr));
+        IBH_HIP(hipStreamSynchronize(nullptr));
+    });
+}
+int ibh_weighted_apply_weight_host(const ibh_weighted *w, int dim, const double *A_b, int32_t nvar, int64_t lda,
+                                   double *out) {
+    return guarded([&] {
+        check_weighted_device(w);
+        IBH_CHECK((dim == 0 || dim == 1) && nvar >= 0 && (nvar == 0 || (A_b && out)), "bad arguments");
+        const int n = dim == 0 ? w->nrow : w->ncol;
+        IBH_CHECK(lda >= n, "leading dimension too small");
+        if (nvar == 0) return;
+        DevBuf<double> dA((size_t)nvar * (size_t)n), dout((size_t)nvar);
+        IBH_HIP(hipMemcpy2DAsync(dA.p, sizeof(double) * (size_t)n, A_b, sizeof(double) * (size_t)lda,
+                                 sizeof(double) * (size_t)n, (size_t)nvar, hipMemcpyHostToDevice, nullptr));
+        weight_dot_launch(dim == 0 ? w->wM.p : w->Mw.p, n, dA.p, nvar, n, dout.p, nullptr);
+        dout.download(out, (size_t)nvar);
+    });
+}
+
+int ibh_weighted_device_view_get(const ibh_weighted *w, ibh_weighted_device_view *out) {
+    return guarded([&] {
+        IBH_CHECK(w && out, "null argument");
+        *out = ibh_weighted_device_view{w->nrow, w->ncol, w->nnz, w->rowptr.p, w->colind.p, w->val.p, w->wM.p, w->Mw.p};
+    });
+}
+
+int ibh_weighted_set_kernel(ibh_weighted *w, const char *name) {
+    return guarded([&] {
+        IBH_CHECK(w && name, "null argument");
+        if (!strcmp(name, "auto")) w->kernel_override = 0;
+        else if (!strcmp(name, "rowblock")) w->kernel_override = 1;
+        else if (!strcmp(name, "shortrow")) w->kernel_override = 2;
+        else fail(IBH_EINVAL, "unknown kernel '%s'", name);
+    });
+}
+int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen) {
+    return guarded([&] {
+        IBH_CHECK(w && buf && buflen > 0, "bad argument");
+        snprintf(buf, (size_t)buflen, "%s", w->last_kernel == 1 ? "rowblock" : w->last_kernel == 2 ? "shortrow" : "none");
+    });
+}
+int ibh_set_tuning(const char *key, int value) {
+    return guarded([&] { IBH_CHECK(key != nullptr, "null key"); set_tuning(key, value); });
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+// common.h -- internal helpers of libicebin_hip.so (error channel, device buffers, handle layouts).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/icebin_hip.h"
+
+namespace ibh {
+
+// ---- error channel -------------------------------------------------------------------------
+struct Error : std::exception {
+    int code;
+    std::string msg;
+    Error(int c, std::string m) : code(c), msg(std::move(m)) {}
+    const char *what() const noexcept override { return msg.c_str(); }
+};
+[[noreturn]] void fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void set_last_error(const char *msg);
+
+#define IBH_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            ::ibh::fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? IBH_ENODEVICE : IBH_EHIP, \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define IBH_CHECK(cond, ...)                                  \
+    do {                                                      \
+        if (!(cond)) ::ibh::fail(IBH_EINVAL, __VA_ARGS__);    \
+    } while (0)
+
+// Wrap a C-ABI body: exceptions -> status code + thread-local message.
+template <class F>
+int guarded(F &&f) noexcept {
+    try {
+        f();
+        return IBH_OK;
+    } catch (const Error &e) {
+        set_last_error(e.msg.c_str());
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        set_last_error("out of host memory");
+        return IBH_EINVAL;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return IBH_EINVAL;
+    }
+}
+
+// ---- device memory -------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        IBH_HIP(hipMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T)));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    void upload(const T *host, size_t count, hipStream_t s = nullptr) {
+        if (count > n || !p) alloc(count);
+        if (count) IBH_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void download(T *host, size_t count, hipStream_t s = nullptr) const {
+        if (count) IBH_HIP(hipMemcpyAsync(host, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+        IBH_HIP(hipStreamSynchronize(s));
+    }
+    void zero(hipStream_t s = nullptr) { if (n) IBH_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+inline int bits_for(uint64_t n) {   // bits needed to represent values in [0, n)
+    int b = 0;
+    while (b < 64 && (n > (1ull << b))) ++b;
+    return b;
+}
+
+}  // namespace ibh
+
+// ---- handle layouts (opaque to the C-ABI user) ----------------------------------------------
+struct ibh_sparse_set {
+    int64_t sparse_extent = -1;
+    std::vector<int64_t> to_sparse;                       // dense -> sparse, first-seen order
+    std::unordered_map<int64_t, int32_t> to_dense_map;    // host lookup
+    bool identity = false;                                // to_sparse[i] == i for all i (no map kept)
+    int32_t dense_extent() const { return (int32_t)to_sparse.size(); }
+};
+
+struct ibh_regridder {
+    int device = 0;
+    int64_t nX = 0, nI = 0, nA = 0;
+    int32_t nA_dense = 0, nhc = 0, interp_style = 0;
+    int64_t hc_stride_A = 1, hc_stride_HC = 0;
+    ibh::DevBuf<int32_t> ex_indices;    // [2*nX]
+    ibh::DevBuf<double> ex_area;        // [nX]
+    ibh::DevBuf<double> hcdefs;         // [nhc]
+    ibh::DevBuf<double> A_ratio_s;      // [nA] native/proj by SPARSE A index, 0 where A cell not realised
+    std::vector<int64_t> A_to_sparse;   // host copies for wA()
+    std::vector<double> A_native, A_proj, hcdefs_h;
+    double hc_last = 0;
+};
+
+struct ibh_regrid_matrices {
+    const ibh_regridder *rg = nullptr;
+    ibh::DevBuf<double> elevmaskI;      // [nI] copy (RegridMatrices_Dynamic.cpp:352)
+    int scale = 1, correctA = 0;
+    double sigma[3] = {0, 0, 0};
+};
+
+struct ibh_weighted {
+    int device = 0;
+    int32_t nrow = 0, ncol = 0;
+    int64_t nnz = 0;
+    ibh::DevBuf<int32_t> rowptr, colind;
+    ibh::DevBuf<double> val, wM, Mw;
+    ibh_sparse_set *dims[2] = {nullptr, nullptr};
+    bool owns[2] = {false, false};
+    int conservative = 1, scaled = 1;
+    // SpMM dispatch
+    int kernel_override = 0;            // 0 auto, 1 rowblock, 2 shortrow
+    mutable int last_kernel = 0;
+    int32_t max_row_nnz = 0;
+    ~ibh_weighted() {
+        for (int k = 0; k < 2; ++k)
+            if (owns[k]) delete dims[k];
+    }
+};
+
+namespace ibh {
+// spmm.hip
+void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda, double *dB, int64_t ldb,
+                 double fill, int force_conservation, hipStream_t stream);
+void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int64_t lda, double *dout,
+                       hipStream_t stream);
+int get_tuning(const char *key, int dflt);
+void set_tuning(const char *key, int value);
+}  // namespace ibh

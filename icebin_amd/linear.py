@@ -1,0 +1,237 @@
+"""linear_Weighted: the Python face of ibmisc::linear::Weighted (sphinx/source/matrix_formats.rst:121-195),
+and SparseSet (spsparse::SparseSet<long,int>), both thin handles over the C-ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, lib, ptr
+
+
+class SparseSet:
+    """spsparse::SparseSet<long,int>: dense ids handed out first-seen (eigen_types.hpp:24)."""
+
+    def __init__(self, sparse_extent=-1, to_sparse=None, _handle=None):
+        h = C.c_void_p()
+        if _handle is not None:
+            h = _handle
+        elif to_sparse is None:
+            check(lib().ibh_sparse_set_create(int(sparse_extent), C.byref(h)))
+        else:
+            a = np.ascontiguousarray(to_sparse, np.int64)
+            check(lib().ibh_sparse_set_from_array(int(sparse_extent), ptr(a), len(a), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def identity(cls, n):
+        """ibmisc id_sparse_set(n) (modele/merge_topo.cpp:48, IceCoupler.cpp:366)."""
+        h = C.c_void_p()
+        check(lib().ibh_sparse_set_create_identity(int(n), C.byref(h)))
+        return cls(_handle=h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().ibh_sparse_set_destroy(self._h)
+            self._h = None
+
+    def sparse_extent(self):
+        v = C.c_int64()
+        check(lib().ibh_sparse_set_sparse_extent(self._h, C.byref(v)))
+        return v.value
+
+    def dense_extent(self):
+        v = C.c_int32()
+        check(lib().ibh_sparse_set_dense_extent(self._h, C.byref(v)))
+        return v.value
+
+    def to_sparse(self):
+        out = np.empty(self.dense_extent(), np.int64)
+        check(lib().ibh_sparse_set_to_sparse(self._h, ptr(out)))
+        return out
+
+
+class linear_Weighted:
+    """A regrid matrix M plus its two weight vectors, resident in HBM.
+
+    Mirrors ibmisc.linear_Weighted (matrix_formats.rst:139-195): apply_M, apply_weight, apply_wM,
+    apply_Mw, to_coo, get_weights, shape; plus the C++ members of linear::Weighted_Eigen the IceBin
+    callers touch (dims, wM, Mw, conservative, scaled, apply()).
+    """
+
+    def __init__(self, handle, keep=()):
+        self._h = handle
+        self._keep = keep          # objects that must outlive the handle (shared dims, regridder)
+        nrow, ncol, nnz = C.c_int32(), C.c_int32(), C.c_int64()
+        check(lib().ibh_weighted_shape(handle, C.byref(nrow), C.byref(ncol), C.byref(nnz)))
+        self.nrow_d, self.ncol_d, self.nnz = nrow.value, ncol.value, nnz.value
+        cons, sc = C.c_int(), C.c_int()
+        check(lib().ibh_weighted_flags(handle, C.byref(cons), C.byref(sc)))
+        self.conservative, self.scaled = bool(cons.value), bool(sc.value)
+        self._dims = [None, None]
+        self._sparse_extents = [None, None]
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().ibh_weighted_destroy(self._h)
+            self._h = None
+
+    # ---- loaders -------------------------------------------------------------------------
+    @classmethod
+    def from_coo(cls, shape, row, col, val, wM, Mw, conservative=True, scaled=True):
+        """Dense-indexed triplets -> Weighted (to_eigen_M, eigen_types.cpp:9-34 / nc_read_weighted)."""
+        row = np.ascontiguousarray(row, np.int32)
+        col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, np.float64)
+        wM = np.ascontiguousarray(wM, np.float64)
+        Mw = np.ascontiguousarray(Mw, np.float64)
+        assert len(row) == len(col) == len(val) and len(wM) == shape[0] and len(Mw) == shape[1]
+        h = C.c_void_p()
+        check(lib().ibh_weighted_from_coo(shape[0], shape[1], len(val), ptr(row), ptr(col), ptr(val), ptr(wM), ptr(Mw),
+                                         int(conservative), int(scaled), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_csr(cls, shape, rowptr, colind, val, wM, Mw, conservative=True, scaled=True):
+        rowptr = np.ascontiguousarray(rowptr, np.int32)
+        colind = np.ascontiguousarray(colind, np.int32)
+        val = np.ascontiguousarray(val, np.float64)
+        wM = np.ascontiguousarray(wM, np.float64)
+        Mw = np.ascontiguousarray(Mw, np.float64)
+        assert len(rowptr) == shape[0] + 1 and len(wM) == shape[0] and len(Mw) == shape[1]
+        h = C.c_void_p()
+        check(lib().ibh_weighted_from_csr(shape[0], shape[1], ptr(rowptr), ptr(colind), ptr(val), ptr(wM), ptr(Mw),
+                                         int(conservative), int(scaled), C.byref(h)))
+        return cls(h)
+
+    # ---- members -------------------------------------------------------------------------
+    def dim(self, k):
+        """dims[k]: dense -> sparse index table of this matrix (int64[dense_extent])."""
+        if self._dims[k] is None:
+            n = self.nrow_d if k == 0 else self.ncol_d
+            out = np.empty(n, np.int64)
+            check(lib().ibh_weighted_dim_to_sparse(self._h, k, ptr(out)))
+            ext = C.c_int64()
+            check(lib().ibh_weighted_dim(self._h, k, C.byref(ext), None))
+            self._dims[k], self._sparse_extents[k] = out, ext.value
+        return self._dims[k]
+
+    def sparse_extent(self, k):
+        self.dim(k)
+        return self._sparse_extents[k]
+
+    @property
+    def shape(self):
+        """Sparse shape of the matrix."""
+        return (self.sparse_extent(0), self.sparse_extent(1))
+
+    @property
+    def wM(self):
+        out = np.empty(self.nrow_d, np.float64)
+        check(lib().ibh_weighted_get_wM(self._h, ptr(out)))
+        return out
+
+    @property
+    def Mw(self):
+        out = np.empty(self.ncol_d, np.float64)
+        check(lib().ibh_weighted_get_Mw(self._h, ptr(out)))
+        return out
+
+    def get_weights(self, dim):
+        """Weight vector in the sparse space (0 = B/output, 1 = A/input); zero where unset."""
+        out = np.zeros(self.sparse_extent(dim), np.float64)
+        out[self.dim(dim)] = self.wM if dim == 0 else self.Mw
+        return out
+
+    def coo_dense(self):
+        """(row_d, col_d, val) in row-major order, dense index spaces."""
+        row = np.empty(self.nnz, np.int32)
+        col = np.empty(self.nnz, np.int32)
+        val = np.empty(self.nnz, np.float64)
+        check(lib().ibh_weighted_get_coo(self._h, ptr(row), ptr(col), ptr(val)))
+        return row, col, val
+
+    def csr_dense(self):
+        rowptr = np.empty(self.nrow_d + 1, np.int32)
+        col = np.empty(self.nnz, np.int32)
+        val = np.empty(self.nnz, np.float64)
+        check(lib().ibh_weighted_get_csr(self._h, ptr(rowptr), ptr(col), ptr(val)))
+        return rowptr, col, val
+
+    def to_coo(self):
+        """scipy.sparse.coo_matrix in the ORIGINAL sparse index spaces (matrix_formats.rst:188-192)."""
+        import scipy.sparse
+        row, col, val = self.coo_dense()
+        return scipy.sparse.coo_matrix((val, (self.dim(0)[row], self.dim(1)[col])), shape=self.shape)
+
+    # ---- products ------------------------------------------------------------------------
+    def apply(self, A_b, fill=np.nan, force_conservation=True):
+        """Weighted_Eigen::apply(A_b, fill, force_conservation, tmp) in DENSE index spaces
+        (modele/merge_topo.cpp:65, modele/icebin22m.cpp:153).  A_b: [ncol_d] or [nvar, ncol_d]."""
+        A = np.ascontiguousarray(np.atleast_2d(A_b), np.float64)
+        if A.shape[1] != self.ncol_d:
+            raise ValueError("apply: input has %d columns, matrix has %d dense columns" % (A.shape[1], self.ncol_d))
+        B = np.empty((A.shape[0], self.nrow_d), np.float64)
+        check(lib().ibh_weighted_apply_host(self._h, ptr(A), A.shape[0], A.shape[1], ptr(B), B.shape[1], float(fill),
+                                           int(force_conservation)))
+        return B if np.ndim(A_b) == 2 else B[0]
+
+    def apply_device(self, dA, out=None, fill=float("nan"), force_conservation=True, stream=None):
+        """Same on fields already resident in HBM: dA is a torch.float64 CUDA tensor [nvar, ncol_d]
+        (row stride >= ncol_d); only enqueues work on `stream` (default: torch's current stream)."""
+        import torch
+        assert dA.is_cuda and dA.dtype == torch.float64 and dA.dim() == 2 and dA.stride(1) == 1
+        assert dA.shape[1] == self.ncol_d
+        nvar = dA.shape[0]
+        if out is None:
+            out = torch.empty((nvar, self.nrow_d), dtype=torch.float64, device=dA.device)
+        assert out.is_cuda and out.dtype == torch.float64 and out.shape == (nvar, self.nrow_d) and out.stride(1) == 1
+        s = torch.cuda.current_stream(dA.device).cuda_stream if stream is None else stream
+        check(lib().ibh_weighted_apply_device(self._h, C.c_void_p(dA.data_ptr()), nvar, dA.stride(0) if nvar > 1 else max(dA.stride(0), self.ncol_d),
+                                             C.c_void_p(out.data_ptr()), out.stride(0) if nvar > 1 else max(out.stride(0), self.nrow_d),
+                                             float(fill), int(force_conservation), C.c_void_p(s)))
+        return out
+
+    def apply_M(self, A_s, fill=np.nan, force_conservation=True):
+        """Applies the regrid matrix to A_s (vectors in the ORIGINAL sparse space of the input grid):
+        a 1-D vector or a 2-D array of row vectors; un-set output cells get `fill`
+        (matrix_formats.rst:156-165)."""
+        A = np.asarray(A_s, np.float64)
+        one = A.ndim == 1
+        A2 = A.reshape(1, -1) if one else A.reshape(A.shape[0], -1)
+        if A2.shape[1] != self.sparse_extent(1):
+            raise ValueError("apply_M: input has %d cells, the input grid has %d" % (A2.shape[1], self.sparse_extent(1)))
+        B_d = self.apply(np.ascontiguousarray(A2[:, self.dim(1)]), fill, force_conservation)
+        B_s = np.full((A2.shape[0], self.sparse_extent(0)), fill, np.float64)
+        B_s[:, self.dim(0)] = B_d
+        return B_s[0] if one else B_s
+
+    def apply_weight(self, dim, A_s):
+        """Dot product of a weight vector with A_s (dim 0: wM / output grid, 1: Mw / input grid)."""
+        A = np.asarray(A_s, np.float64)
+        one = A.ndim == 1
+        A2 = A.reshape(1, -1) if one else A.reshape(A.shape[0], -1)
+        if A2.shape[1] != self.sparse_extent(dim):
+            raise ValueError("apply_weight: input has %d cells, expected %d" % (A2.shape[1], self.sparse_extent(dim)))
+        A_d = np.ascontiguousarray(A2[:, self.dim(dim)])
+        out = np.empty(A_d.shape[0], np.float64)
+        check(lib().ibh_weighted_apply_weight_host(self._h, dim, ptr(A_d), A_d.shape[0], A_d.shape[1], ptr(out)))
+        return out[0] if one else out
+
+    def apply_wM(self, A_s):
+        return self.apply_weight(0, A_s)
+
+    def apply_Mw(self, A_s):
+        return self.apply_weight(1, A_s)
+
+    # ---- tuning / introspection ----------------------------------------------------------
+    def set_kernel(self, name):
+        check(lib().ibh_weighted_set_kernel(self._h, name.encode()))
+
+    def last_kernel(self):
+        buf = C.create_string_buffer(32)
+        check(lib().ibh_weighted_last_kernel(self._h, buf, 32))
+        return buf.value.decode()
+
+
+def set_tuning(key, value):
+    check(lib().ibh_set_tuning(key.encode(), int(value)))

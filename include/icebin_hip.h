@@ -1,0 +1,185 @@
+/*
+ * icebin_hip.h -- C-ABI of libicebin_hip.so, the MI355X (gfx950) implementation
+ * of IceBin's conservative-regridding hot path.
+ *
+ * This is the drop-in boundary: plain C, opaque handles, plain
+ * pointers and sizes, int status codes.  Every entry point replaces one piece
+ * of the reference's C++ interface, cited as file:line under /root/reference.
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md;
+ * icebin_amd/host/ (C++) and the icebin_amd Python package (ctypes) are two users of it.
+ *
+ * Conventions
+ *   - All functions return IBH_OK (0) or a negative IBH_E* code; the message is
+ *     available from ibh_last_error() (thread-local).  This replaces
+ *     (*icebin_error)(-1, fmt, ...) (slib/icebin/error.hpp:28-32): the host
+ *     wrappers re-throw it as a C++ exception / Python RuntimeError.
+ *   - Host arrays are borrowed for the duration of the call only.
+ *   - "_d" = dense (renumbered) index, "_s" = sparse (native) index
+ *     (sphinx/source/sparse_matrices.rst).  Dense ids are int32, sparse ids
+ *     int64, values double (slib/icebin/eigen_types.hpp:16-18).
+ *   - Fields ("variables") are stored field-major: A_b[k*lda + j], the
+ *     blitz::Array<double,2>(nvar, n) layout of modele/icebin22m.cpp:142.
+ *   - Single-threaded per handle; the stream argument is a hipStream_t passed
+ *     as void* (NULL = the default stream).  The library uses the current HIP
+ *     device of the calling thread; handles are bound to the device they were
+ *     created on.
+ *   - There is no CPU fallback: without a HIP device every compute entry
+ *     point fails with IBH_ENODEVICE.
+ */
+#ifndef ICEBIN_HIP_H
+#define ICEBIN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IBH_OK          0
+#define IBH_EINVAL     -1   /* bad argument / inconsistent sizes                       */
+#define IBH_ENODEVICE  -2   /* no usable HIP device                                    */
+#define IBH_EHIP       -3   /* a HIP runtime call failed                               */
+#define IBH_ERANGE     -4   /* elevation above the last height class                   */
+                            /*   (IceRegridder_L0.cpp:84-85)                           */
+#define IBH_ENOTIMPL   -5   /* feature outside the hot-path scope (sigma != 0)         */
+#define IBH_ENOKEY     -6   /* unknown matrix name (regrids.at(), RegridMatrices_Dynamic.cpp:419) */
+
+const char *ibh_last_error(void);
+/* Library / device info.  ibh_device_count does not initialise the GPU context. */
+int ibh_version(void);
+int ibh_device_count(int *count);
+int ibh_set_device(int device);
+
+/* ------------------------------------------------------------------------- */
+/* SparseSet: spsparse::SparseSet<long,int> (eigen_types.hpp:24; used as the
+ * `dims` of every matrix, RegridMatrices_Dynamic.hpp:51-54).  Host-side value
+ * type: dense -> sparse table in first-seen order.  Passed IN/OUT to matrix_d:
+ * a pre-populated set is appended to, never reset (IceCoupler.cpp:366-371). */
+typedef struct ibh_sparse_set ibh_sparse_set;
+int ibh_sparse_set_create(int64_t sparse_extent, ibh_sparse_set **out);
+int ibh_sparse_set_create_identity(int64_t n, ibh_sparse_set **out);          /* ibmisc id_sparse_set, modele/merge_topo.cpp:48 */
+int ibh_sparse_set_from_array(int64_t sparse_extent, const int64_t *to_sparse, int32_t n, ibh_sparse_set **out);
+int ibh_sparse_set_destroy(ibh_sparse_set *s);
+int ibh_sparse_set_sparse_extent(const ibh_sparse_set *s, int64_t *out);
+int ibh_sparse_set_dense_extent(const ibh_sparse_set *s, int32_t *out);
+int ibh_sparse_set_to_sparse(const ibh_sparse_set *s, int64_t *out /* [dense_extent] */);
+
+/* ------------------------------------------------------------------------- */
+/* Regridder: the state of GCMRegridder_Standard (GCMRegridder.hpp:207-302) and
+ * one IceRegridder_L0 (IceRegridder.hpp:46-133) that the path reads, uploaded
+ * to HBM once.  Replaces GCMRegridder_Standard::init + add_sheet
+ * (GCMRegridder.cpp:65-86, GCMRegridder.hpp:353-367) and IceRegridder::init
+ * (IceRegridder.cpp:93-119) for the data they keep. */
+typedef struct ibh_regridder_desc {
+    /* ExchangeGrid (AbbrGrid.hpp:40-89) */
+    int64_t        nX;
+    const int32_t *ex_indices;    /* [2*nX] interleaved (iA_s, iI_s), AbbrGrid.hpp:42 */
+    const double  *ex_area;       /* [nX] overlaps, AbbrGrid.hpp:43                  */
+    int64_t        nI;            /* ice-grid sparse extent (IceRegridder::nI)       */
+    /* agridA (AbbrGrid.hpp:93-109) and IceRegridder::gridA_proj_area */
+    int64_t        nA;            /* atmosphere sparse extent (GCMRegridder::nA)     */
+    int32_t        nA_dense;
+    const int64_t *A_to_sparse;   /* [nA_dense] agridA->dim                          */
+    const double  *A_native_area; /* [nA_dense]                                      */
+    const double  *A_proj_area;   /* [nA_dense] (== native when sproj=="", IceRegridder.cpp:106-108) */
+    /* elevation classes */
+    int32_t        nhc;
+    const double  *hcdefs;        /* [nhc] ascending (GCMRegridder.hpp:253-256)      */
+    int64_t        hc_stride_A;   /* indexingHC.tuple_to_index: iE = iA*stride_A + ihc*stride_HC */
+    int64_t        hc_stride_HC;  /*   (icebin_cython.cpp:69 -> 1 and nA)            */
+    int32_t        interp_style;  /* 0 Z_INTERP, 1 ELEV_CLASS_INTERP (IceRegridder.hpp:36-39) */
+} ibh_regridder_desc;
+
+typedef struct ibh_regridder ibh_regridder;
+int ibh_regridder_create(const ibh_regridder_desc *desc, ibh_regridder **out);
+int ibh_regridder_destroy(ibh_regridder *rg);
+int ibh_regridder_sizes(const ibh_regridder *rg, int64_t *nA, int64_t *nE, int64_t *nI, int64_t *nX, int32_t *nhc);
+/* GCMRegridder::wA (GCMRegridder.hpp:305-315, icebin_cython.cpp:103-117):
+ * out[nA] = fill, then out[A_to_sparse[id]] = native or projected area. */
+int ibh_regridder_wA(const ibh_regridder *rg, int native, double fill, double *out /* [nA] */);
+
+/* ------------------------------------------------------------------------- */
+/* Weighted: ibmisc::linear::Weighted_Eigen {dims, M, wM, Mw, conservative,
+ * scaled} (RegridMatrices_Dynamic.cpp:63-65,100,115,123,421).  M lives in HBM
+ * as CSR (int32 rowptr/colind, f64 values, columns ascending inside a row). */
+typedef struct ibh_weighted ibh_weighted;
+
+/* RegridMatrices: GCMRegridder_Standard::regrid_matrices
+ * (RegridMatrices_Dynamic.cpp:334-402; Cython shim new_regrid_matrices,
+ * icebin_cython.cpp:215-236).  Copies elevmaskI (length must equal nI) to HBM. */
+typedef struct ibh_regrid_matrices ibh_regrid_matrices;
+int ibh_regrid_matrices_create(const ibh_regridder *rg, const double *elevmaskI, int64_t n,
+                               int scale, int correctA, const double sigma[3],
+                               ibh_regrid_matrices **out);
+int ibh_regrid_matrices_destroy(ibh_regrid_matrices *rm);
+
+/* RegridMatrices_Dynamic::matrix_d(spec, dims, params) (:412-423).
+ * spec in {AvI IvA AvX XvA EvI IvE EvX XvE EvA AvE}.  dim0/dim1 are IN/OUT;
+ * they must outlive the result unless passed as NULL, in which case fresh
+ * sets owned by the result are used (== RegridMatrices_Dynamic::matrix, :425-437). */
+int ibh_regrid_matrices_matrix_d(const ibh_regrid_matrices *rm, const char *spec,
+                                 ibh_sparse_set *dim0, ibh_sparse_set *dim1,
+                                 int scale, int correctA, const double sigma[3],
+                                 ibh_weighted **out);
+/* RegridMatrices::matrix(spec) (RegridMatrices.hpp:60-61): own dims, params of rm. */
+int ibh_regrid_matrices_matrix(const ibh_regrid_matrices *rm, const char *spec, ibh_weighted **out);
+
+/* Load a Weighted from dense-indexed triplets: to_eigen_M (eigen_types.cpp:9-34)
+ * / ibmisc.nc_read_weighted (matrix_formats.rst:139-147).  Duplicates are
+ * summed in input order (Eigen setFromTriplets).  dims are identity. */
+int ibh_weighted_from_coo(int32_t nrow, int32_t ncol, int64_t nnz,
+                          const int32_t *row, const int32_t *col, const double *val,
+                          const double *wM /* [nrow] */, const double *Mw /* [ncol] */,
+                          int conservative, int scaled, ibh_weighted **out);
+/* Same from host CSR arrays (columns need not be sorted; no duplicate merging). */
+int ibh_weighted_from_csr(int32_t nrow, int32_t ncol, const int32_t *rowptr,
+                          const int32_t *colind, const double *val,
+                          const double *wM, const double *Mw,
+                          int conservative, int scaled, ibh_weighted **out);
+int ibh_weighted_destroy(ibh_weighted *w);
+
+/* Public members of Weighted_Eigen, read back to host. */
+int ibh_weighted_shape(const ibh_weighted *w, int32_t *nrow_d, int32_t *ncol_d, int64_t *nnz);
+int ibh_weighted_flags(const ibh_weighted *w, int *conservative, int *scaled);
+int ibh_weighted_dim(const ibh_weighted *w, int k, int64_t *sparse_extent, int32_t *dense_extent);
+int ibh_weighted_dim_to_sparse(const ibh_weighted *w, int k, int64_t *out /* [dense_extent] */);
+int ibh_weighted_get_wM(const ibh_weighted *w, double *out /* [nrow_d] */);
+int ibh_weighted_get_Mw(const ibh_weighted *w, double *out /* [ncol_d] */);
+/* ->M in row-major COO order (row asc, col asc); any of row/col/val may be NULL. */
+int ibh_weighted_get_coo(const ibh_weighted *w, int32_t *row, int32_t *col, double *val);
+int ibh_weighted_get_csr(const ibh_weighted *w, int32_t *rowptr, int32_t *colind, double *val);
+
+/* Weighted_Eigen::apply(A_b, fill, force_conservation, tmp)
+ * (call sites modele/merge_topo.cpp:65, modele/icebin22m.cpp:153; inline Eigen
+ * products IceCoupler.cpp:237,445).  B_b[k, :] = M * A_b[k, :] for k < nvar in
+ * dense index spaces; rows with wM == 0 receive `fill`; when the matrix is
+ * not conservative and force_conservation != 0 each variable is rescaled by
+ * (Mw . A) / (wM . B).  _host takes host pointers (copies over PCIe);
+ * _device takes device pointers and only enqueues work on `stream`. */
+int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nvar, int64_t lda,
+                            double *B_b, int64_t ldb, double fill, int force_conservation);
+int ibh_weighted_apply_device(const ibh_weighted *w, const double *dA_b, int32_t nvar, int64_t lda,
+                              double *dB_b, int64_t ldb, double fill, int force_conservation,
+                              void *stream);
+/* linear_Weighted.apply_weight(dim, A) (matrix_formats.rst:167-186):
+ * out[k] = sum_j w[j] * A_b[k*lda + j], w = wM (dim 0) or Mw (dim 1); host pointers. */
+int ibh_weighted_apply_weight_host(const ibh_weighted *w, int dim, const double *A_b,
+                                   int32_t nvar, int64_t lda, double *out /* [nvar] */);
+
+/* Device pointers of the CSR and weights, for callers that keep fields resident
+ * (IceCoupler.cpp:408,445,456 read ->M and ->wM directly). */
+typedef struct ibh_weighted_device_view {
+    int32_t nrow, ncol; int64_t nnz;
+    const int32_t *rowptr, *colind; const double *val, *wM, *Mw;
+} ibh_weighted_device_view;
+int ibh_weighted_device_view_get(const ibh_weighted *w, ibh_weighted_device_view *out);
+
+/* Tuning / introspection (not part of the reference interface). */
+int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow" */
+int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
+int ibh_set_tuning(const char *key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -410,7 +410,7 @@ static void gen_GvEp(const orc_regridder *rg, const double *em, trip *out, errct
     for (long id = 0; id < rg->nX; ++id) {
         long iA = rg->ex_indices[2 * id], iI = rg->ex_indices[2 * id + 1];
         if (isnan(em[iI])) continue;
-        double elevation = em[iI] > 0.0 ? em[iI] : 0.0;   /* std::max(elev, 0.0), :123 */
+        double elevation = em[iI] < 0.0 ? 0.0 : em[iI];   /* std::max(elev, 0.0), :123 */
         if (rg->interp_style == ORC_Z_INTERP) {
             long ih[2]; double wh[2];
             if (orc_linterp_1d_b(rg->hcdefs, rg->nhc, elevation, ih, wh) != 0) {

@@ -1,0 +1,67 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/icebin_hip.h declares, and fails loudly (no fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from icebin_amd import _capi
+from icebin_amd.build import build_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build_library()
+    return _capi.lib()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "icebin_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ibh_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libicebin_hip.so does not export %s" % n
+    assert set(_capi.exported_symbols()) == set(names), set(_capi.exported_symbols()) ^ set(names)
+
+
+def test_sparse_set_host_logic(lib):
+    from icebin_amd import SparseSet
+    import numpy as np
+    s = SparseSet(100, [7, 3, 99])
+    assert s.sparse_extent() == 100 and s.dense_extent() == 3 and s.to_sparse().tolist() == [7, 3, 99]
+    i = SparseSet.identity(5)
+    assert i.to_sparse().tolist() == [0, 1, 2, 3, 4] and i.sparse_extent() == 5
+    with pytest.raises(_capi.IcebinHipError, match="duplicate sparse index"):
+        SparseSet(100, [1, 1])
+    with pytest.raises(_capi.IcebinHipError, match="outside extent"):
+        SparseSet(10, [11])
+
+
+@pytest.mark.skipif(_capi.device_count() > 0, reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly(lib):
+    import numpy as np
+    from icebin_amd import linear_Weighted, from_synthetic, synthetic
+    with pytest.raises(_capi.IcebinHipError, match="no CPU fallback") as ei:
+        linear_Weighted.from_coo((1, 1), [0], [0], [1.0], [1.0], [1.0])
+    assert ei.value.code == _capi.IBH_ENODEVICE
+    with pytest.raises(_capi.IcebinHipError, match="no CPU fallback"):
+        from_synthetic(synthetic.make_grids("tiny"))
+
+
+def test_product_never_imports_oracle():
+    # the oracle is test infrastructure: nothing under icebin_amd/ may reference it
+    pkg = os.path.join(ROOT, "icebin_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert "liboracle" not in text and "icebin_oracle.h" not in text, f

@@ -1,0 +1,254 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle, on a real MI355X.
+
+Bar: dims / CSR structure / wM / Mw / M bit-exact; regridded fp64 fields within
+1e-12 relative L-inf; conservation residual < 1e-13."""
+import math
+
+import numpy as np
+import pytest
+
+import icebin_amd
+from icebin_amd import synthetic as syn
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ALL = ("AvI", "IvA", "AvX", "XvA", "EvI", "IvE", "EvX", "XvE", "EvA", "AvE")
+FIELD_RTOL = 1e-12        # relative L-inf tolerance for regridded fields (BASELINE.json north_star)
+
+
+def rel_linf(a, b):
+    m = np.isfinite(b)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    return np.max(np.abs(a[m] - b[m])) / max(np.max(np.abs(b[m])), 1e-300)
+
+
+def assert_same_weighted(w, o, name=""):
+    assert (w.nrow_d, w.ncol_d, w.nnz) == (o.nrow, o.ncol, o.nnz), name
+    assert w.conservative == o.conservative and w.scaled == o.scaled
+    np.testing.assert_array_equal(w.dim(0), o.dims[0], err_msg=name + " dims[0]")
+    np.testing.assert_array_equal(w.dim(1), o.dims[1], err_msg=name + " dims[1]")
+    assert w.shape == (o.sparse_extents[0], o.sparse_extents[1])
+    row, col, val = w.coo_dense()
+    np.testing.assert_array_equal(row, o.row, err_msg=name + " row")
+    np.testing.assert_array_equal(col, o.col, err_msg=name + " col")
+    # bit-exact, not merely close: compare the raw 64-bit patterns
+    np.testing.assert_array_equal(val.view(np.uint64), o.val.view(np.uint64), err_msg=name + " M")
+    np.testing.assert_array_equal(w.wM.view(np.uint64), o.wM.view(np.uint64), err_msg=name + " wM")
+    np.testing.assert_array_equal(w.Mw.view(np.uint64), o.Mw.view(np.uint64), err_msg=name + " Mw")
+
+
+def setup(config, **kw):
+    g = syn.make_grids(config, **kw)
+    em = syn.dome_elevmask(g)
+    return g, em, icebin_amd.from_synthetic(g), orc.Regridder(g)
+
+
+@pytest.mark.parametrize("variant", ["sorted", "shuffled", "zero_area", "negative_area", "elev_class"])
+def test_assembly_bit_exact_all_matrices(variant):
+    kw = {}
+    if variant == "shuffled":
+        kw["order"] = "shuffled"
+    if variant == "zero_area":
+        kw["zero_area_every"] = 7
+    g = syn.make_grids("g50", **kw)
+    if variant == "negative_area":
+        g["ex_area"] = g["ex_area"].copy()
+        g["ex_area"][::11] *= -1.0
+    if variant == "elev_class":
+        g["interp_style"] = 1
+    em = syn.dome_elevmask(g)
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    rm = mm.regrid_matrices("greenland", em)
+    for name in ALL:
+        for scale in (True, False):
+            for correctA in (True, False):
+                w = rm.matrix_d(name, scale=scale, correctA=correctA)
+                o = rg.matrix_d(name, em, scale=scale, correctA=correctA)
+                assert_same_weighted(w, o, "%s scale=%d correctA=%d %s" % (name, scale, correctA, variant))
+
+
+def test_config1_real_mask_bit_exact(elev_mask_g20):
+    # BASELINE config 1: 20 km Greenland, the reference's own PISM mask fixture, all six matrices
+    g = syn.make_grids("g20")
+    _, em = orc.elevmask_pism(elev_mask_g20["mask"], elev_mask_g20["thk"], elev_mask_g20["topg"])
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    for name in ("AvI", "IvA", "EvI", "IvE", "EvA", "AvE"):
+        assert_same_weighted(rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True), name)
+    # Python default correctA=True (_icebin.pyx:165) vs C++ default false (RegridMatrices.hpp:33)
+    rm2 = mm.regrid_matrices("greenland", em)
+    assert_same_weighted(rm2.matrix("AvI"), rg.matrix_d("AvI", em, scale=True, correctA=True))
+
+
+def test_prepopulated_and_shared_dims():
+    # IceCoupler.cpp:366-371,462,467: identity dimI, one dimE shared by EvI / IvE / XvE
+    g, em, mm, rg = setup("g50")
+    rm = mm.regrid_matrices("greenland", em)
+    dimI, dimE = icebin_amd.SparseSet.identity(g["nI"]), icebin_amd.SparseSet(g["nA"] * 40)
+    odimI, odimE = orc.SparseSet(g["nI"], init=np.arange(g["nI"])), orc.SparseSet(g["nA"] * 40)
+    w1 = rm.matrix_d("EvI", (dimE, dimI), scale=False, correctA=False)
+    o1 = rg.matrix_d("EvI", em, (odimE, odimI), scale=False, correctA=False)
+    assert_same_weighted(w1, o1, "EvI shared")
+    w2 = rm.matrix_d("IvE", (dimI, dimE), scale=True, correctA=True)
+    o2 = rg.matrix_d("IvE", em, (odimI, odimE), scale=True, correctA=True)
+    assert_same_weighted(w2, o2, "IvE shared")
+    dimX, odimX = icebin_amd.SparseSet.identity(len(g["ex_area"])), orc.SparseSet(len(g["ex_area"]), init=np.arange(len(g["ex_area"])))
+    w3 = rm.matrix_d("XvE", (dimX, dimE), scale=False, correctA=True)
+    o3 = rg.matrix_d("XvE", em, (odimX, odimE), scale=False, correctA=True)
+    assert_same_weighted(w3, o3, "XvE shared")
+    np.testing.assert_array_equal(dimE.to_sparse(), odimE.to_sparse())
+    # a partially pre-populated, non-identity set is appended to in first-seen order
+    some = o1.dims[0][::3][::-1].copy()
+    dimE2, odimE2 = icebin_amd.SparseSet(g["nA"] * 40, some), orc.SparseSet(g["nA"] * 40, init=some)
+    assert_same_weighted(rm.matrix_d("EvA", (dimE2, None)), rg.matrix_d("EvA", em, (odimE2, None)), "EvA prepopulated")
+    np.testing.assert_array_equal(dimE2.to_sparse()[:len(some)], some)
+
+
+def test_errors_mirror_reference():
+    g, em, mm, rg = setup("tiny")
+    rm = mm.regrid_matrices("greenland", em)
+    with pytest.raises(icebin_amd.IcebinHipError, match="unknown regrid matrix"):
+        rm.matrix("BvA")                                  # regrids.at() throws, RegridMatrices_Dynamic.cpp:419
+    with pytest.raises(icebin_amd.IcebinHipError, match="elevmaskI has"):
+        mm.regrid_matrices("greenland", em[:-1])          # np_to_blitz shape check, icebin_cython.cpp:231
+    with pytest.raises(KeyError):
+        mm.regrid_matrices("antarctica", em)
+    hi = em.copy(); hi[np.isfinite(hi).argmax()] = 3900.0   # above the last height class 3850 m
+    rmh = mm.regrid_matrices("greenland", hi)
+    with pytest.raises(icebin_amd.IcebinHipError, match=r"Elevation 3900 out of bounds \(-50, 3850\)") as ei:
+        rmh.matrix("EvI")                                 # linterp_1d_b, IceRegridder_L0.cpp:84-85
+    assert ei.value.code == -4
+    with pytest.raises(orc.OracleError, match=r"Elevation 3900 out of bounds \(-50, 3850\)"):
+        rg.matrix_d("EvI", hi)
+    assert rmh.matrix("AvI").nnz > 0                      # matrices that never call GvEp are unaffected
+    with pytest.raises(icebin_amd.IcebinHipError) as ei:
+        mm.regrid_matrices("greenland", em, sigma=(50e3, 50e3, 100.)).matrix("IvA")
+    assert ei.value.code == -5
+
+
+@pytest.mark.parametrize("nvar", [1, 2, 3, 5, 8, 16, 17, 64])
+@pytest.mark.parametrize("name", ["AvI", "IvA", "EvI", "IvE", "EvA", "AvE"])
+def test_apply_parity(name, nvar):
+    g, em, mm, rg = setup("g20")
+    w = mm.regrid_matrices("greenland", em, scale=True, correctA=True).matrix(name)
+    o = rg.matrix_d(name, em, scale=True, correctA=True)
+    x = syn.fields(nvar, w.ncol_d)
+    for kernel in ("auto", "rowblock", "shortrow"):
+        w.set_kernel(kernel)
+        y = w.apply(x, fill=np.nan, force_conservation=False)
+        ref = o.apply(x, fill=np.nan, force_conservation=False)
+        assert rel_linf(y, ref) <= FIELD_RTOL, (name, nvar, kernel)
+        assert w.last_kernel() in ("rowblock", "shortrow")
+    y1 = w.apply(x[0])
+    assert y1.shape == (w.nrow_d,) and rel_linf(y1, o.apply(x[0])) <= FIELD_RTOL
+
+
+def test_apply_fill_nan_and_identity_dims():
+    # merge_topo.cpp:48-65: identity dimI, the field applied is elevmaskI itself (NaN in masked cells);
+    # NaNs sit in empty columns and must not leak; rows with wM == 0 get `fill`.
+    g, em, mm, rg = setup("g20")
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=False)
+    dimI, odimI = icebin_amd.SparseSet.identity(g["nI"]), orc.SparseSet(g["nI"], init=np.arange(g["nI"]))
+    w = rm.matrix_d("AvI", (None, dimI), scale=True, correctA=False)
+    o = rg.matrix_d("AvI", em, (None, odimI), scale=True, correctA=False)
+    assert_same_weighted(w, o)
+    y = w.apply(em, fill=np.nan, force_conservation=False)
+    assert np.all(np.isfinite(y)) and rel_linf(y, o.apply(em)) <= FIELD_RTOL
+    wi = rm.matrix_d("IvA", (dimI, None), scale=True, correctA=False)
+    oi = rg.matrix_d("IvA", em, (odimI, None), scale=True, correctA=False)
+    for kernel in ("rowblock", "shortrow"):
+        wi.set_kernel(kernel)
+        yi = wi.apply(syn.fields(3, wi.ncol_d), fill=-1.5)
+        ref = oi.apply(syn.fields(3, wi.ncol_d), fill=-1.5)
+        assert np.all(yi[:, np.isnan(em)] == -1.5)
+        assert rel_linf(yi, ref) <= FIELD_RTOL
+
+
+def test_python_surface_apply_M_and_weights():
+    # matrix_formats.rst:149-195
+    g, em, mm, rg = setup("g20")
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    AvI, IvA = rm.matrix("AvI"), rm.matrix("IvA")
+    oA = rg.matrix_d("AvI", em, scale=True, correctA=True)
+    assert AvI.shape == (g["nA"], g["nI"]) and mm.nA == g["nA"] and mm.nE == g["nA"] * 40 and mm.nhc == 40
+    valI = np.ones(g["nI"])
+    valA = AvI.apply_M(valI)
+    assert valA.shape == (g["nA"],) and np.isnan(valA).sum() == g["nA"] - AvI.nrow_d
+    back = IvA.apply_M(np.nan_to_num(valA))
+    ok = ~np.isnan(back)
+    assert ok.sum() == np.isfinite(em).sum() and np.all(np.abs(back[ok] - 1) < 1e-12)   # constant survives I->A->I
+    two = AvI.apply_M(np.stack([valI, 2 * valI]))
+    assert two.shape == (2, g["nA"]) and np.allclose(two[1], 2 * two[0], equal_nan=True)
+    # conservation: sum(x*Mw) == sum(Mx * wM)  (test_conserv.py:174-205)
+    xi = syn.fields(1, g["nI"])[0]
+    lhs, rhs = AvI.apply_Mw(xi), AvI.apply_wM(np.nan_to_num(AvI.apply_M(xi)))
+    assert abs(lhs - rhs) / abs(lhs) < 1e-12
+    np.testing.assert_array_equal(AvI.get_weights(0)[AvI.dim(0)], oA.wM)
+    M = AvI.to_coo()
+    assert M.shape == (g["nA"], g["nI"]) and M.nnz == oA.nnz
+    np.testing.assert_array_equal(mm.wA("greenland", "native")[g["A_to_sparse"]], g["A_native_area"])
+    assert np.all(mm.wA("greenland", "proj", fill=-1.0)[np.setdiff1d(np.arange(g["nA"]), g["A_to_sparse"])] == -1.0)
+
+
+def test_from_coo_duplicates_bit_exact():
+    # Eigen setFromTriplets: duplicates summed in input order (to_eigen_M, eigen_types.cpp:9-34)
+    rng = np.random.default_rng(5)
+    nrow, ncol, n = 300, 5000, 200000
+    r, c = rng.integers(0, nrow, n), rng.integers(0, ncol, n)
+    v = rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n)
+    wM, Mw = rng.random(nrow) + 0.5, rng.random(ncol) + 0.5
+    w = icebin_amd.linear_Weighted.from_coo((nrow, ncol), r, c, v, wM, Mw)
+    o = orc.Weighted.from_coo(nrow, ncol, r, c, v, wM, Mw)
+    assert_same_weighted(w, o, "from_coo")
+    x = rng.standard_normal((4, ncol))
+    assert rel_linf(w.apply(x), o.apply(x)) <= FIELD_RTOL
+
+
+def test_force_conservation_branch():
+    # non-conservative matrices only arise from smoothing; exercised through from_coo(conservative=False)
+    rng = np.random.default_rng(6)
+    nrow, ncol, n = 40, 900, 5000
+    r, c, v = rng.integers(0, nrow, n), rng.integers(0, ncol, n), rng.random(n)
+    wM, Mw = rng.random(nrow) + 0.5, rng.random(ncol) + 0.5
+    wM[3] = 0.0
+    w = icebin_amd.linear_Weighted.from_coo((nrow, ncol), r, c, v, wM, Mw, conservative=False)
+    o = orc.Weighted.from_coo(nrow, ncol, r, c, v, wM, Mw, conservative=False)
+    x = rng.random((3, ncol))
+    for fc in (False, True):
+        y, ref = w.apply(x, fill=-2.0, force_conservation=fc), o.apply(x, fill=-2.0, force_conservation=fc)
+        assert np.all(y[:, 3] == -2.0) and rel_linf(y, ref) <= 1e-12
+
+
+def test_5km_headline_shape_parity_and_conservation():
+    # BASELINE config 2/metric shape: 5 km Greenland -> 2x2.5, AvI + IvA, 64 fields
+    g, em, mm, rg = setup("g5")
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=False)
+    AvI, IvA = rm.matrix("AvI"), rm.matrix("IvA")
+    oA, oI = rg.matrix_d("AvI", em), rg.matrix_d("IvA", em)
+    assert_same_weighted(AvI, oA, "AvI g5")
+    assert_same_weighted(IvA, oI, "IvA g5")
+    x = syn.fields(64, AvI.ncol_d)
+    y = AvI.apply(x)
+    assert rel_linf(y, oA.apply(x)) <= FIELD_RTOL
+    wM, Mw = AvI.wM, AvI.Mw
+    for k in (0, 17, 63):     # conservation residual with compensated summation
+        a = math.fsum((Mw * x[k]).tolist())
+        b = math.fsum((wM * y[k]).tolist())
+        assert abs(a - b) / abs(a) < 1e-13
+    xa = syn.fields(64, IvA.ncol_d)
+    assert rel_linf(IvA.apply(xa), oI.apply(xa)) <= FIELD_RTOL
+
+
+def test_device_resident_apply_torch():
+    import torch
+    g, em, mm, rg = setup("g20")
+    w = mm.regrid_matrices("greenland", em, scale=True, correctA=False).matrix("AvI")
+    o = rg.matrix_d("AvI", em)
+    x = syn.fields(16, w.ncol_d)
+    dx = torch.from_numpy(x).cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        dy = w.apply_device(dx, force_conservation=False)
+    s.synchronize()
+    assert rel_linf(dy.cpu().numpy(), o.apply(x)) <= FIELD_RTOL
