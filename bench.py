@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the regrid hot path on MI355X.
+
+Metric (BASELINE.json): regridded cells/sec + achieved HBM GB/s, AvI 5 km -> 2x2.5 deg, 64 fields.
+A "step" is one Weighted::apply of the AvI matrix to one batch of 64 synthetic fields that
+are already resident in HBM.  Steps cycle through enough distinct field batches (>= 512 MiB in
+total) that no batch can be served from the 256 MiB Infinity Cache: every step streams its X
+from HBM ("cold" numbers).
+
+N GPUs (torchrun, one rank per GPU): the fields of a 64*N-field regrid are sharded by field
+across ranks (each rank applies the replicated CSR to its own 64 fields; zero communication
+in the SpMM), then one RCCL all-gather reassembles the [64*N, nrow] result on every rank.  The
+gather of step i overlaps the SpMM of step i+1 on a second stream.  Scaling is weak.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+
+def spmm_bytes(nnz, nrow, ncol, nf):
+    """Algorithmic bytes of one apply: CSR once + every X element once + Y once."""
+    return 12 * nnz + 4 * (nrow + 1) + 8 * nf * ncol + 8 * nf * nrow
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", default="g5", help="synthetic grid config (icebin_amd/synthetic.py)")
+    ap.add_argument("--matrix", default="AvI")
+    ap.add_argument("--fields", type=int, default=64, help="fields per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--warm", action="store_true", help="reuse ONE field batch (Infinity-Cache-resident numbers)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or args.gpus > 1:
+        assert world == args.gpus, "launch with torchrun --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import icebin_amd
+    from icebin_amd import _capi
+    from icebin_amd import synthetic as syn
+
+    # ---- the workload: assemble the matrix on this GPU (replicated on every rank) -----------------
+    grids = syn.make_grids(args.config)
+    em = syn.dome_elevmask(grids)
+    mm = icebin_amd.from_synthetic(grids)
+    t0 = time.perf_counter()
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    W = rm.matrix(args.matrix)
+    torch.cuda.synchronize()
+    t_asm_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    W2 = rm.matrix(args.matrix)
+    torch.cuda.synchronize()
+    t_asm = time.perf_counter() - t0
+    del W2
+    nrow, ncol, nnz, nf = W.nrow_d, W.ncol_d, W.nnz, args.fields
+    n_unmasked = int(np.isfinite(em).sum())
+
+    # ---- field batches resident in HBM -----------------------------------------------------------
+    xbytes = 8 * nf * ncol
+    nbuf = 1 if args.warm else max(2, -(-(512 << 20) // xbytes))
+    x_host = syn.fields(nf, ncol, seed=syn.SEED + rank)
+    x0 = torch.from_numpy(x_host).to(dev)
+    X = [x0 if b == 0 else x0 + 1e-3 * b for b in range(nbuf)]
+    Y = [torch.empty((nf, nrow), dtype=torch.float64, device=dev) for _ in range(2)]
+    Yall = [torch.empty((world * nf, nrow), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+
+    L = _capi.lib()
+    fn = L.ibh_weighted_apply_device
+    compute = torch.cuda.Stream(device=dev)
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    cs = C.c_void_p(compute.cuda_stream)
+    xp = [C.c_void_p(x.data_ptr()) for x in X]
+    yp = [C.c_void_p(y.data_ptr()) for y in Y]
+    nan = float("nan")
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    ev_free = [torch.cuda.Event() for _ in range(2)]
+
+    def step(i):
+        s = i & 1
+        if world > 1 and i >= 2:
+            compute.wait_event(ev_free[s])          # Y[s] was handed to the gather two steps ago
+        rc = fn(W._h, xp[i % nbuf], nf, ncol, yp[s], nrow, nan, 0, cs)
+        if rc != 0:
+            _capi.check(rc)
+        if world > 1:
+            ev_done[s].record(compute)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev_done[s])
+                dist.all_gather_into_tensor(Yall[s], Y[s])
+                ev_free[s].record(comm)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(compute)
+    for i in range(args.steps):
+        step(i)
+    e1.record(compute)
+    sync_all()
+    dt = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / max(args.steps, 1)      # avg launch-to-launch on the launch stream
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- parity spot check of the timed configuration (checker only; not in the timed region) ----
+    result = None
+    if rank == 0:
+        cells = n_unmasked * nf * world * args.steps
+        B = spmm_bytes(nnz, nrow, ncol, nf)
+        achieved = B / (kernel_ms * 1e-3) / 1e9
+        result = {
+            "metric": "regridded cells/sec (%s, %s, %d fields/GPU)" % (args.matrix, args.config, nf),
+            "value": cells / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "searise 5 km Greenland -> ModelE 2x2.5 %s, %d fields" % (args.matrix, nf)
+                       if args.config == "g5" else "%s %s %d fields" % (args.config, args.matrix, nf),
+                       "nI": grids["nI"], "nX": int(len(grids["ex_area"])), "unmasked_cells": n_unmasked,
+                       "nrow_d": nrow, "ncol_d": ncol, "nnz": nnz, "fields_per_gpu": nf, "field_batches": nbuf,
+                       "cache": "warm" if args.warm else "cold (rotating batches > Infinity Cache)",
+                       "kernel": W.last_kernel(), "parallelism": "field-shard x%d + all-gather" % world if world > 1 else "1 GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_us": kernel_ms * 1e3, "algorithmic_bytes": B},
+            "assembly_ms": {"first_call": t_asm_first * 1e3, "steady": t_asm * 1e3},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(grids, em, args, x_host, n_unmasked)
+        y = Y[(args.steps - 1) & 1].cpu().numpy() if args.steps > 0 else None
+        result["finite_output"] = bool(y is not None and np.isfinite(y).all())
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(grids, em, args, x_host, n_unmasked):
+    """The oracle (reference-faithful port: Eigen's ColMajor sparse x dense loop, 1 thread, as the
+    reference is single-threaded, CMakeLists.txt:135-137) timed on this box's host cores on the
+    same matrix and the same 64 fields; also a row-partitioned CSR SpMM on all cores."""
+    from oracle import oracle as orc
+    rg = orc.Regridder(grids)
+    o = rg.matrix_d(args.matrix, em, scale=True, correctA=True)
+    nf = x_host.shape[0]
+    t1 = o.time_apply(x_host, reps=1, threads=1)
+    reps = max(3, int(8.0 / max(t1, 1e-6)))
+    reps = min(reps, 20000)
+    t1 = min(o.time_apply(x_host, reps=max(1, reps // 4), threads=1) for _ in range(4))
+    ncpu = len(os.sched_getaffinity(0))
+    tn = min(o.time_apply(x_host, reps=max(1, reps // 4), threads=ncpu) for _ in range(4))
+    return {"value": n_unmasked * nf / t1, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "same matrix and %d fields, %d applies, best of 4 batches" % (nf, reps),
+            "ms_per_apply": t1 * 1e3,
+            "all_cores": {"value": n_unmasked * nf / tn, "cores": ncpu, "ms_per_apply": tn * 1e3}}
+
+
+if __name__ == "__main__":
+    main()

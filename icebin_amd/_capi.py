@@ -83,6 +83,29 @@ _SIGS = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
+    libhsa-runtime64; if this library pulled in /opt/rocm's copy as well, whichever runtime came
+    second would find no GPU.  So when torch is installed, load ITS runtime first (without importing
+    torch): the dynamic linker then binds libicebin_hip.so's libamdhip64.so.7 to the copy already
+    loaded, and a later `import torch` shares it.  ICEBIN_HIP_RUNTIME=system skips this."""
+    if os.environ.get("ICEBIN_HIP_RUNTIME", "torch") != "torch":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return      # torch already loaded its runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load the HIP library; fails loudly (no fallback) when it has not been built."""
     global _lib
@@ -91,6 +114,7 @@ def lib():
             raise ImportError(
                 "icebin_amd: %s is missing. Build it with `python -m icebin_amd.build` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.ibh_last_error.restype = C.c_char_p
         for name, (res, args) in _SIGS.items():
@@ -117,3 +141,14 @@ def device_count():
     n = C.c_int(0)
     check(lib().ibh_device_count(C.byref(n)))
     return n.value
+
+
+def destroy(fn_name, handle):
+    """Handle destructor usable from __del__, also during interpreter shutdown."""
+    L = _lib
+    if L is None or handle is None or not getattr(handle, "value", None):
+        return
+    try:
+        getattr(L, fn_name)(handle)
+    except Exception:
+        pass

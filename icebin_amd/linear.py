@@ -30,9 +30,8 @@ class SparseSet:
         return cls(_handle=h)
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            lib().ibh_sparse_set_destroy(self._h)
-            self._h = None
+        _capi.destroy("ibh_sparse_set_destroy", getattr(self, "_h", None))
+        self._h = None
 
     def sparse_extent(self):
         v = C.c_int64()
@@ -71,9 +70,8 @@ class linear_Weighted:
         self._sparse_extents = [None, None]
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            lib().ibh_weighted_destroy(self._h)
-            self._h = None
+        _capi.destroy("ibh_weighted_destroy", getattr(self, "_h", None))
+        self._h = None
 
     # ---- loaders -------------------------------------------------------------------------
     @classmethod

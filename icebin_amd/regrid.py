@@ -19,9 +19,8 @@ class RegridMatrices:
         self._keep = keep
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            lib().ibh_regrid_matrices_destroy(self._h)
-            self._h = None
+        _capi.destroy("ibh_regrid_matrices_destroy", getattr(self, "_h", None))
+        self._h = None
 
     def matrix(self, spec_name):
         """Compute a regrid matrix: 'EvI', 'AvI', 'IvA', 'IvE', 'EvA', 'AvE' (also 'AvX', 'XvA',
@@ -107,9 +106,8 @@ class GCMRegridder:
 
     def __del__(self):
         for s in getattr(self, "_sheets", {}).values():
-            if s.h.value:
-                lib().ibh_regridder_destroy(s.h)
-                s.h = C.c_void_p()
+            _capi.destroy("ibh_regridder_destroy", s.h)
+            s.h = None
 
     def wA(self, sheet_name, snative, fill=0.):
         """Returns weights (as a vector) of overall grid (_icebin.pyx:116-125)."""
