@@ -181,7 +181,7 @@ def cpu_baseline(grids, em, args, x_host, n_unmasked):
     reps = max(3, int(8.0 / max(t1, 1e-6)))
     reps = min(reps, 20000)
     t1 = min(o.time_apply(x_host, reps=max(1, reps // 4), threads=1) for _ in range(4))
-    ncpu = len(os.sched_getaffinity(0))
+    ncpu = min(len(os.sched_getaffinity(0)), 16)      # the GPU box's CPU share for one GPU
     tn = min(o.time_apply(x_host, reps=max(1, reps // 4), threads=ncpu) for _ in range(4))
     return {"value": n_unmasked * nf / t1, "unit": "cells/s", "cores": 1, "kind": "port",
             "sample": "same matrix and %d fields, %d applies, best of 4 batches" % (nf, reps),

@@ -100,12 +100,21 @@ __global__ __launch_bounds__(RB_THREADS) void spmm_rowblock_kernel(
             s_val[k] = vals[seg + k];
         }
         __syncthreads();
-        int k = wk * 64 + lane;
-        for (; k + (UNROLL - 1) * STEP < n; k += UNROLL * STEP) {
+        // Uniform batches of UNROLL*STEP entries: every lane issues all UNROLL*FPW loads of a batch
+        // before the first FMA, so a row costs ceil(n / (UNROLL*STEP)) memory round trips.  Lanes past
+        // the end re-read the last entry and are masked at the FMA (never multiplied by 0: 0*NaN).
+        for (int k0 = wk * 64 + lane; k0 - lane < n; k0 += UNROLL * STEP) {
             int c[UNROLL];
             double v[UNROLL];
+            bool ok[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) { c[u] = s_col[k + u * STEP]; v[u] = s_val[k + u * STEP]; }
+            for (int u = 0; u < UNROLL; ++u) {
+                const int k = k0 + u * STEP;
+                ok[u] = k < n;
+                const int kk = ok[u] ? k : n - 1;
+                c[u] = s_col[kk];
+                v[u] = s_val[kk];
+            }
             double x[FPW][UNROLL];
 #pragma unroll
             for (int j = 0; j < FPW; ++j)
@@ -114,13 +123,7 @@ __global__ __launch_bounds__(RB_THREADS) void spmm_rowblock_kernel(
 #pragma unroll
             for (int j = 0; j < FPW; ++j)
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) acc[j] = fma(v[u], x[j][u], acc[j]);
-        }
-        for (; k < n; k += STEP) {
-            const int c = s_col[k];
-            const double v = s_val[k];
-#pragma unroll
-            for (int j = 0; j < FPW; ++j) acc[j] = fma(v, xf[j][c], acc[j]);
+                for (int u = 0; u < UNROLL; ++u) acc[j] = ok[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
         }
     }
 #pragma unroll
@@ -230,13 +233,15 @@ static void launch_rowblock(const ibh_weighted *w, const double *dA, int nvar, l
     const int nfc = ceil_div(nvar, FB);
     const long nb = (long)w->nrow * nfc;
     IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
-    const int unroll = get_tuning("rowblock_unroll", 4);
+    const int unroll = get_tuning("rowblock_unroll", 8);
 #define IBH_RB(U)                                                                                        \
     hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U>), dim3((unsigned)nb), dim3(RB_THREADS), 0, stream, \
                        w->rowptr.p, w->colind.p, w->val.p, dA, lda, dB, ldb, w->nrow, nvar, nfc, w->wM.p, fill)
     if (unroll == 1) IBH_RB(1);
     else if (unroll == 2) IBH_RB(2);
+    else if (unroll == 6) IBH_RB(6);
     else if (unroll == 8) IBH_RB(8);
+    else if (unroll == 12) IBH_RB(12);
     else IBH_RB(4);
 #undef IBH_RB
     IBH_HIP(hipGetLastError());
@@ -257,8 +262,7 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
     if (kernel == 1) {
         int fpw = get_tuning("rowblock_fpw", 0), wk = get_tuning("rowblock_wk", 0);
         if (fpw == 0 || wk == 0) {
-            if (nvar >= 16) { fpw = 4; wk = 1; }
-            else if (nvar >= 8) { fpw = 2; wk = 1; }
+            if (nvar >= 8) { fpw = 2; wk = 1; }
             else if (nvar >= 4) { fpw = 1; wk = 1; }
             else if (nvar >= 2) { fpw = 1; wk = 2; }
             else { fpw = 1; wk = 4; }

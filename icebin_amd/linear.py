@@ -30,7 +30,10 @@ class SparseSet:
         return cls(_handle=h)
 
     def __del__(self):
-        _capi.destroy("ibh_sparse_set_destroy", getattr(self, "_h", None))
+        try:
+            _capi.destroy("ibh_sparse_set_destroy", getattr(self, "_h", None))
+        except Exception:      # interpreter shutdown
+            pass
         self._h = None
 
     def sparse_extent(self):
@@ -70,7 +73,10 @@ class linear_Weighted:
         self._sparse_extents = [None, None]
 
     def __del__(self):
-        _capi.destroy("ibh_weighted_destroy", getattr(self, "_h", None))
+        try:
+            _capi.destroy("ibh_weighted_destroy", getattr(self, "_h", None))
+        except Exception:      # interpreter shutdown
+            pass
         self._h = None
 
     # ---- loaders -------------------------------------------------------------------------

@@ -19,7 +19,10 @@ class RegridMatrices:
         self._keep = keep
 
     def __del__(self):
-        _capi.destroy("ibh_regrid_matrices_destroy", getattr(self, "_h", None))
+        try:
+            _capi.destroy("ibh_regrid_matrices_destroy", getattr(self, "_h", None))
+        except Exception:      # interpreter shutdown
+            pass
         self._h = None
 
     def matrix(self, spec_name):
@@ -105,9 +108,12 @@ class GCMRegridder:
         self._sheets[name] = _Sheet(h, int(gridI["nI"]), (idx, area, proj))
 
     def __del__(self):
-        for s in getattr(self, "_sheets", {}).values():
-            _capi.destroy("ibh_regridder_destroy", s.h)
-            s.h = None
+        try:
+            for s in getattr(self, "_sheets", {}).values():
+                _capi.destroy("ibh_regridder_destroy", s.h)
+                s.h = None
+        except Exception:      # interpreter shutdown
+            pass
 
     def wA(self, sheet_name, snative, fill=0.):
         """Returns weights (as a vector) of overall grid (_icebin.pyx:116-125)."""
