@@ -56,12 +56,14 @@ def main():
         assert world == args.gpus, "launch with torchrun --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also rehearsable at N=1)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     import icebin_amd
     from icebin_amd import _capi
     from icebin_amd import synthetic as syn
+    from icebin_amd.distributed import all_gather_fields
 
     # ---- the workload: assemble the matrix on this GPU (replicated on every rank) -----------------
     grids = syn.make_grids(args.config)
@@ -87,12 +89,12 @@ def main():
     x0 = torch.from_numpy(x_host).to(dev)
     X = [x0 if b == 0 else x0 + 1e-3 * b for b in range(nbuf)]
     Y = [torch.empty((nf, nrow), dtype=torch.float64, device=dev) for _ in range(2)]
-    Yall = [torch.empty((world * nf, nrow), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    Yall = [torch.empty((world * nf, nrow), dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
 
     L = _capi.lib()
     fn = L.ibh_weighted_apply_device
     compute = torch.cuda.Stream(device=dev)
-    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm = torch.cuda.Stream(device=dev) if use_dist else None
     cs = C.c_void_p(compute.cuda_stream)
     xp = [C.c_void_p(x.data_ptr()) for x in X]
     yp = [C.c_void_p(y.data_ptr()) for y in Y]
@@ -102,21 +104,21 @@ def main():
 
     def step(i):
         s = i & 1
-        if world > 1 and i >= 2:
+        if use_dist and i >= 2:
             compute.wait_event(ev_free[s])          # Y[s] was handed to the gather two steps ago
         rc = fn(W._h, xp[i % nbuf], nf, ncol, yp[s], nrow, nan, 0, cs)
         if rc != 0:
             _capi.check(rc)
-        if world > 1:
+        if use_dist:
             ev_done[s].record(compute)
             with torch.cuda.stream(comm):
                 comm.wait_event(ev_done[s])
-                dist.all_gather_into_tensor(Yall[s], Y[s])
+                all_gather_fields(Y[s], world * nf, None, out=Yall[s])
                 ev_free[s].record(comm)
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -132,7 +134,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / max(args.steps, 1)      # avg launch-to-launch on the launch stream
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -155,7 +157,7 @@ def main():
                        "cache": "warm" if args.warm else "cold (rotating batches > Infinity Cache)",
                        "kernel": W.last_kernel(), "parallelism": "field-shard x%d + all-gather" % world if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, W.last_kernel()),
                          "kernel_us": kernel_ms * 1e3, "algorithmic_bytes": B},
             "assembly_ms": {"first_call": t_asm_first * 1e3, "steady": t_asm * 1e3},
         }
@@ -164,9 +166,25 @@ def main():
         y = Y[(args.steps - 1) & 1].cpu().numpy() if args.steps > 0 else None
         result["finite_output"] = bool(y is not None and np.isfinite(y).all())
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this very command,
+    FETCH doubled per the gfx950 correction).  None when no profile matches this workload."""
+    import glob
+    key = "spmm_%s_%s_%s_%df" % (kernel, args.config, args.matrix, args.fields)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if key in d and not args.warm:
+            return d[key]["traffic_bytes"]
+    return None
 
 
 def cpu_baseline(grids, em, args, x_host, n_unmasked):

@@ -3,6 +3,7 @@
 #include <memory>
 
 #include "common.h"
+#include "prims.h"
 
 namespace ibh {
 // RegridMatrices_Dynamic::matrix_d (RegridMatrices_Dynamic.cpp:412-423) on device.
@@ -11,5 +12,4 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
 // Eigen setFromTriplets (to_eigen_M, eigen_types.cpp:9-34) on device: fills w's CSR from host COO.
 void weighted_from_coo_device(ibh_weighted *w, int nrow, int ncol, int64_t n, const int32_t *row, const int32_t *col,
                               const double *val);
-void release_workspace();
 }  // namespace ibh

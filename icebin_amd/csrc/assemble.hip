@@ -21,31 +21,6 @@
 
 namespace ibh {
 
-// ---- workspace arena: bump allocator over a few big hipMalloc blocks, reused across builds ----
-struct Arena {
-    struct Block { char *p; size_t cap, used; };
-    std::vector<Block> blocks;
-    ~Arena() { for (auto &b : blocks) (void)hipFree(b.p); }
-    void reset() { for (auto &b : blocks) b.used = 0; }
-    template <class T>
-    T *get(size_t n) {
-        size_t bytes = ((n ? n : 1) * sizeof(T) + 255) & ~size_t(255);
-        for (auto &b : blocks)
-            if (b.cap - b.used >= bytes) { char *p = b.p + b.used; b.used += bytes; return reinterpret_cast<T *>(p); }
-        size_t cap = bytes > (size_t(64) << 20) ? bytes : (size_t(64) << 20);
-        Block nb{nullptr, cap, bytes};
-        IBH_HIP(hipMalloc(reinterpret_cast<void **>(&nb.p), cap));
-        blocks.push_back(nb);
-        return reinterpret_cast<T *>(nb.p);
-    }
-};
-static Arena &arena() { static thread_local Arena a; return a; }
-void release_workspace() {
-    Arena &a = arena();
-    for (auto &b : a.blocks) (void)hipFree(b.p);
-    a.blocks.clear();
-}
-
 enum { LIST_AP = 0, LIST_I = 1, LIST_EP = 2 };
 enum { KEY_A = 0, KEY_I = 1, KEY_E = 2, KEY_X = 3 };
 enum { FAM_AEVI = 0, FAM_IVAE = 1, FAM_EVA = 2 };
@@ -187,15 +162,21 @@ template <bool WITH_EP>
 __global__ void k_number_first(RgView rg, int list, int key, const int32_t *__restrict__ tab,
                                uint32_t *__restrict__ first, int *__restrict__ err_x) {
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= rg.nX) return;
-    const XCell c = load_cell<WITH_EP>(rg, x);
-    if (WITH_EP && c.range_error) { atomicMin(err_x, (int)x); return; }
-    long keys[2];
-    const int n = list_entries(c, x, list, key, keys);
+    long keys[2] = {-1, -1};
+    int n = 0;                                  // no early return: every lane takes part in the shuffle
+    if (x < rg.nX) {
+        const XCell c = load_cell<WITH_EP>(rg, x);
+        if (WITH_EP && c.range_error) atomicMin(err_x, (int)x);
+        else n = list_entries(c, x, list, key, keys);
+    }
+    // Sorted exchange grids give long runs of equal keys (one atmosphere cell per ~10^2..10^3
+    // consecutive x): the lane below already carries a smaller position for the same key, so only
+    // the first lane of a run inside the wave needs the atomic.
+    const long prev0 = __shfl_up(n > 0 ? keys[0] : -1l, 1, 64);
+    const bool lane0 = (threadIdx.x & 63) == 0;
     for (int j = 0; j < n; ++j) {
-        const uint32_t p = (uint32_t)(2 * x + j);
-        // the plain read only filters: first[] decreases monotonically, a stale value costs one extra atomic
-        if (tab[keys[j]] < 0 && first[keys[j]] > p) atomicMin(&first[keys[j]], p);
+        if (j == 0 && !lane0 && prev0 == keys[0]) continue;
+        if (tab[keys[j]] < 0) atomicMin(&first[keys[j]], (uint32_t)(2 * x + j));
     }
 }
 template <bool WITH_EP>
@@ -397,29 +378,57 @@ __global__ void k_rowptr(const int32_t *__restrict__ row, long nnz, int nrow, in
     if (u == nnz - 1)
         for (int q = r + 1; q <= nrow; ++q) rowptr[q] = (int32_t)nnz;
 }
-// spsparse sum(M,0,'+'): along each CSR row in ascending column order
-__global__ void k_row_sums(const int32_t *__restrict__ rowptr, const double *__restrict__ val, int nrow,
-                           double *__restrict__ rs) {
+// spsparse sum(M,dim,'+'): one sequential chain per segment (a CSR row in ascending column order,
+// or a column in ascending row order through the stable by-column permutation `idx`), exactly
+// ret = ret + v starting from 0.  Thread-per-segment suits 1-3 entry segments; the wave form
+// loads 64 values coalesced and replays the same sequential chain from registers (every lane
+// computes the identical sum), which is what long rows (10^2..10^4 entries) need.
+__global__ void k_seg_sums_thread(const int32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
+                                  const double *__restrict__ val, int nseg, double *__restrict__ out) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrow) return;
+    if (r >= nseg) return;
     double s = 0.0;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) s = s + val[k];
-    rs[r] = s;
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) s = s + val[idx ? idx[k] : (uint32_t)k];
+    out[r] = s;
+}
+__global__ void k_seg_sums_wave(const int32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
+                                const double *__restrict__ val, int nseg, double *__restrict__ out) {
+    const int r = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= nseg) return;
+    const int beg = ptr[r], end = ptr[r + 1];
+    double s = 0.0;
+    for (int base = beg; base < end; base += 64) {
+        const int k = base + lane;
+        const double v = k < end ? val[idx ? idx[k] : (uint32_t)k] : 0.0;
+        const int cnt = min(64, end - base);
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        if (cnt == 64) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j)
+                s = s + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+        } else {
+            for (int j = 0; j < cnt; ++j)
+                s = s + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+        }
+    }
+    if (lane == 0) out[r] = s;
+}
+static void seg_sums(const int32_t *ptr, const uint32_t *idx, const double *val, int nseg, long nnz, double *out,
+                     hipStream_t st) {
+    if (nseg == 0) return;
+    if (nnz >= 8l * nseg)
+        hipLaunchKernelGGL(k_seg_sums_wave, dim3(ceil_div((long)nseg * 64, 256)), dim3(256), 0, st, ptr, idx, val, nseg, out);
+    else
+        hipLaunchKernelGGL(k_seg_sums_thread, dim3(ceil_div(nseg, 256)), dim3(256), 0, st, ptr, idx, val, nseg, out);
 }
 __global__ void k_col_keys(const int32_t *__restrict__ col, long nnz, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
     const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (u < nnz) { keys[u] = (uint64_t)(uint32_t)col[u]; idx[u] = (uint32_t)u; }
 }
-// spsparse sum(M,1,'+'): along each column in ascending row order (stable by-column order)
-__global__ void k_col_sums(const uint64_t *__restrict__ ckeys, const uint32_t *__restrict__ idx,
-                           const double *__restrict__ val, long nnz, double *__restrict__ cs) {
-    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nnz) return;
-    const uint64_t c = ckeys[k];
-    if (k != 0 && ckeys[k - 1] == c) return;
-    double s = 0.0;
-    for (long m = k; m < nnz && ckeys[m] == c; ++m) s = s + val[idx[m]];
-    cs[c] = s;
+__global__ void k_keys_to_i32(const uint64_t *__restrict__ keys, long n, int32_t *__restrict__ out) {
+    const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < n) out[u] = (int32_t)keys[u];
 }
 
 // ---- weights and scaling (RegridMatrices_Dynamic.cpp:100-146, 201-233, 290-329) ----------------
@@ -620,15 +629,19 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     double *rs = A.get<double>((size_t)nrow), *cs = A.get<double>((size_t)ncol);
     double *rowmul = A.get<double>((size_t)nrow), *colmul = A.get<double>((size_t)ncol);
     w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
-    if (nrow) hipLaunchKernelGGL(k_row_sums, dim3(ceil_div(nrow, T)), dim3(T), 0, st, w->rowptr.p, w->val.p, nrow, rs);
-    if (ncol) IBH_HIP(hipMemsetAsync(cs, 0, sizeof(double) * (size_t)ncol, st));
+    seg_sums(w->rowptr.p, nullptr, w->val.p, nrow, nnz, rs, st);
     if (nnz) {
         uint64_t *ck = A.get<uint64_t>((size_t)nnz), *ck2 = A.get<uint64_t>((size_t)nnz);
         uint32_t *ci = A.get<uint32_t>((size_t)nnz), *ci2 = A.get<uint32_t>((size_t)nnz);
         hipLaunchKernelGGL(k_col_keys, dim3(ceil_div(nnz, T)), dim3(T), 0, st, w->colind.p, nnz, ck, ci);
         KeyField f{0, bits_for((uint64_t)ncol)};
         if (f.nbits > 0 && radix_sort_pairs(ck, ck2, ci, ci2, (size_t)nnz, &f, 1, st)) { std::swap(ck, ck2); std::swap(ci, ci2); }
-        hipLaunchKernelGGL(k_col_sums, dim3(ceil_div(nnz, T)), dim3(T), 0, st, ck, ci, w->val.p, nnz, cs);
+        int32_t *scol = A.get<int32_t>((size_t)nnz), *colptr = A.get<int32_t>((size_t)ncol + 1);
+        hipLaunchKernelGGL(k_keys_to_i32, dim3(ceil_div(nnz, T)), dim3(T), 0, st, ck, nnz, scol);
+        hipLaunchKernelGGL(k_rowptr, dim3(ceil_div(nnz, T)), dim3(T), 0, st, scol, nnz, ncol, colptr);
+        seg_sums(colptr, ci, w->val.p, ncol, nnz, cs, st);
+    } else if (ncol) {
+        IBH_HIP(hipMemsetAsync(cs, 0, sizeof(double) * (size_t)ncol, st));
     }
     FinalizeArgs fa{sp->family, scale, correctA, sp->row_key, sp->col_key, nrow, ncol, rset.to_sparse, cset.to_sparse,
                     rs, cs, w->wM.p, w->Mw.p, rowmul, colmul};

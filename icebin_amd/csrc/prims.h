@@ -5,6 +5,20 @@
 
 namespace ibh {
 
+// Workspace arena: bump allocator over a few big hipMalloc blocks, reused across matrix builds
+// (the coupler rebuilds four matrices per step: no hipMalloc/hipFree on that path).  One per host
+// thread; everything that uses it runs on one stream, so reuse after reset() is ordered.
+struct Arena {
+    struct Block { char *p; size_t cap, used; };
+    std::vector<Block> blocks;
+    ~Arena();
+    void reset() { for (auto &b : blocks) b.used = 0; }
+    void *get_bytes(size_t bytes);
+    template <class T> T *get(size_t n) { return static_cast<T *>(get_bytes((n ? n : 1) * sizeof(T))); }
+};
+Arena &arena();
+void release_workspace();
+
 // out[i] = sum_{j<i} in[j] (u32, wraps at 2^32); in == out allowed.  If total != nullptr the
 // grand total is written there (device pointer).  All work is enqueued on `stream`.
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total, hipStream_t stream);

@@ -10,6 +10,24 @@
 
 namespace ibh {
 
+Arena::~Arena() { for (auto &b : blocks) (void)hipFree(b.p); }
+void *Arena::get_bytes(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    for (auto &b : blocks)
+        if (b.cap - b.used >= bytes) { char *p = b.p + b.used; b.used += bytes; return p; }
+    const size_t cap = bytes > (size_t(64) << 20) ? bytes : (size_t(64) << 20);
+    Block nb{nullptr, cap, bytes};
+    IBH_HIP(hipMalloc(reinterpret_cast<void **>(&nb.p), cap));
+    blocks.push_back(nb);
+    return nb.p;
+}
+Arena &arena() { static thread_local Arena a; return a; }
+void release_workspace() {
+    Arena &a = arena();
+    for (auto &b : a.blocks) (void)hipFree(b.p);
+    a.blocks.clear();
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -106,12 +124,11 @@ void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *t
     }
     const size_t nb = (n + SC_TILE - 1) / SC_TILE;
     IBH_CHECK(nb < (1ul << 31), "scan too large");
-    DevBuf<uint32_t> sums(nb);
-    hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)nb), dim3(SC_T), 0, stream, in, n, sums.p);
-    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums.p, (int)nb, total);
-    hipLaunchKernelGGL(scan_tile_apply, dim3((unsigned)nb), dim3(SC_T), 0, stream, in, out, n, sums.p);
+    uint32_t *sums = arena().get<uint32_t>(nb);
+    hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)nb), dim3(SC_T), 0, stream, in, n, sums);
+    hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, (int)nb, total);
+    hipLaunchKernelGGL(scan_tile_apply, dim3((unsigned)nb), dim3(SC_T), 0, stream, in, out, n, sums);
     IBH_HIP(hipGetLastError());
-    IBH_HIP(hipStreamSynchronize(stream));   // sums is freed on return
 }
 
 // ---- radix sort ----------------------------------------------------------------------------
@@ -201,7 +218,7 @@ bool radix_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32
     if (n <= 1) return false;
     IBH_CHECK(n < (1ul << 32), "sort too large");
     const size_t nblocks = (n + RS_TILE - 1) / RS_TILE;
-    DevBuf<uint32_t> table(256 * nblocks);
+    uint32_t *table = arena().get<uint32_t>(256 * nblocks);
     bool in_alt = false;
     for (int f = 0; f < nfields; ++f) {
         int done = 0;
@@ -216,16 +233,15 @@ bool radix_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32
             uint64_t *kout = in_alt ? keys : keys_alt;
             uint32_t *vout = in_alt ? vals : vals_alt;
             hipLaunchKernelGGL(rs_hist, dim3((unsigned)nblocks), dim3(RS_T), 0, stream, kin, n, shift, mask,
-                               table.p, (int)nblocks);
-            exclusive_scan_u32(table.p, table.p, (size_t)(mask + 1) * nblocks, nullptr, stream);
+                               table, (int)nblocks);
+            exclusive_scan_u32(table, table, (size_t)(mask + 1) * nblocks, nullptr, stream);
             hipLaunchKernelGGL(rs_scatter, dim3((unsigned)nblocks), dim3(RS_T), 0, stream, kin, vin, kout, vout, n,
-                               shift, nbits, table.p, (int)nblocks);
+                               shift, nbits, table, (int)nblocks);
             IBH_HIP(hipGetLastError());
             in_alt = !in_alt;
             done += nbits;
         }
     }
-    IBH_HIP(hipStreamSynchronize(stream));   // table is freed on return
     return in_alt;
 }
 

@@ -1,0 +1,332 @@
+// icebin_hip.hpp -- host-side C++ mirror of IceBin's regrid-matrix interface over the C-ABI.
+//
+// Same class names, method names, argument order and defaults as the reference, so a caller of
+//   GCMRegridder_Standard::regrid_matrices()  (slib/icebin/GCMRegridder.hpp:290-293, 369-372)
+//   RegridMatrices_Dynamic::matrix_d()/matrix() (slib/icebin/RegridMatrices_Dynamic.hpp:51-59)
+//   linear::Weighted_Eigen::apply()           (call sites modele/merge_topo.cpp:65, icebin22m.cpp:153)
+// can switch to this header and link libicebin_hip.so instead of ibmisc/spsparse/Eigen.
+// Differences, all forced by the absent third-party types:
+//   - blitz::Array<double,N>  -> icebin::ArrayView<double> (pointer + extents, row-major, borrowed)
+//     for inputs and std::vector<double> for results;
+//   - Eigen matrix `M`        -> device CSR owned by the handle; host copies via M_coo();
+//   - errors: (*icebin_error)(-1, ...) -> icebin::Exception (an std::runtime_error), like
+//     everytrace::Exception (slib/icebin/error.hpp:28).
+// Header-only; C++14.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/icebin_hip.h"
+
+namespace icebin {
+
+struct Exception : std::runtime_error {
+    int code;
+    Exception(int c, std::string const &msg) : std::runtime_error(msg), code(c) {}
+};
+inline void check(int rc) {
+    if (rc != IBH_OK) throw Exception(rc, ibh_last_error());
+}
+
+/** Borrowed row-major view: stands in for blitz::Array<T,1> / <T,2> arguments. */
+template <class T>
+struct ArrayView {
+    T *data;
+    long extent0, extent1;     // extent1 == 1 for rank-1 views
+    int rank;
+    ArrayView(T *p, long n) : data(p), extent0(n), extent1(1), rank(1) {}
+    ArrayView(T *p, long n0, long n1) : data(p), extent0(n0), extent1(n1), rank(2) {}
+    ArrayView(std::vector<typename std::remove_const<T>::type> const &v)
+        : data(const_cast<T *>(v.data())), extent0((long)v.size()), extent1(1), rank(1) {}
+    long size() const { return extent0 * extent1; }
+};
+
+// ---- eigen_types.hpp:16-24 -------------------------------------------------------------------
+typedef long sparse_index_type;
+typedef int dense_index_type;
+typedef double val_type;
+
+/** spsparse::SparseSet<long,int> (eigen_types.hpp:24). */
+class SparseSetT {
+    ibh_sparse_set *h_;
+    SparseSetT(ibh_sparse_set *h) : h_(h) {}
+public:
+    SparseSetT() : h_(nullptr) { check(ibh_sparse_set_create(-1, &h_)); }
+    explicit SparseSetT(long sparse_extent) : h_(nullptr) { check(ibh_sparse_set_create(sparse_extent, &h_)); }
+    SparseSetT(SparseSetT const &) = delete;
+    SparseSetT &operator=(SparseSetT const &) = delete;
+    SparseSetT(SparseSetT &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    ~SparseSetT() { if (h_) ibh_sparse_set_destroy(h_); }
+    /** ibmisc id_sparse_set<SparseSetT>(n) (modele/merge_topo.cpp:48, IceCoupler.cpp:366) */
+    static SparseSetT identity(long n) { ibh_sparse_set *h; check(ibh_sparse_set_create_identity(n, &h)); return SparseSetT(h); }
+    long sparse_extent() const { int64_t v; check(ibh_sparse_set_sparse_extent(h_, &v)); return (long)v; }
+    int dense_extent() const { int32_t v; check(ibh_sparse_set_dense_extent(h_, &v)); return v; }
+    std::vector<long> to_sparse_all() const {
+        std::vector<int64_t> t((size_t)dense_extent());
+        check(ibh_sparse_set_to_sparse(h_, t.data()));
+        return std::vector<long>(t.begin(), t.end());
+    }
+    long to_sparse(int id) const { return to_sparse_all().at((size_t)id); }
+    ibh_sparse_set *handle() const { return h_; }
+};
+
+// ---- RegridMatrices.hpp:17-37 ----------------------------------------------------------------
+struct RegridParams {
+    bool scale;
+    bool correctA;
+    std::array<double, 3> sigma;
+    bool smooth() const { return sigma[0] != 0; }
+    RegridParams() : scale(true), correctA(false), sigma({0., 0., 0.}) {}
+    RegridParams(bool _scale, bool _correctA, std::array<double, 3> const &_sigma)
+        : scale(_scale), correctA(_correctA), sigma(_sigma) {}
+};
+
+namespace linear {
+/** ibmisc::linear::Weighted / Weighted_Eigen: M plus wM, Mw, dims, conservative, scaled. */
+class Weighted {
+    ibh_weighted *h_;
+public:
+    bool conservative, scaled;
+    explicit Weighted(ibh_weighted *h) : h_(h) {
+        int c, s;
+        check(ibh_weighted_flags(h, &c, &s));
+        conservative = c != 0; scaled = s != 0;
+    }
+    Weighted(Weighted const &) = delete;
+    Weighted &operator=(Weighted const &) = delete;
+    virtual ~Weighted() { if (h_) ibh_weighted_destroy(h_); }
+    ibh_weighted *handle() const { return h_; }
+
+    /** Dense shape {nrow_d, ncol_d} and number of stored entries. */
+    std::array<int, 2> shape_d() const { int32_t r, c; check(ibh_weighted_shape(h_, &r, &c, nullptr)); return {{r, c}}; }
+    long nnz() const { int64_t n; check(ibh_weighted_shape(h_, nullptr, nullptr, &n)); return (long)n; }
+    /** Sparse shape (dims[k]->sparse_extent()). */
+    std::array<long, 2> shape() const {
+        int64_t a, b;
+        check(ibh_weighted_dim(h_, 0, &a, nullptr)); check(ibh_weighted_dim(h_, 1, &b, nullptr));
+        return {{(long)a, (long)b}};
+    }
+    /** dims[k]->to_sparse(j) for all j */
+    std::vector<long> dim_to_sparse(int k) const {
+        std::vector<int64_t> t((size_t)shape_d()[(size_t)k]);
+        check(ibh_weighted_dim_to_sparse(h_, k, t.data()));
+        return std::vector<long>(t.begin(), t.end());
+    }
+    std::vector<double> wM() const { std::vector<double> v((size_t)shape_d()[0]); check(ibh_weighted_get_wM(h_, v.data())); return v; }
+    std::vector<double> Mw() const { std::vector<double> v((size_t)shape_d()[1]); check(ibh_weighted_get_Mw(h_, v.data())); return v; }
+    /** ->M as row-major COO in dense index space */
+    void M_coo(std::vector<int> &row, std::vector<int> &col, std::vector<double> &val) const {
+        size_t n = (size_t)nnz();
+        row.resize(n); col.resize(n); val.resize(n);
+        check(ibh_weighted_get_coo(h_, row.data(), col.data(), val.data()));
+    }
+
+    /** apply(A_b, fill, force_conservation, tmp): A_b is (nvar, ncol_d) or a rank-1 vector of
+        ncol_d values; returns (nvar, nrow_d) row-major.  The reference's TmpAlloc argument owned
+        the result; here the returned vector does. */
+    std::vector<double> apply(ArrayView<const double> const &A_b, double fill = std::nan(""),
+                              bool force_conservation = true) const {
+        auto sh = shape_d();
+        long nvar = A_b.rank == 1 ? 1 : A_b.extent0;
+        long ncol = A_b.rank == 1 ? A_b.extent0 : A_b.extent1;
+        if (ncol != sh[1]) throw Exception(IBH_EINVAL, "apply: input has " + std::to_string(ncol) +
+                                                        " columns, matrix has " + std::to_string(sh[1]));
+        std::vector<double> B((size_t)(nvar * sh[0]));
+        check(ibh_weighted_apply_host(h_, A_b.data, (int32_t)nvar, ncol, B.data(), sh[0], fill, force_conservation ? 1 : 0));
+        return B;
+    }
+    /** Device-resident variant: dA_b (nvar x lda) and dB_b (nvar x ldb) are HBM pointers; enqueues on stream. */
+    void apply_device(const double *dA_b, int nvar, long lda, double *dB_b, long ldb, double fill,
+                      bool force_conservation, void *stream) const {
+        check(ibh_weighted_apply_device(h_, dA_b, nvar, lda, dB_b, ldb, fill, force_conservation ? 1 : 0, stream));
+    }
+};
+typedef Weighted Weighted_Eigen;      // the concrete type callers name (RegridMatrices_Dynamic.hpp:27)
+}   // namespace linear
+
+// ---- AbbrGrid.hpp:40-89 ----------------------------------------------------------------------
+class ExchangeGrid {
+public:
+    std::vector<int> indices;       // Length*2: (ixA, ixI)
+    std::vector<double> overlaps;
+    void reserve(size_t n) { indices.reserve(n * 2); overlaps.reserve(n); }
+    void add(std::array<int, 2> const &index, double _area) {
+        indices.push_back(index[0]); indices.push_back(index[1]); overlaps.push_back(_area);
+    }
+    int dense_extent() const { return (int)overlaps.size(); }
+    long sparse_extent() const { return (long)overlaps.size(); }
+    long to_sparse(int id) const { return id; }
+    int ijk(int id, int index) const { return indices[(size_t)id * 2 + (size_t)index]; }
+    double native_area(int id) const { return overlaps[(size_t)id]; }
+};
+
+/** The parts of AbbrGrid (AbbrGrid.hpp:93-109) the regrid path reads. */
+struct AbbrGrid {
+    long sparse_extent = 0;             // dim.sparse_extent()
+    std::vector<long> dim_to_sparse;    // dim: dense -> sparse
+    std::vector<double> native_area;    // dense indexing
+    std::string name, sproj;
+};
+
+struct InterpStyle { enum { Z_INTERP = 0, ELEV_CLASS_INTERP = 1 }; };    // IceRegridder.hpp:36-39
+
+class GCMRegridder_Standard;
+class RegridMatrices_Dynamic;
+
+/** IceRegridder / IceRegridder_L0 (IceRegridder.hpp:46-133): one ice sheet. */
+class IceRegridder {
+    friend class GCMRegridder_Standard;
+    ibh_regridder *h_ = nullptr;
+    std::string _name;
+    long _nI = 0, _nX = 0;
+public:
+    int interp_style = InterpStyle::Z_INTERP;
+    ~IceRegridder() { if (h_) ibh_regridder_destroy(h_); }
+    std::string const &name() const { return _name; }
+    size_t nI() const { return (size_t)_nI; }
+    size_t nX() const { return (size_t)_nX; }
+    ibh_regridder *handle() const { return h_; }
+};
+
+// ---- RegridMatrices.hpp:39-62 ----------------------------------------------------------------
+class RegridMatrices {
+    RegridParams _params;
+public:
+    RegridMatrices(RegridParams const &params) : _params(params) {}
+    virtual ~RegridMatrices() {}
+    RegridParams const &params() const { return _params; }
+    virtual std::unique_ptr<linear::Weighted> matrix(std::string const &spec_name) const = 0;
+};
+
+// ---- RegridMatrices_Dynamic.hpp:20-59 --------------------------------------------------------
+class RegridMatrices_Dynamic : public RegridMatrices {
+    ibh_regrid_matrices *h_;
+public:
+    IceRegridder const *ice_regridder;
+    RegridMatrices_Dynamic(IceRegridder const *_ice_regridder, ibh_regrid_matrices *h, RegridParams const &params)
+        : RegridMatrices(params), h_(h), ice_regridder(_ice_regridder) {}
+    ~RegridMatrices_Dynamic() { if (h_) ibh_regrid_matrices_destroy(h_); }
+
+    /** matrix_d(spec_name, dims, params): ignores this->params() (RegridMatrices_Dynamic.hpp:51-54).
+        dims may be pre-populated and are appended to; they must outlive the result. */
+    std::unique_ptr<linear::Weighted_Eigen> matrix_d(std::string const &spec_name,
+                                                     std::array<SparseSetT *, 2> dims,
+                                                     RegridParams const &params) const {
+        ibh_weighted *w = nullptr;
+        check(ibh_regrid_matrices_matrix_d(h_, spec_name.c_str(), dims[0] ? dims[0]->handle() : nullptr,
+                                           dims[1] ? dims[1]->handle() : nullptr, params.scale, params.correctA,
+                                           params.sigma.data(), &w));
+        return std::unique_ptr<linear::Weighted_Eigen>(new linear::Weighted_Eigen(w));
+    }
+    /** Produces its own dims (RegridMatrices_Dynamic.cpp:425-437). */
+    std::unique_ptr<linear::Weighted> matrix(std::string const &spec_name) const override {
+        ibh_weighted *w = nullptr;
+        check(ibh_regrid_matrices_matrix(h_, spec_name.c_str(), &w));
+        return std::unique_ptr<linear::Weighted>(new linear::Weighted(w));
+    }
+};
+
+// ---- GCMRegridder.hpp:207-399 ----------------------------------------------------------------
+class GCMRegridder_Standard {
+    AbbrGrid agridA_;
+    std::vector<double> _hcdefs;
+    long hc_stride_A_ = 1, hc_stride_HC_ = 0;
+    std::vector<std::unique_ptr<IceRegridder>> sheets_;
+    std::map<std::string, size_t> sheets_index_;
+public:
+    bool correctA = false;
+    AbbrGrid const *agridA = nullptr;
+
+    /** init(agridA, hcdefs, indexingHC, correctA) (GCMRegridder.cpp:65-86).  indexingHC is given by its
+        two strides: iE = iA*stride_A + ihc*stride_HC; the Cython-built default is {1, nA}
+        (icebin_cython.cpp:69). */
+    void init(AbbrGrid &&_agridA, std::vector<double> &&hcdefs, std::array<long, 2> indexingHC_strides, bool _correctA) {
+        agridA_ = std::move(_agridA);
+        agridA = &agridA_;
+        _hcdefs = std::move(hcdefs);
+        hc_stride_A_ = indexingHC_strides[0]; hc_stride_HC_ = indexingHC_strides[1];
+        correctA = _correctA;
+    }
+    void init(AbbrGrid &&_agridA, std::vector<double> &&hcdefs, bool _correctA) {
+        long nA_ = _agridA.sparse_extent;
+        init(std::move(_agridA), std::move(hcdefs), {{1, nA_}}, _correctA);
+    }
+    std::vector<double> const &hcdefs() const { return _hcdefs; }
+    unsigned int nhc() const { return (unsigned int)_hcdefs.size(); }
+    unsigned long nA() const { return (unsigned long)agridA_.sparse_extent; }
+    unsigned long nE() const { return nA() * nhc(); }                      // GCMRegridder.hpp:273
+    size_t nI(int sheet_index) const { return sheets_.at((size_t)sheet_index)->nI(); }
+
+    /** add_sheet(name, regridder) + IceRegridder::init (GCMRegridder.hpp:353-367, IceRegridder.cpp:93-119):
+        the ice grid is given by its size, the exchange grid by value; gridA_proj_area (dense, like
+        agridA.native_area) may be empty = no projection (IceRegridder.cpp:106-108). */
+    size_t add_sheet(std::string const &name, long nI, ExchangeGrid const &aexgrid,
+                     std::vector<double> const &gridA_proj_area = {}, int interp_style = InterpStyle::Z_INTERP) {
+        std::unique_ptr<IceRegridder> sheet(new IceRegridder);
+        std::vector<int64_t> a2s(agridA_.dim_to_sparse.begin(), agridA_.dim_to_sparse.end());
+        std::vector<double> const &proj = gridA_proj_area.empty() ? agridA_.native_area : gridA_proj_area;
+        ibh_regridder_desc d{};
+        d.nX = (int64_t)aexgrid.overlaps.size();
+        d.ex_indices = aexgrid.indices.data(); d.ex_area = aexgrid.overlaps.data();
+        d.nI = nI; d.nA = agridA_.sparse_extent; d.nA_dense = (int32_t)a2s.size();
+        d.A_to_sparse = a2s.data(); d.A_native_area = agridA_.native_area.data(); d.A_proj_area = proj.data();
+        d.nhc = (int32_t)_hcdefs.size(); d.hcdefs = _hcdefs.data();
+        d.hc_stride_A = hc_stride_A_; d.hc_stride_HC = hc_stride_HC_; d.interp_style = interp_style;
+        check(ibh_regridder_create(&d, &sheet->h_));
+        sheet->_name = name; sheet->_nI = nI; sheet->_nX = (long)d.nX; sheet->interp_style = interp_style;
+        size_t ix = sheets_.size();
+        sheets_index_[name] = ix;
+        sheets_.push_back(std::move(sheet));
+        return ix;
+    }
+    /** ice_regridders().index.at(name) */
+    size_t sheet_index(std::string const &name) const {
+        auto it = sheets_index_.find(name);
+        if (it == sheets_index_.end()) throw Exception(IBH_ENOKEY, "no ice sheet named '" + name + "'");
+        return it->second;
+    }
+    IceRegridder const *ice_regridder(size_t ix) const { return sheets_.at(ix).get(); }
+
+    /** regrid_matrices(sheet_index, elevmaskI, params = RegridParams()) (GCMRegridder.hpp:290-293;
+        RegridMatrices_Dynamic.cpp:334-402).  elevmaskI is copied. */
+    std::unique_ptr<RegridMatrices_Dynamic> regrid_matrices(int sheet_index, ArrayView<const double> const &elevmaskI,
+                                                            RegridParams const &params = RegridParams()) const {
+        IceRegridder const *regridder = sheets_.at((size_t)sheet_index).get();
+        ibh_regrid_matrices *rm = nullptr;
+        check(ibh_regrid_matrices_create(regridder->h_, elevmaskI.data, elevmaskI.size(), params.scale, params.correctA,
+                                         params.sigma.data(), &rm));
+        return std::unique_ptr<RegridMatrices_Dynamic>(new RegridMatrices_Dynamic(regridder, rm, params));
+    }
+    /** GCMRegridder::wA (GCMRegridder.hpp:305-315, icebin_cython.cpp:103-117) */
+    std::vector<double> wA(std::string const &ice_sheet_name, bool native, double fill = 0.) const {
+        std::vector<double> out((size_t)nA());
+        check(ibh_regridder_wA(sheets_.at(sheet_index(ice_sheet_name))->h_, native, fill, out.data()));
+        return out;
+    }
+};
+
+// ---- pylib/icebin_cython.hpp:70-87 -----------------------------------------------------------
+namespace cython {
+/** new_regrid_matrices(gcm, sheet_name, elevmaskI, scale, correctA, sigma_x, sigma_y, sigma_z, conserve):
+    like the reference (icebin_cython.cpp:215-236) looks the sheet up by name, checks the shape {nI}
+    and ignores `conserve`.  The PyObject* becomes a plain (pointer, length). */
+inline RegridMatrices *new_regrid_matrices(GCMRegridder_Standard const *gcm, std::string const &sheet_name,
+                                           const double *elevmaskI, long elevmaskI_len, bool scale, bool correctA,
+                                           double sigma_x, double sigma_y, double sigma_z, bool /*conserve*/) {
+    auto sheet_index = gcm->sheet_index(sheet_name);
+    return gcm->regrid_matrices((int)sheet_index, ArrayView<const double>(elevmaskI, elevmaskI_len),
+                                RegridParams(scale, correctA, {{sigma_x, sigma_y, sigma_z}})).release();
+}
+/** RegridMatrices_matrix(cself, spec_name) (icebin_cython.cpp:195-198) */
+inline linear::Weighted *RegridMatrices_matrix(RegridMatrices *cself, std::string const &spec_name) {
+    return cself->matrix(spec_name).release();
+}
+}   // namespace cython
+
+}   // namespace icebin
