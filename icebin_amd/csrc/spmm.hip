@@ -55,71 +55,145 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nb) {
     return base + slot;
 }
 
+// blockIdx -> (row, field chunk).  Workgroups are dealt round-robin over the 8 XCDs, each with its
+// own L2.  Two rows that share X lines (an ice cell straddling two GCM cells is a column of both)
+// read them for the SAME field chunk, so:
+//   mode 1 (nfc a multiple of 8, or 1/2/4): an XCD owns whole field chunks and runs every row for
+//           them -- no X line is fetched by two XCDs, all XCDs do identical work; the (small) CSR
+//           is read by every XCD and served from the memory-side Infinity Cache after the first.
+//   mode 0: contiguous ranges of (row, chunk) pairs per XCD (rows of one chunk share the staged
+//           CSR segment through L2); used when the chunk count does not split over 8 XCDs.
+__device__ __forceinline__ bool block_to_task(int b, int nrow, int nfc, int mode, int &r, int &fc) {
+    if (mode == 1) {
+        const int x = b & 7, slot = b >> 3;
+        if (nfc >= 8) {                       // nfc % 8 == 0
+            const int per = nfc >> 3;
+            r = slot / per;
+            fc = x + 8 * (slot - r * per);
+        } else {                              // nfc in {1,2,4}: 8/nfc XCDs share one chunk, split by row range
+            const int m = 8 / nfc;
+            fc = x % nfc;
+            const int part = x / nfc;
+            const int r0 = (int)((long)nrow * part / m), r1 = (int)((long)nrow * (part + 1) / m);
+            r = r0 + slot;
+            if (r >= r1) return false;
+        }
+        return r < nrow;
+    }
+    const int logical = xcd_contiguous(b, nrow * nfc);
+    r = logical / nfc;
+    fc = logical - r * nfc;
+    return true;
+}
+
 constexpr int RB_THREADS = 256;
-constexpr int RB_SEG = 2048;    // nnz staged per pass: 24 KB of LDS
+constexpr int RB_SEG = 1024;    // nnz staged per pass: 12 KB of LDS
+constexpr int RB_STAGE = RB_SEG / RB_THREADS;
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// One field's X row through a buffer descriptor: 32-bit per-lane byte offset, SGPR base.  The
+// same voffset (col << 3) serves every field of the wave, so a gathered element costs one
+// buffer_load + one FMA instead of a 64-bit address computation per load; at the 40 MB headline
+// size the kernel is as much instruction-issue- as bandwidth-limited.
+__device__ __forceinline__ double xload(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0));
+}
 
 // FPW = fields per wave, WK = waves that split the nnz range of the row.
 // The 4 waves form WF = 4/WK groups over fields; a block covers FB = FPW*WF fields.
 template <int FPW, int WK, int UNROLL>
 __global__ __launch_bounds__(RB_THREADS) void spmm_rowblock_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
-    const double *__restrict__ X, long ldx, double *__restrict__ Y, long ldy, int nrow, int nf, int nfc,
-    const double *__restrict__ wM, double fill)
+    const double *__restrict__ X, long ldx, int ncol, double *__restrict__ Y, long ldy, int nrow, int nf, int nfc,
+    int xcd_mode, const double *__restrict__ wM, double fill)
 {
     constexpr int WF = 4 / WK;
     constexpr int FB = FPW * WF;
+    constexpr int STEP = WK * 64;
+    constexpr int BATCH = UNROLL * STEP;
     __shared__ int s_col[RB_SEG];
     __shared__ double s_val[RB_SEG];
     __shared__ double s_part[WK][FB];
 
-    const int nb = nrow * nfc;
-    const int logical = xcd_contiguous(blockIdx.x, nb);
-    const int r = logical / nfc;
-    const int fc = logical - r * nfc;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int r, fc;
+    if (!block_to_task(blockIdx.x, nrow, nfc, xcd_mode, r, fc)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // provably wave-uniform
     const int wf = wave % WF, wk = wave / WF;
     const int f0 = fc * FB + wf * FPW;
 
-    const double *xf[FPW];
+    __amdgpu_buffer_rsrc_t rs[FPW];
 #pragma unroll
     for (int j = 0; j < FPW; ++j) {
-        int f = f0 + j < nf ? f0 + j : nf - 1;    // clamp: tail fields read valid memory, never stored
-        xf[j] = X + (long)f * ldx;
+        const int f = f0 + j < nf ? f0 + j : nf - 1;    // clamp: tail fields read valid memory, never stored
+        rs[j] = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)f * ldx), 0, ncol * 8, 0x00020000);
     }
     double acc[FPW];
 #pragma unroll
     for (int j = 0; j < FPW; ++j) acc[j] = 0.0;
 
     const int beg = rowptr[r], end = rowptr[r + 1];
-    constexpr int STEP = WK * 64;
     for (int seg = beg; seg < end; seg += RB_SEG) {
         const int n = min(RB_SEG, end - seg);
         if (seg != beg) __syncthreads();
-        for (int k = threadIdx.x; k < n; k += RB_THREADS) {
-            s_col[k] = colind[seg + k];
-            s_val[k] = vals[seg + k];
+        {   // stage the row segment: all loads first (clamped, unconditional), then the LDS writes
+            int cc[RB_STAGE];
+            double vv[RB_STAGE];
+#pragma unroll
+            for (int i = 0; i < RB_STAGE; ++i) {
+                const int k = min((int)threadIdx.x + i * RB_THREADS, n - 1);
+                cc[i] = colind[seg + k];
+                vv[i] = vals[seg + k];
+            }
+#pragma unroll
+            for (int i = 0; i < RB_STAGE; ++i) {
+                const int k = threadIdx.x + i * RB_THREADS;
+                if (k < n) { s_col[k] = cc[i]; s_val[k] = vv[i]; }
+            }
         }
         __syncthreads();
-        // Uniform batches of UNROLL*STEP entries: every lane issues all UNROLL*FPW loads of a batch
-        // before the first FMA, so a row costs ceil(n / (UNROLL*STEP)) memory round trips.  Lanes past
-        // the end re-read the last entry and are masked at the FMA (never multiplied by 0: 0*NaN).
-        for (int k0 = wk * 64 + lane; k0 - lane < n; k0 += UNROLL * STEP) {
-            int c[UNROLL];
+        // Full batches: every lane issues UNROLL*FPW loads before the first FMA, no predication.
+        const int nfull = n - n % BATCH;
+        int kb = 0;
+        for (; kb < nfull; kb += BATCH) {
+            int off[UNROLL];
+            double v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int k = kb + wk * 64 + lane + u * STEP;
+                off[u] = s_col[k] << 3;
+                v[u] = s_val[k];
+            }
+            double x[FPW][UNROLL];
+#pragma unroll
+            for (int j = 0; j < FPW; ++j)
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) x[j][u] = xload(rs[j], off[u]);
+#pragma unroll
+            for (int j = 0; j < FPW; ++j)
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) acc[j] = fma(v[u], x[j][u], acc[j]);
+        }
+        // Tail batch: lanes past the end re-read the last entry and are masked at the FMA (never
+        // multiplied by 0: 0*NaN must not leak into a row).
+        if (kb + wk * 64 < n) {
+            int off[UNROLL];
             double v[UNROLL];
             bool ok[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                const int k = k0 + u * STEP;
+                const int k = kb + wk * 64 + lane + u * STEP;
                 ok[u] = k < n;
                 const int kk = ok[u] ? k : n - 1;
-                c[u] = s_col[kk];
+                off[u] = s_col[kk] << 3;
                 v[u] = s_val[kk];
             }
             double x[FPW][UNROLL];
 #pragma unroll
             for (int j = 0; j < FPW; ++j)
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) x[j][u] = xf[j][c[u]];
+                for (int u = 0; u < UNROLL; ++u) x[j][u] = xload(rs[j], off[u]);
 #pragma unroll
             for (int j = 0; j < FPW; ++j)
 #pragma unroll
@@ -172,16 +246,25 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     if (n > 1) { c1 = colind[beg + 1]; v1 = vals[beg + 1]; }
     if (n > 2) { c2 = colind[beg + 2]; v2 = vals[beg + 2]; }
     if (n > 3) { c3 = colind[beg + 3]; v3 = vals[beg + 3]; }
-    for (int f = fbeg; f < fend; ++f) {
-        const double *xf = X + (long)f * ldx;
-        double acc = 0.0;
-        // predicated, never multiplied by a padded zero: 0*NaN must not leak into a row
-        if (n > 0) acc = v0 * xf[c0];
-        if (n > 1) acc = fma(v1, xf[c1], acc);
-        if (n > 2) acc = fma(v2, xf[c2], acc);
-        if (n > 3) acc = fma(v3, xf[c3], acc);
-        for (int k = beg + 4; k < end; ++k) acc = fma(vals[k], xf[colind[k]], acc);
-        __builtin_nontemporal_store(dead ? fill : acc, &Y[(long)f * ldy + r]);
+    constexpr int G = 8;    // fields in flight per thread: G gathers issued before the first store
+    for (int f0 = fbeg; f0 < fend; f0 += G) {
+        double acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int f = f0 + g < fend ? f0 + g : fend - 1;
+            const double *xf = X + (long)f * ldx;
+            // predicated, never multiplied by a padded zero: 0*NaN must not leak into a row
+            double a = 0.0;
+            if (n > 0) a = v0 * xf[c0];
+            if (n > 1) a = fma(v1, xf[c1], a);
+            if (n > 2) a = fma(v2, xf[c2], a);
+            if (n > 3) a = fma(v3, xf[c3], a);
+            for (int k = beg + 4; k < end; ++k) a = fma(vals[k], xf[colind[k]], a);
+            acc[g] = a;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (f0 + g < fend) __builtin_nontemporal_store(dead ? fill : acc[g], &Y[(long)(f0 + g) * ldy + r]);
     }
 }
 
@@ -231,17 +314,23 @@ static void launch_rowblock(const ibh_weighted *w, const double *dA, int nvar, l
 {
     constexpr int FB = FPW * (4 / WK);
     const int nfc = ceil_div(nvar, FB);
-    const long nb = (long)w->nrow * nfc;
+    int xcd_mode = (nfc % 8 == 0 || nfc == 1 || nfc == 2 || nfc == 4) ? 1 : 0;
+    xcd_mode = get_tuning("rowblock_xcd_mode", xcd_mode);
+    long nb = (long)w->nrow * nfc;
+    if (xcd_mode == 1 && nfc < 8) {           // 8/nfc XCDs per chunk, each a row range of <= ceil(nrow/m) rows
+        const int m = 8 / nfc;
+        nb = 8l * ((w->nrow + m - 1) / m + 1);
+    }
     IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
+    IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
     const int unroll = get_tuning("rowblock_unroll", 8);
 #define IBH_RB(U)                                                                                        \
     hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U>), dim3((unsigned)nb), dim3(RB_THREADS), 0, stream, \
-                       w->rowptr.p, w->colind.p, w->val.p, dA, lda, dB, ldb, w->nrow, nvar, nfc, w->wM.p, fill)
+                       w->rowptr.p, w->colind.p, w->val.p, dA, lda, w->ncol, dB, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill)
     if (unroll == 1) IBH_RB(1);
     else if (unroll == 2) IBH_RB(2);
-    else if (unroll == 6) IBH_RB(6);
     else if (unroll == 8) IBH_RB(8);
-    else if (unroll == 12) IBH_RB(12);
+    else if (unroll == 14 && FPW <= 2) IBH_RB(14);
     else IBH_RB(4);
 #undef IBH_RB
     IBH_HIP(hipGetLastError());
@@ -262,7 +351,11 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
     if (kernel == 1) {
         int fpw = get_tuning("rowblock_fpw", 0), wk = get_tuning("rowblock_wk", 0);
         if (fpw == 0 || wk == 0) {
-            if (nvar >= 8) { fpw = 2; wk = 1; }
+            // enough workgroups to give every CU ~8: small problems are latency-bound and want many
+            // small tasks, big ones amortise the staged row segment over more fields
+            const long pairs = (long)w->nrow * nvar;
+            if (nvar >= 16 && pairs >= 4 * 8192) { fpw = 4; wk = 1; }
+            else if (nvar >= 8 && pairs >= 2 * 8192) { fpw = 2; wk = 1; }
             else if (nvar >= 4) { fpw = 1; wk = 1; }
             else if (nvar >= 2) { fpw = 1; wk = 2; }
             else { fpw = 1; wk = 4; }
@@ -276,6 +369,8 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
         else if (fpw == 1 && wk == 2) launch_rowblock<1, 2>(w, dA, nvar, lda, dB, ldb, fill, stream);
         else if (fpw == 2 && wk == 4) launch_rowblock<2, 4>(w, dA, nvar, lda, dB, ldb, fill, stream);
         else if (fpw == 4 && wk == 4) launch_rowblock<4, 4>(w, dA, nvar, lda, dB, ldb, fill, stream);
+        else if (fpw == 8 && wk == 4) launch_rowblock<8, 4>(w, dA, nvar, lda, dB, ldb, fill, stream);
+        else if (fpw == 8 && wk == 2) launch_rowblock<8, 2>(w, dA, nvar, lda, dB, ldb, fill, stream);
         else launch_rowblock<1, 4>(w, dA, nvar, lda, dB, ldb, fill, stream);
     } else {
         int fper = get_tuning("shortrow_fper", 16);

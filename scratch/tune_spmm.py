@@ -32,7 +32,7 @@ def run(steps=300):
 variants = eval(sys.argv[4]) if len(sys.argv) > 4 else None
 if variants is None:
     variants = [dict(rowblock_fpw=f, rowblock_wk=k, rowblock_unroll=u) for f,k,u in
-                [(4,1,4),(4,1,6),(4,1,8),(4,1,12),(2,1,8),(2,1,12),(8,1,6),(1,1,12),(4,2,6),(2,2,6),(2,2,12),(1,2,12),(1,4,4)]]
+                [(4,1,4),(4,1,2),(4,1,8),(2,1,4),(2,1,8),(8,1,2),(8,1,4),(1,1,8),(4,2,4),(2,2,4)]]
 for v in variants:
     for k, val in v.items(): icebin_amd.set_tuning(k, val)
     us = run()

@@ -252,3 +252,68 @@ def test_device_resident_apply_torch():
         dy = w.apply_device(dx, force_conservation=False)
     s.synchronize()
     assert rel_linf(dy.cpu().numpy(), o.apply(x)) <= FIELD_RTOL
+
+
+def _conservation(W, x, y):
+    a = math.fsum((W.Mw * x).tolist())
+    b = math.fsum((W.wM * y).tolist())
+    return abs(a - b) / abs(a)
+
+
+def test_config4_full_size_1km_properties_and_parity():
+    # BASELINE config 4 at full size: Greenland 1 km (4 204 301 cells) <-> 1x1 deg; oracle parity on the
+    # matrices (seconds on one core) and size-independent properties on the fields.
+    g, em, mm, rg = setup("g1")
+    assert g["nI"] == 4204301
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    AvI, IvA = rm.matrix("AvI"), rm.matrix("IvA")
+    assert_same_weighted(AvI, rg.matrix_d("AvI", em, scale=True, correctA=True), "AvI g1")
+    assert_same_weighted(IvA, rg.matrix_d("IvA", em, scale=True, correctA=True), "IvA g1")
+    x = syn.fields(4, AvI.ncol_d)
+    y = AvI.apply(x)
+    for k in range(4):
+        assert _conservation(AvI, x[k], y[k]) < 1e-13
+    # linearity and the constant: M(a*x + b) == a*Mx + b*M1
+    ones = np.ones((1, AvI.ncol_d))
+    y1 = AvI.apply(ones)
+    z = AvI.apply(2.5 * x[:1] - 3.0 * ones)
+    assert rel_linf(z, 2.5 * y[:1] - 3.0 * y1) <= 1e-12
+    # with correctA the constant is scaled by proj/native per GCM cell; I -> A -> I returns it
+    back = IvA.apply(y1)
+    assert np.all(np.abs(back - 1.0) < 1e-11)
+
+
+def test_config5_antarctica_1km_assembly_and_apply_properties():
+    # BASELINE config 5 (the Antarctic sheet, 36 012 001 ice cells, 1/2 deg GCM): COO -> CSR assembly +
+    # apply at full size.  Too large for the single-core oracle: checked through properties.
+    g = syn.make_grids("a1h")
+    assert g["nI"] == 36012001
+    em = syn.dome_elevmask(g)
+    mm = icebin_amd.from_synthetic(g)
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=False)
+    AvI = rm.matrix("AvI")
+    n_unmasked = int(np.isfinite(em).sum())
+    assert AvI.ncol_d == n_unmasked and AvI.nnz >= n_unmasked
+    # dims: first-seen order over an (iA, iI)-sorted exchange grid -> the dense->sparse table of I is a
+    # permutation of the unmasked cells; of A strictly ascending
+    dI, dA = AvI.dim(1), AvI.dim(0)
+    assert np.array_equal(np.sort(dI), np.flatnonzero(np.isfinite(em)))
+    assert np.all(np.diff(dA) > 0)
+    rowptr, col, val = AvI.csr_dense()
+    assert rowptr[-1] == AvI.nnz and np.all(np.diff(rowptr) >= 0)
+    # scaled rows sum to 1 (M = diag(1/wM) * ApvI), weights are areas: sum(wM) == sum(Mw) == unmasked overlap area
+    rs = np.add.reduceat(val, rowptr[:-1][np.diff(rowptr) > 0])
+    assert np.all(np.abs(rs - 1.0) < 1e-12)
+    wM, Mw = AvI.wM, AvI.Mw
+    ok = np.isfinite(em[g["ex_indices"][:, 1]])
+    total = math.fsum(g["ex_area"][ok].tolist())
+    assert abs(math.fsum(wM.tolist()) - total) / total < 1e-13
+    assert abs(math.fsum(Mw.tolist()) - total) / total < 1e-13
+    x = syn.fields(2, AvI.ncol_d)
+    y = AvI.apply(x)
+    for k in range(2):
+        assert _conservation(AvI, x[k], y[k]) < 1e-13
+    IvA = rm.matrix("IvA")
+    assert IvA.nnz == AvI.nnz and IvA.last_kernel() == "none"
+    back = IvA.apply(AvI.apply(np.ones((1, AvI.ncol_d))))
+    assert IvA.last_kernel() == "shortrow" and np.all(np.abs(back - 1.0) < 1e-11)
