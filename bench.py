@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--matrix", default="AvI")
     ap.add_argument("--fields", type=int, default=64, help="fields per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steps-per-gather", type=int, default=16, help="N>1: applies per RCCL all-gather")
     ap.add_argument("--warm", action="store_true", help="reuse ONE field batch (Infinity-Cache-resident numbers)")
     args = ap.parse_args()
 
@@ -63,7 +64,7 @@ def main():
     import icebin_amd
     from icebin_amd import _capi
     from icebin_amd import synthetic as syn
-    from icebin_amd.distributed import all_gather_fields
+    from icebin_amd.distributed import FieldShardedApply
 
     # ---- the workload: assemble the matrix on this GPU (replicated on every rank) -----------------
     grids = syn.make_grids(args.config)
@@ -89,50 +90,45 @@ def main():
     x0 = torch.from_numpy(x_host).to(dev)
     X = [x0 if b == 0 else x0 + 1e-3 * b for b in range(nbuf)]
     Y = [torch.empty((nf, nrow), dtype=torch.float64, device=dev) for _ in range(2)]
-    Yall = [torch.empty((world * nf, nrow), dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
 
     L = _capi.lib()
     fn = L.ibh_weighted_apply_device
     compute = torch.cuda.Stream(device=dev)
-    comm = torch.cuda.Stream(device=dev) if use_dist else None
     cs = C.c_void_p(compute.cuda_stream)
     xp = [C.c_void_p(x.data_ptr()) for x in X]
     yp = [C.c_void_p(y.data_ptr()) for y in Y]
     nan = float("nan")
-    ev_done = [torch.cuda.Event() for _ in range(2)]
-    ev_free = [torch.cuda.Event() for _ in range(2)]
+    sharded = FieldShardedApply(W, world * nf, None, dev, steps_per_gather=args.steps_per_gather) if use_dist else None
 
     def step(i):
-        s = i & 1
-        if use_dist and i >= 2:
-            compute.wait_event(ev_free[s])          # Y[s] was handed to the gather two steps ago
-        rc = fn(W._h, xp[i % nbuf], nf, ncol, yp[s], nrow, nan, 0, cs)
+        if use_dist:        # field-sharded SpMM + (grouped) all-gather, icebin_amd/distributed.py
+            sharded.apply(X[i % nbuf])
+            return
+        rc = fn(W._h, xp[i % nbuf], nf, ncol, yp[i & 1], nrow, nan, 0, cs)
         if rc != 0:
             _capi.check(rc)
-        if use_dist:
-            ev_done[s].record(compute)
-            with torch.cuda.stream(comm):
-                comm.wait_event(ev_done[s])
-                all_gather_fields(Y[s], world * nf, None, out=Yall[s])
-                ev_free[s].record(comm)
 
     def sync_all():
+        if use_dist:
+            sharded.flush()
+            sharded.wait()
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(i)
-    sync_all()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(compute)
-    for i in range(args.steps):
-        step(i)
-    e1.record(compute)
-    sync_all()
-    dt = time.perf_counter() - t0
+    with torch.cuda.stream(compute):
+        for i in range(args.warmup):
+            step(i)
+        sync_all()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(compute)
+        for i in range(args.steps):
+            step(i)
+        e1.record(compute)
+        sync_all()
+        dt = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / max(args.steps, 1)      # avg launch-to-launch on the launch stream
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -155,7 +151,7 @@ def main():
                        "nI": grids["nI"], "nX": int(len(grids["ex_area"])), "unmasked_cells": n_unmasked,
                        "nrow_d": nrow, "ncol_d": ncol, "nnz": nnz, "fields_per_gpu": nf, "field_batches": nbuf,
                        "cache": "warm" if args.warm else "cold (rotating batches > Infinity Cache)",
-                       "kernel": W.last_kernel(), "parallelism": "field-shard x%d + all-gather" % world if world > 1 else "1 GPU"},
+                       "kernel": W.last_kernel(), "parallelism": ("field-shard x%d + all-gather every %d steps" % (world, args.steps_per_gather)) if use_dist else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, W.last_kernel()),
                          "kernel_us": kernel_ms * 1e3, "algorithmic_bytes": B},
@@ -163,7 +159,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(grids, em, args, x_host, n_unmasked)
-        y = Y[(args.steps - 1) & 1].cpu().numpy() if args.steps > 0 else None
+        if use_dist:
+            y = sharded.result(0, 0).cpu().numpy()
+        else:
+            y = Y[(args.steps - 1) & 1].cpu().numpy() if args.steps > 0 else None
         result["finite_output"] = bool(y is not None and np.isfinite(y).all())
         print(json.dumps(result), flush=True)
     if use_dist:

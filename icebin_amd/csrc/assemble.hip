@@ -153,6 +153,10 @@ __global__ void k_iota_i32(int32_t *p, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = (int32_t)i;
 }
+__global__ void k_iota_i64(int64_t *p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int64_t)i;
+}
 __global__ void k_scatter_existing(int32_t *tab, const int64_t *to_sparse, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) tab[to_sparse[i]] = i;
@@ -219,66 +223,90 @@ struct DeviceSet {
 };
 
 // Number `set` through the entries of `list` (keys of kind `key`), appending new keys first-seen.
-static DeviceSet number_set(const RgView &rg, ibh_sparse_set *set, int64_t sparse_extent, int list, int key,
-                            int64_t max_new, int *d_err, hipStream_t st) {
+// Two phases around ONE host sync shared by the whole build: begin() enqueues everything up to the
+// scan (the number of new keys lands in *d_new), finish() assigns the ids once the host knows it.
+struct Numbering {
+    DeviceSet ds;
+    ibh_sparse_set *set = nullptr;
+    uint32_t *first = nullptr, *flag = nullptr;
+    int list = 0, key = 0;
+    int64_t max_new = 0;
+    bool done = false;          // identity set that already covers the whole sparse space
+};
+
+static Numbering number_set_begin(const RgView &rg, ibh_sparse_set *set, int64_t sparse_extent, int list, int key,
+                                  int64_t max_new, int *d_err, uint32_t *d_new, hipStream_t st) {
     Arena &A = arena();
     set->sparse_extent = sparse_extent;                       // set_sparse_extent, RegridMatrices_Dynamic.cpp:69-72
-    DeviceSet ds;
+    Numbering nb;
+    nb.set = set; nb.list = list; nb.key = key;
+    DeviceSet &ds = nb.ds;
     ds.n_old = set->dense_extent();
     if (set->identity) {
         IBH_CHECK(ds.n_old <= sparse_extent, "identity dims larger than sparse extent");
-    } else {
-        for (int64_t s : set->to_sparse)
-            IBH_CHECK(s >= 0 && s < sparse_extent, "dims entry %ld outside sparse extent %ld", (long)s, (long)sparse_extent);
+    } else if (set->host_n == ds.n_old) {
+        for (int32_t i = 0; i < ds.n_old; ++i)
+            IBH_CHECK(set->host[(size_t)i] >= 0 && set->host[(size_t)i] < sparse_extent, "dims entry %ld outside sparse extent %ld",
+                      (long)set->host[(size_t)i], (long)sparse_extent);
     }
     if (max_new > sparse_extent - ds.n_old) max_new = sparse_extent - ds.n_old;
+    nb.max_new = max_new;
     ds.tab = A.get<int32_t>((size_t)sparse_extent);
     const int64_t cap = (int64_t)ds.n_old + max_new;
     ds.to_sparse = A.get<int64_t>((size_t)cap);
     const int T = 256;
-    if (set->identity) {
-        hipLaunchKernelGGL(k_fill_i32, dim3(ceil_div(sparse_extent, T)), dim3(T), 0, st, ds.tab, (size_t)sparse_extent, -1);
-        hipLaunchKernelGGL(k_iota_i32, dim3(ceil_div(ds.n_old, T)), dim3(T), 0, st, ds.tab, (size_t)ds.n_old);
-    } else {
-        hipLaunchKernelGGL(k_fill_i32, dim3(ceil_div(sparse_extent, T)), dim3(T), 0, st, ds.tab, (size_t)sparse_extent, -1);
-    }
+    hipLaunchKernelGGL(k_fill_i32, dim3(ceil_div(sparse_extent, T)), dim3(T), 0, st, ds.tab, (size_t)sparse_extent, -1);
     if (ds.n_old) {
-        IBH_HIP(hipMemcpyAsync(ds.to_sparse, set->to_sparse.data(), sizeof(int64_t) * (size_t)ds.n_old,
-                               hipMemcpyHostToDevice, st));
-        if (!set->identity)
+        if (set->identity) {
+            hipLaunchKernelGGL(k_iota_i32, dim3(ceil_div(ds.n_old, T)), dim3(T), 0, st, ds.tab, (size_t)ds.n_old);
+            hipLaunchKernelGGL(k_iota_i64, dim3(ceil_div(ds.n_old, T)), dim3(T), 0, st, ds.to_sparse, (size_t)ds.n_old);
+        } else {
+            if (set->dev_n == ds.n_old)
+                IBH_HIP(hipMemcpyAsync(ds.to_sparse, set->dev.p, sizeof(int64_t) * (size_t)ds.n_old, hipMemcpyDeviceToDevice, st));
+            else {
+                set->ensure_host();
+                IBH_HIP(hipMemcpyAsync(ds.to_sparse, set->host.data(), sizeof(int64_t) * (size_t)ds.n_old, hipMemcpyHostToDevice, st));
+            }
             hipLaunchKernelGGL(k_scatter_existing, dim3(ceil_div(ds.n_old, T)), dim3(T), 0, st, ds.tab, ds.to_sparse, ds.n_old);
+        }
     }
     ds.n = ds.n_old;
-    if (set->identity && ds.n_old == sparse_extent) return ds;   // nothing can be new
-    uint32_t *first = A.get<uint32_t>((size_t)sparse_extent);
-    uint32_t *flag = A.get<uint32_t>((size_t)(2 * rg.nX));
-    uint32_t *d_total = A.get<uint32_t>(1);
-    IBH_HIP(hipMemsetAsync(first, 0xFF, sizeof(uint32_t) * (size_t)sparse_extent, st));
+    IBH_HIP(hipMemsetAsync(d_new, 0, sizeof(uint32_t), st));
+    if (set->identity && ds.n_old == sparse_extent) { nb.done = true; return nb; }   // nothing can be new
+    nb.first = A.get<uint32_t>((size_t)sparse_extent);
+    nb.flag = A.get<uint32_t>((size_t)(2 * rg.nX));
+    IBH_HIP(hipMemsetAsync(nb.first, 0xFF, sizeof(uint32_t) * (size_t)sparse_extent, st));
     const dim3 grid(ceil_div(rg.nX, T));
-    const bool ep = list == LIST_EP;
-    if (ep) hipLaunchKernelGGL(k_number_first<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, d_err);
-    else hipLaunchKernelGGL(k_number_first<false>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, d_err);
-    if (ep) hipLaunchKernelGGL(k_number_flag<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, flag);
-    else hipLaunchKernelGGL(k_number_flag<false>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, flag);
-    exclusive_scan_u32(flag, flag, (size_t)(2 * rg.nX), d_total, st);
-    uint32_t n_new = 0;
-    IBH_HIP(hipMemcpyAsync(&n_new, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    IBH_HIP(hipStreamSynchronize(st));
-    IBH_CHECK((int64_t)n_new <= max_new, "internal: more new keys (%u) than reserved (%ld)", n_new, (long)max_new);
+    if (list == LIST_EP) {
+        hipLaunchKernelGGL(k_number_first<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, nb.first, d_err);
+        hipLaunchKernelGGL(k_number_flag<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, nb.first, nb.flag);
+    } else {
+        hipLaunchKernelGGL(k_number_first<false>, grid, dim3(T), 0, st, rg, list, key, ds.tab, nb.first, d_err);
+        hipLaunchKernelGGL(k_number_flag<false>, grid, dim3(T), 0, st, rg, list, key, ds.tab, nb.first, nb.flag);
+    }
+    exclusive_scan_u32(nb.flag, nb.flag, (size_t)(2 * rg.nX), d_new, st);
+    return nb;
+}
+
+static void number_set_finish(const RgView &rg, Numbering &nb, uint32_t n_new, hipStream_t st) {
+    DeviceSet &ds = nb.ds;
+    ibh_sparse_set *set = nb.set;
+    if (nb.done || n_new == 0) return;
+    IBH_CHECK((int64_t)n_new <= nb.max_new, "internal: more new keys (%u) than reserved (%ld)", n_new, (long)nb.max_new);
     IBH_CHECK((int64_t)ds.n_old + n_new < (1ll << 31), "dense extent overflows int32");
-    if (ep) hipLaunchKernelGGL(k_number_assign<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, flag, ds.n_old, ds.to_sparse);
-    else hipLaunchKernelGGL(k_number_assign<false>, grid, dim3(T), 0, st, rg, list, key, ds.tab, first, flag, ds.n_old, ds.to_sparse);
+    const int T = 256;
+    const dim3 grid(ceil_div(rg.nX, T));
+    if (nb.list == LIST_EP) hipLaunchKernelGGL(k_number_assign<true>, grid, dim3(T), 0, st, rg, nb.list, nb.key, ds.tab, nb.first, nb.flag, ds.n_old, ds.to_sparse);
+    else hipLaunchKernelGGL(k_number_assign<false>, grid, dim3(T), 0, st, rg, nb.list, nb.key, ds.tab, nb.first, nb.flag, ds.n_old, ds.to_sparse);
     IBH_HIP(hipGetLastError());
     ds.n = ds.n_old + (int)n_new;
-    if (n_new) {
-        set->to_sparse.resize((size_t)ds.n);
-        IBH_HIP(hipMemcpyAsync(set->to_sparse.data() + ds.n_old, ds.to_sparse + ds.n_old, sizeof(int64_t) * n_new,
-                               hipMemcpyDeviceToHost, st));
-        IBH_HIP(hipStreamSynchronize(st));
-        set->identity = false;
-        set->to_dense_map.clear();
-    }
-    return ds;
+    // the set keeps its table on the device; the host copy is completed only when somebody asks
+    DevBuf<int64_t> grown((size_t)ds.n);
+    IBH_HIP(hipMemcpyAsync(grown.p, ds.to_sparse, sizeof(int64_t) * (size_t)ds.n, hipMemcpyDeviceToDevice, st));
+    if (set->identity) { set->host.clear(); set->host_n = 0; }     // an identity prefix was never materialised
+    set->dev = std::move(grown);
+    set->dev_n = set->n = ds.n;
+    set->identity = false;
 }
 
 // ---- contributions ---------------------------------------------------------------------------
@@ -354,20 +382,21 @@ __global__ void k_head_flags(const uint64_t *__restrict__ keys, size_t n, uint32
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) head[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1u : 0u;
 }
-// One thread per segment head: sequential sum in sorted (== emission) order, first term assigned.
-__global__ void k_segment_sum(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx,
-                              const double *__restrict__ term, size_t n, const uint32_t *__restrict__ upos,
-                              int32_t *__restrict__ row, int32_t *__restrict__ col, double *__restrict__ val) {
+// Duplicate (row,col) contributions are summed in sorted (== emission) order, the first term
+// ASSIGNED (Eigen's product and setFromTriplets both start from the first value, which keeps a
+// signed zero): k_segment_heads lists the segment boundaries, seg_sums<false> does the chains.
+__global__ void k_segment_heads(const uint64_t *__restrict__ keys, size_t n, const uint32_t *__restrict__ upos,
+                                uint32_t nseg, int32_t *__restrict__ segptr, int32_t *__restrict__ row,
+                                int32_t *__restrict__ col) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint64_t key = keys[k];
+    if (k == 0) segptr[nseg] = (int32_t)n;
     if (k != 0 && keys[k - 1] == key) return;
-    double s = term[idx[k]];
-    for (size_t m = k + 1; m < n && keys[m] == key; ++m) s = s + term[idx[m]];
     const uint32_t u = upos[k];
+    segptr[u] = (int32_t)k;
     row[u] = (int32_t)(key >> 32);
     col[u] = (int32_t)(key & 0xffffffffu);
-    val[u] = s;
 }
 __global__ void k_rowptr(const int32_t *__restrict__ row, long nnz, int nrow, int32_t *__restrict__ rowptr) {
     const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,14 +412,19 @@ __global__ void k_rowptr(const int32_t *__restrict__ row, long nnz, int nrow, in
 // ret = ret + v starting from 0.  Thread-per-segment suits 1-3 entry segments; the wave form
 // loads 64 values coalesced and replays the same sequential chain from registers (every lane
 // computes the identical sum), which is what long rows (10^2..10^4 entries) need.
+template <bool FROM_ZERO>
 __global__ void k_seg_sums_thread(const int32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
                                   const double *__restrict__ val, int nseg, double *__restrict__ out) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nseg) return;
+    int k = ptr[r];
+    const int end = ptr[r + 1];
     double s = 0.0;
-    for (int k = ptr[r]; k < ptr[r + 1]; ++k) s = s + val[idx ? idx[k] : (uint32_t)k];
+    if (!FROM_ZERO && k < end) { s = val[idx ? idx[k] : (uint32_t)k]; ++k; }
+    for (; k < end; ++k) s = s + val[idx ? idx[k] : (uint32_t)k];
     out[r] = s;
 }
+template <bool FROM_ZERO>
 __global__ void k_seg_sums_wave(const int32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
                                 const double *__restrict__ val, int nseg, double *__restrict__ out) {
     const int r = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -403,24 +437,30 @@ __global__ void k_seg_sums_wave(const int32_t *__restrict__ ptr, const uint32_t 
         const double v = k < end ? val[idx ? idx[k] : (uint32_t)k] : 0.0;
         const int cnt = min(64, end - base);
         const int lo = __double2loint(v), hi = __double2hiint(v);
-        if (cnt == 64) {
+        int j = 0;
+        if (!FROM_ZERO && base == beg) {      // first term assigned
+            s = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+            j = 1;
+        }
+        if (cnt == 64 && j == 0) {
 #pragma unroll
-            for (int j = 0; j < 64; ++j)
-                s = s + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+            for (int q = 0; q < 64; ++q)
+                s = s + __hiloint2double(__builtin_amdgcn_readlane(hi, q), __builtin_amdgcn_readlane(lo, q));
         } else {
-            for (int j = 0; j < cnt; ++j)
+            for (; j < cnt; ++j)
                 s = s + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
         }
     }
     if (lane == 0) out[r] = s;
 }
+template <bool FROM_ZERO>
 static void seg_sums(const int32_t *ptr, const uint32_t *idx, const double *val, int nseg, long nnz, double *out,
                      hipStream_t st) {
     if (nseg == 0) return;
     if (nnz >= 8l * nseg)
-        hipLaunchKernelGGL(k_seg_sums_wave, dim3(ceil_div((long)nseg * 64, 256)), dim3(256), 0, st, ptr, idx, val, nseg, out);
+        hipLaunchKernelGGL(k_seg_sums_wave<FROM_ZERO>, dim3(ceil_div((long)nseg * 64, 256)), dim3(256), 0, st, ptr, idx, val, nseg, out);
     else
-        hipLaunchKernelGGL(k_seg_sums_thread, dim3(ceil_div(nseg, 256)), dim3(256), 0, st, ptr, idx, val, nseg, out);
+        hipLaunchKernelGGL(k_seg_sums_thread<FROM_ZERO>, dim3(ceil_div(nseg, 256)), dim3(256), 0, st, ptr, idx, val, nseg, out);
 }
 __global__ void k_col_keys(const int32_t *__restrict__ col, long nnz, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
     const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -531,8 +571,9 @@ static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, 
     w->nnz = nnz;
     w->colind.alloc(nnz); w->val.alloc(nnz);
     int32_t *row = A.get<int32_t>(nnz);
-    hipLaunchKernelGGL(k_segment_sum, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.idx, t.term, t.n, head, row,
-                       w->colind.p, w->val.p);
+    int32_t *segptr = A.get<int32_t>((size_t)nnz + 1);
+    hipLaunchKernelGGL(k_segment_heads, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, head, nnz, segptr, row, w->colind.p);
+    seg_sums<false>(segptr, t.idx, t.term, (int)nnz, (long)t.n, w->val.p, st);
     hipLaunchKernelGGL(k_rowptr, dim3(ceil_div(nnz, T)), dim3(T), 0, st, row, (long)nnz, nrow, w->rowptr.p);
     IBH_HIP(hipGetLastError());
     *row_out = row;
@@ -574,23 +615,30 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     auto extent_of = [&](int key) -> int64_t {
         return key == KEY_A ? g->nA : key == KEY_E ? g->nA * (int64_t)g->nhc : key == KEY_I ? g->nI : g->nX;
     };
-    int *d_err = A.get<int>(1);
+    // counters read back with ONE sync: [0] first out-of-range exchange cell, [1] new row keys,
+    // [2] new column keys, [3] number of contributions
+    uint32_t *d_cnt = A.get<uint32_t>(4);
+    int *d_err = reinterpret_cast<int *>(d_cnt);
     const int big = 0x7fffffff;
     IBH_HIP(hipMemcpyAsync(d_err, &big, sizeof(int), hipMemcpyHostToDevice, st));
 
-    // dense numbering in the reference's order: the A/E-side Ur matrix is densified first
-    // (RegridMatrices_Dynamic.cpp:75-81, 178-183, 270-277), then the other one.
-    // (each user-visible set is numbered by exactly one Ur matrix, so the order between the two
-    // sets is immaterial; rows first.)
-    DeviceSet rset, cset;
-    auto do_rows = [&] { rset = number_set(rg, dims[0], extent_of(sp->row_key), sp->row_list, sp->row_key,
-                                           (sp->row_list == LIST_EP ? 2 : 1) * g->nX, d_err, st); };
-    auto do_cols = [&] { cset = number_set(rg, dims[1], extent_of(sp->col_key), sp->col_list, sp->col_key,
-                                           (sp->col_list == LIST_EP ? 2 : 1) * g->nX, d_err, st); };
-    do_rows(); do_cols();
-    int err_x = big;
-    IBH_HIP(hipMemcpyAsync(&err_x, d_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    // dense numbering in emission order; each user-visible set is numbered by exactly one Ur matrix
+    // (RegridMatrices_Dynamic.cpp:75-81, 86-90, 178-183, 187-190, 270-277), so the two are independent.
+    Numbering rnum = number_set_begin(rg, dims[0], extent_of(sp->row_key), sp->row_list, sp->row_key,
+                                      (sp->row_list == LIST_EP ? 2 : 1) * g->nX, d_err, d_cnt + 1, st);
+    Numbering cnum = number_set_begin(rg, dims[1], extent_of(sp->col_key), sp->col_list, sp->col_key,
+                                      (sp->col_list == LIST_EP ? 2 : 1) * g->nX, d_err, d_cnt + 2, st);
+    // contributions in emission (x) order: count + scan do not depend on the numbering
+    const int T = 256;
+    const dim3 grid(ceil_div(g->nX, T));
+    uint32_t *cnt = A.get<uint32_t>((size_t)g->nX);
+    if (uses_ep) hipLaunchKernelGGL(k_contrib_count<true>, grid, dim3(T), 0, st, rg, *sp, cnt);
+    else hipLaunchKernelGGL(k_contrib_count<false>, grid, dim3(T), 0, st, rg, *sp, cnt);
+    exclusive_scan_u32(cnt, cnt, (size_t)g->nX, d_cnt + 3, st);
+    uint32_t h_cnt[4];
+    IBH_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
     IBH_HIP(hipStreamSynchronize(st));
+    const int err_x = (int)h_cnt[0];
     if (err_x != big) {
         // message of linterp_1d_b, IceRegridder_L0.cpp:84-85
         std::vector<int32_t> ij(2);
@@ -599,19 +647,11 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
         IBH_HIP(hipMemcpy(&e, rm->elevmaskI.p + ij[1], sizeof(double), hipMemcpyDeviceToHost));
         fail(IBH_ERANGE, "Elevation %g out of bounds (%g, %g)", e < 0 ? 0.0 : e, g->hcdefs_h.front(), g->hcdefs_h.back());
     }
+    number_set_finish(rg, rnum, h_cnt[1], st);
+    number_set_finish(rg, cnum, h_cnt[2], st);
+    const DeviceSet &rset = rnum.ds, &cset = cnum.ds;
     const int nrow = rset.n, ncol = cset.n;
-
-    // contributions in emission (x) order
-    const int T = 256;
-    const dim3 grid(ceil_div(g->nX, T));
-    uint32_t *cnt = A.get<uint32_t>((size_t)g->nX);
-    uint32_t *d_total = A.get<uint32_t>(1);
-    if (uses_ep) hipLaunchKernelGGL(k_contrib_count<true>, grid, dim3(T), 0, st, rg, *sp, cnt);
-    else hipLaunchKernelGGL(k_contrib_count<false>, grid, dim3(T), 0, st, rg, *sp, cnt);
-    exclusive_scan_u32(cnt, cnt, (size_t)g->nX, d_total, st);
-    uint32_t ncontrib = 0;
-    IBH_HIP(hipMemcpyAsync(&ncontrib, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    IBH_HIP(hipStreamSynchronize(st));
+    const uint32_t ncontrib = h_cnt[3];
     Triplets t;
     t.n = ncontrib;
     t.keys = A.get<uint64_t>(t.n); t.keys_alt = A.get<uint64_t>(t.n);
@@ -629,7 +669,7 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     double *rs = A.get<double>((size_t)nrow), *cs = A.get<double>((size_t)ncol);
     double *rowmul = A.get<double>((size_t)nrow), *colmul = A.get<double>((size_t)ncol);
     w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
-    seg_sums(w->rowptr.p, nullptr, w->val.p, nrow, nnz, rs, st);
+    seg_sums<true>(w->rowptr.p, nullptr, w->val.p, nrow, nnz, rs, st);
     if (nnz) {
         uint64_t *ck = A.get<uint64_t>((size_t)nnz), *ck2 = A.get<uint64_t>((size_t)nnz);
         uint32_t *ci = A.get<uint32_t>((size_t)nnz), *ci2 = A.get<uint32_t>((size_t)nnz);
@@ -639,7 +679,7 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
         int32_t *scol = A.get<int32_t>((size_t)nnz), *colptr = A.get<int32_t>((size_t)ncol + 1);
         hipLaunchKernelGGL(k_keys_to_i32, dim3(ceil_div(nnz, T)), dim3(T), 0, st, ck, nnz, scol);
         hipLaunchKernelGGL(k_rowptr, dim3(ceil_div(nnz, T)), dim3(T), 0, st, scol, nnz, ncol, colptr);
-        seg_sums(colptr, ci, w->val.p, ncol, nnz, cs, st);
+        seg_sums<true>(colptr, ci, w->val.p, ncol, nnz, cs, st);
     } else if (ncol) {
         IBH_HIP(hipMemsetAsync(cs, 0, sizeof(double) * (size_t)ncol, st));
     }

@@ -1,7 +1,9 @@
 // capi.hip -- extern "C" entry points declared in include/icebin_hip.h.
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <memory>
+#include <mutex>
 
 #include "assemble.h"
 #include "common.h"
@@ -17,6 +19,68 @@ void fail(int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     throw Error(code, buf);
+}
+
+// ---- caching device allocator ----------------------------------------------------------------
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_blocks;   // (device, size class) -> blocks
+    size_t cached_bytes = 0;
+};
+Pool &pool() { static Pool *p = new Pool; return *p; }      // leaked on purpose: outlives the HIP runtime teardown
+constexpr size_t kMaxCached = size_t(32) << 30;
+
+size_t size_class(size_t bytes) {      // 512 B granules below 64 KiB, then eighth-of-a-power-of-two steps (<= 12.5 % slack)
+    if (bytes <= 65536) return (bytes + 511) & ~size_t(511);
+    size_t p2 = 1;
+    while ((p2 << 1) <= bytes) p2 <<= 1;
+    const size_t step = p2 >> 3;
+    return (bytes + step - 1) / step * step;
+}
+}  // namespace
+
+void *dev_alloc(size_t bytes, size_t *granted) {
+    const size_t cls = size_class(bytes);
+    int dev = 0;
+    IBH_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(pool().mu);
+        auto it = pool().free_blocks.find({dev, cls});
+        if (it != pool().free_blocks.end() && !it->second.empty()) {
+            void *p = it->second.back();
+            it->second.pop_back();
+            pool().cached_bytes -= cls;
+            *granted = cls;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, cls);
+    if (e == hipErrorOutOfMemory) {          // give the cache back and retry once
+        (void)hipGetLastError();
+        release_cached_memory();
+        e = hipMalloc(&p, cls);
+    }
+    if (e != hipSuccess) fail(e == hipErrorNoDevice ? IBH_ENODEVICE : IBH_EHIP, "hipMalloc(%zu) failed: %s", cls, hipGetErrorString(e));
+    *granted = cls;
+    return p;
+}
+void dev_free(void *p, size_t granted) {
+    if (!p) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;      // runtime already gone (process exit)
+    std::lock_guard<std::mutex> lk(pool().mu);
+    if (pool().cached_bytes + granted > kMaxCached) { (void)hipFree(p); return; }
+    pool().free_blocks[{dev, granted}].push_back(p);
+    pool().cached_bytes += granted;
+}
+void release_cached_memory() {
+    std::lock_guard<std::mutex> lk(pool().mu);
+    for (auto &kv : pool().free_blocks)
+        for (void *p : kv.second) (void)hipFree(p);
+    pool().free_blocks.clear();
+    pool().cached_bytes = 0;
 }
 
 static void require_device() {
@@ -36,8 +100,7 @@ static void check_weighted_device(const ibh_weighted *w) {
 
 static void make_identity(ibh_sparse_set *s, int64_t n) {
     s->sparse_extent = n;
-    s->to_sparse.resize((size_t)n);
-    for (int64_t i = 0; i < n; ++i) s->to_sparse[(size_t)i] = i;
+    s->n = (int32_t)n;
     s->identity = true;
 }
 
@@ -89,12 +152,14 @@ int ibh_sparse_set_from_array(int64_t sparse_extent, const int64_t *to_sparse, i
         IBH_CHECK(out != nullptr && n >= 0 && (n == 0 || to_sparse != nullptr), "bad arguments");
         std::unique_ptr<ibh_sparse_set> s(new ibh_sparse_set);
         s->sparse_extent = sparse_extent;
-        s->to_sparse.assign(to_sparse, to_sparse + n);
-        s->to_dense_map.reserve((size_t)n * 2);
+        s->host.assign(to_sparse, to_sparse + n);
+        s->n = s->host_n = n;
+        std::vector<int64_t> sorted(s->host);
+        std::sort(sorted.begin(), sorted.end());
         for (int32_t i = 0; i < n; ++i) {
-            IBH_CHECK(to_sparse[i] >= 0 && (sparse_extent < 0 || to_sparse[i] < sparse_extent),
-                      "sparse index %ld outside extent %ld", (long)to_sparse[i], (long)sparse_extent);
-            IBH_CHECK(s->to_dense_map.emplace(to_sparse[i], i).second, "duplicate sparse index %ld", (long)to_sparse[i]);
+            IBH_CHECK(sorted[(size_t)i] >= 0 && (sparse_extent < 0 || sorted[(size_t)i] < sparse_extent),
+                      "sparse index %ld outside extent %ld", (long)sorted[(size_t)i], (long)sparse_extent);
+            IBH_CHECK(i == 0 || sorted[(size_t)i] != sorted[(size_t)i - 1], "duplicate sparse index %ld", (long)sorted[(size_t)i]);
         }
         *out = s.release();
     });
@@ -108,8 +173,9 @@ int ibh_sparse_set_dense_extent(const ibh_sparse_set *s, int32_t *out) {
 }
 int ibh_sparse_set_to_sparse(const ibh_sparse_set *s, int64_t *out) {
     return guarded([&] {
-        IBH_CHECK(s && (out || s->to_sparse.empty()), "null argument");
-        std::copy(s->to_sparse.begin(), s->to_sparse.end(), out);
+        IBH_CHECK(s && (out || s->n == 0), "null argument");
+        s->ensure_host();
+        std::copy(s->host.begin(), s->host.begin() + s->n, out);
     });
 }
 
@@ -302,7 +368,8 @@ int ibh_weighted_dim_to_sparse(const ibh_weighted *w, int k, int64_t *out) {
         // a shared dims set may have grown after this matrix was built: report this matrix's extent
         const int32_t n = k == 0 ? w->nrow : w->ncol;
         IBH_CHECK(n == 0 || out, "null output");
-        std::copy(w->dims[k]->to_sparse.begin(), w->dims[k]->to_sparse.begin() + n, out);
+        w->dims[k]->ensure_host();
+        std::copy(w->dims[k]->host.begin(), w->dims[k]->host.begin() + n, out);
     });
 }
 int ibh_weighted_get_wM(const ibh_weighted *w, double *out) {
@@ -394,6 +461,9 @@ int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen) {
         IBH_CHECK(w && buf && buflen > 0, "bad argument");
         snprintf(buf, (size_t)buflen, "%s", w->last_kernel == 1 ? "rowblock" : w->last_kernel == 2 ? "shortrow" : "none");
     });
+}
+int ibh_release_cached_memory(void) {
+    return guarded([&] { release_workspace(); release_cached_memory(); });
 }
 int ibh_set_tuning(const char *key, int value) {
     return guarded([&] { IBH_CHECK(key != nullptr, "null key"); set_tuning(key, value); });

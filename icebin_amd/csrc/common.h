@@ -58,28 +58,37 @@ int guarded(F &&f) noexcept {
 }
 
 // ---- device memory -------------------------------------------------------------------------
+// Caching allocator (capi.hip): freed blocks are kept per device and size class and handed out again,
+// so that rebuilding the same matrices every coupling step does no hipMalloc/hipFree (both
+// synchronise the device).  ibh_release_cached_memory() returns everything to the driver.
+void *dev_alloc(size_t bytes, size_t *granted);
+void dev_free(void *p, size_t granted);
+void release_cached_memory();
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    size_t granted = 0;     // bytes actually reserved (size class)
     DevBuf() = default;
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), granted(o.granted) { o.p = nullptr; o.n = 0; o.granted = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; granted = o.granted; o.p = nullptr; o.n = 0; o.granted = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
     void alloc(size_t count) {
+        if (p && count * sizeof(T) <= granted) { n = count; return; }
         release();
         n = count;
-        IBH_HIP(hipMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T)));
+        p = static_cast<T *>(dev_alloc((count ? count : 1) * sizeof(T), &granted));
     }
     void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
+        if (p) dev_free(p, granted);
+        p = nullptr; n = 0; granted = 0;
     }
     void upload(const T *host, size_t count, hipStream_t s = nullptr) {
         if (count > n || !p) alloc(count);
@@ -104,10 +113,27 @@ inline int bits_for(uint64_t n) {   // bits needed to represent values in [0, n)
 // ---- handle layouts (opaque to the C-ABI user) ----------------------------------------------
 struct ibh_sparse_set {
     int64_t sparse_extent = -1;
-    std::vector<int64_t> to_sparse;                       // dense -> sparse, first-seen order
-    std::unordered_map<int64_t, int32_t> to_dense_map;    // host lookup
-    bool identity = false;                                // to_sparse[i] == i for all i (no map kept)
-    int32_t dense_extent() const { return (int32_t)to_sparse.size(); }
+    int32_t n = 0;                       // dense extent
+    bool identity = false;               // to_sparse[i] == i for i < n; neither copy is materialised until asked for
+    // dense -> sparse table in first-seen order.  A matrix build appends on the DEVICE; the host copy
+    // is completed lazily (ensure_host) so that a 10^7-entry dims table never crosses PCIe unless a
+    // caller actually reads it.
+    mutable std::vector<int64_t> host;   // entries [0, host_n) valid
+    mutable int32_t host_n = 0;
+    ibh::DevBuf<int64_t> dev;            // entries [0, dev_n) valid
+    int32_t dev_n = 0;
+    int32_t dense_extent() const { return n; }
+    void ensure_host() const {
+        if (host_n >= n) return;
+        host.resize((size_t)n);
+        if (identity) {
+            for (int32_t i = host_n; i < n; ++i) host[(size_t)i] = i;
+        } else {
+            if (dev_n < n) ibh::fail(IBH_EINVAL, "internal: sparse set has no valid copy of entries [%d,%d)", host_n, n);
+            IBH_HIP(hipMemcpy(host.data() + host_n, dev.p + host_n, sizeof(int64_t) * (size_t)(n - host_n), hipMemcpyDeviceToHost));
+        }
+        host_n = n;
+    }
 };
 
 struct ibh_regridder {

@@ -47,36 +47,77 @@ def all_gather_fields(y_local, nf_total, group=None, out=None):
 class FieldShardedApply:
     """Weighted::apply of nf_total fields, sharded by field over the ranks of `group`.
 
-    apply(x_local) runs the local SpMM on the calling stream and the all-gather on a second
-    stream, so the gather of one call overlaps the SpMM of the next; results are double-buffered
-    and wait() (or the returned event) orders consumers."""
+    apply(x_local) enqueues the local SpMM on the calling stream.  Results are reassembled with
+    one all-gather per `steps_per_gather` applies (fewer, larger collectives: a [nf_local, nrow]
+    AvI result is only tens of KB, far below the size at which an RCCL call is bandwidth- rather
+    than latency-bound), issued on a second stream so it overlaps the following SpMMs.  Buffers
+    are double-buffered by group; result(g, slot) is valid after wait()."""
 
-    def __init__(self, weighted, nf_total, group=None, device=None):
+    def __init__(self, weighted, nf_total, group=None, device=None, steps_per_gather=1):
+        import ctypes as C
+        from . import _capi
         self.w, self.nf_total, self.group = weighted, nf_total, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        assert nf_total % self.world == 0 or steps_per_gather == 1, "grouped gathers need equal shards"
         self.f0, self.f1 = field_shard(nf_total, self.world, self.rank)
-        self.device = device
+        self.device, self.G = device, int(steps_per_gather)
         self.comm = torch.cuda.Stream(device=device)
-        nl = self.f1 - self.f0
-        self._y = [torch.empty((nl, weighted.nrow_d), dtype=torch.float64, device=device) for _ in range(2)]
-        self._out = [torch.empty((nf_total, weighted.nrow_d), dtype=torch.float64, device=device) for _ in range(2)]
+        nl, nrow = self.f1 - self.f0, weighted.nrow_d
+        self.nl, self.nrow = nl, nrow
+        self._y = [torch.empty((self.G, nl, nrow), dtype=torch.float64, device=device) for _ in range(2)]
+        if self.G == 1:
+            self._out = [torch.empty((nf_total, nrow), dtype=torch.float64, device=device) for _ in range(2)]
+        else:
+            self._out = [torch.empty((self.world, self.G, nl, nrow), dtype=torch.float64, device=device) for _ in range(2)]
         self._done = [torch.cuda.Event() for _ in range(2)]
         self._free = [torch.cuda.Event() for _ in range(2)]
+        self._used = [False, False]
         self._i = 0
+        # raw C-ABI call, arguments prepared once: the per-apply host cost must stay below the ~10 us kernel
+        self._fn = _capi.lib().ibh_weighted_apply_device
+        self._check = _capi.check
+        self._h = weighted._h
+        self._yp = [[C.c_void_p(self._y[g][s].data_ptr()) for s in range(self.G)] for g in range(2)]
+        self._C = C
 
     def apply(self, x_local, fill=float("nan")):
-        s = self._i & 1
+        """x_local: torch.float64 CUDA tensor [nf_local, ncol_d], contiguous.  Returns (group, slot)."""
+        g, slot = (self._i // self.G) & 1, self._i % self.G
         cur = torch.cuda.current_stream(self.device)
-        if self._i >= 2:
-            cur.wait_event(self._free[s])        # y[s] is still being gathered from two calls ago
-        self.w.apply_device(x_local, out=self._y[s], fill=fill, force_conservation=False)
-        self._done[s].record(cur)
-        with torch.cuda.stream(self.comm):
-            self.comm.wait_event(self._done[s])
-            all_gather_fields(self._y[s], self.nf_total, self.group, out=self._out[s])
-            self._free[s].record(self.comm)
+        if slot == 0 and self._used[g]:
+            cur.wait_event(self._free[g])           # this group's buffers are still being gathered
+        rc = self._fn(self._h, self._C.c_void_p(x_local.data_ptr()), self.nl, x_local.stride(0), self._yp[g][slot],
+                      self.nrow, fill, 0, self._C.c_void_p(cur.cuda_stream))
+        if rc != 0:
+            self._check(rc)
         self._i += 1
-        return self._out[s], self._free[s]
+        if slot == self.G - 1:
+            self._gather(g, cur)
+        return g, slot
+
+    def _gather(self, g, cur):
+        self._done[g].record(cur)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self._done[g])
+            if self.G == 1:
+                all_gather_fields(self._y[g][0], self.nf_total, self.group, out=self._out[g])
+            else:
+                dist.all_gather_into_tensor(self._out[g], self._y[g], group=self.group)
+            self._free[g].record(self.comm)
+        self._used[g] = True
+
+    def flush(self):
+        """Gather a partially filled group (end of a run)."""
+        if self._i % self.G != 0:
+            g = (self._i // self.G) & 1
+            self._gather(g, torch.cuda.current_stream(self.device))
+            self._i += self.G - self._i % self.G
 
     def wait(self):
         torch.cuda.current_stream(self.device).wait_stream(self.comm)
+
+    def result(self, g, slot):
+        """[world, nf_local, nrow] view (rank-major == field-major) of the gathered fields of one apply."""
+        if self.G == 1:
+            return self._out[g].view(self.world, self.nl, self.nrow)
+        return self._out[g][:, slot]

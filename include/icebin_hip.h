@@ -178,6 +178,9 @@ int ibh_weighted_device_view_get(const ibh_weighted *w, ibh_weighted_device_view
 int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow" */
 int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
 int ibh_set_tuning(const char *key, int value);
+/* Return the per-thread workspace and all cached device blocks to the driver (the library keeps
+ * freed device memory for reuse: a coupler rebuilds the same matrices every step). */
+int ibh_release_cached_memory(void);
 
 #ifdef __cplusplus
 }

@@ -4,13 +4,14 @@
 #include <cstdio>
 #include <vector>
 template <int FPW, int UNROLL, bool XCD>
-__global__ __launch_bounds__(256) void piece_sum(const double* __restrict__ X, long ldx, int nrow, int nfc, int len, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void piece_sum(const double* __restrict__ X, long ldx, int nrow, int nfc, int len_, double* __restrict__ out, const int* __restrict__ rowptr) {
     int b = blockIdx.x, nb = nrow * nfc;
     if (XCD) { int q = nb >> 3, rem = nb & 7, x = b & 7, slot = b >> 3; b = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + slot; }
     const int r = b / nfc, fc = b - r * nfc;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int f0 = fc * 4 * FPW + wave * FPW;
-    const long c0 = (long)r * len;
+    const int len = rowptr ? rowptr[r + 1] - rowptr[r] : len_;
+    const long c0 = rowptr ? (long)rowptr[r] * 76611 / 82870 : (long)r * len_;
     double acc[FPW];
     for (int j = 0; j < FPW; ++j) acc[j] = 0;
     for (int k0 = lane; k0 - lane < len; k0 += 64 * UNROLL) {
@@ -38,7 +39,13 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
         double us = ms * 1e3 / steps; printf("%-44s %7.2f us  %7.0f GB/s\n", name, us, (double)nrow * len * nf * 8 / us / 1e3);
     };
-#define RUN(FPW, U, XCD) time([&](int i) { hipLaunchKernelGGL((piece_sum<FPW, U, XCD>), dim3(nrow * (nf / (4 * FPW))), dim3(256), 0, 0, x + (long)(i % nbuf) * total, ldx, nrow, nf / (4 * FPW), len, out); }, "pieces FPW=" #FPW " U=" #U " xcd=" #XCD)
-    RUN(4, 4, true); RUN(4, 4, false); RUN(2, 8, true); RUN(2, 8, false); RUN(2, 4, true); RUN(1, 8, true); RUN(1, 8, false); RUN(4, 2, true); RUN(1, 4, true); RUN(1, 10, true); RUN(2, 10, true);
+#define RUN(FPW, U, XCD) time([&](int i) { hipLaunchKernelGGL((piece_sum<FPW, U, XCD>), dim3(nrow * (nf / (4 * FPW))), dim3(256), 0, 0, x + (long)(i % nbuf) * total, ldx, nrow, nf / (4 * FPW), len, out, RP); }, RP ? "REAL lens FPW=" #FPW " U=" #U " xcd=" #XCD : "uniform   FPW=" #FPW " U=" #U " xcd=" #XCD)
+    std::vector<int> rp(nrow + 1, 0);
+    { FILE* f = fopen("scratch/rowlens_g5.txt", "r"); for (int i = 0; i < nrow; ++i) { int v; if (fscanf(f, "%d", &v) != 1) return 1; rp[i + 1] = rp[i] + v; } fclose(f); }
+    int* d_rp; hipMalloc(&d_rp, sizeof(int) * (nrow + 1)); hipMemcpy(d_rp, rp.data(), sizeof(int) * (nrow + 1), hipMemcpyHostToDevice);
+    for (int pass = 0; pass < 2; ++pass) {
+    const int* RP = pass ? d_rp : nullptr;
+    RUN(4, 4, true); RUN(4, 4, false); RUN(2, 8, true); RUN(2, 8, false); RUN(2, 4, true); RUN(1, 8, true); RUN(1, 8, false); RUN(4, 2, true); RUN(1, 4, true); RUN(1, 10, true); RUN(2, 10, true); RUN(1, 14, true); RUN(2, 14, true);
+    }
     return 0;
 }

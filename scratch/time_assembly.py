@@ -1,0 +1,19 @@
+"""Time matrix assembly on the GPU for several configs/matrices (dev tool)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import icebin_amd
+from icebin_amd import synthetic as syn
+for cfg in sys.argv[1].split(","):
+    g = syn.make_grids(cfg); em = syn.dome_elevmask(g)
+    mm = icebin_amd.from_synthetic(g)
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    nX, nI = len(g["ex_area"]), g["nI"]
+    for name in sys.argv[2].split(","):
+        w = rm.matrix(name); torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); w = rm.matrix(name); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        t = min(ts)
+        B = 16 * nX + 8 * nI + 12 * w.nnz + 4 * (w.nrow_d + 1) + 8 * (w.nrow_d + w.ncol_d)
+        print("%-5s %-4s nX=%9d nnz=%9d  %9.3f ms   B_asm=%8.1f MB  %7.1f GB/s" % (cfg, name, nX, w.nnz, t * 1e3, B / 1e6, B / t / 1e9), flush=True)

@@ -317,3 +317,39 @@ def test_config5_antarctica_1km_assembly_and_apply_properties():
     assert IvA.nnz == AvI.nnz and IvA.last_kernel() == "none"
     back = IvA.apply(AvI.apply(np.ones((1, AvI.ncol_d))))
     assert IvA.last_kernel() == "shortrow" and np.all(np.abs(back - 1.0) < 1e-11)
+
+
+def test_field_sharded_apply_rccl_world1():
+    # the bench's N>1 path (field shard + grouped RCCL all-gather on a second stream), rehearsed at world_size 1
+    import socket
+    import torch
+    import torch.distributed as dist
+    from icebin_amd.distributed import FieldShardedApply
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        g, em, mm, rg = setup("g20")
+        w = mm.regrid_matrices("greenland", em, scale=True, correctA=False).matrix("AvI")
+        o = rg.matrix_d("AvI", em)
+        xs = [syn.fields(8, w.ncol_d, seed=100 + i) for i in range(7)]
+        dxs = [torch.from_numpy(x).cuda() for x in xs]
+        for G in (1, 4):
+            sh = FieldShardedApply(w, 8, None, torch.device("cuda", 0), steps_per_gather=G)
+            handles = []
+            for i, dx in enumerate(dxs):
+                handles.append(sh.apply(dx))
+                if G == 4 and i == 3:      # first full group gathered: check it before its buffers are reused
+                    sh.wait(); torch.cuda.synchronize()
+                    for j in range(4):
+                        y = sh.result(*handles[j]).reshape(8, -1).cpu().numpy()
+                        assert rel_linf(y, o.apply(xs[j])) <= FIELD_RTOL
+            sh.flush(); sh.wait(); torch.cuda.synchronize()
+            last = range(4, 7) if G == 4 else range(5, 7)     # results still held in the double buffers
+            for j in last:
+                y = sh.result(*handles[j]).reshape(8, -1).cpu().numpy()
+                assert rel_linf(y, o.apply(xs[j])) <= FIELD_RTOL, (G, j)
+    finally:
+        dist.destroy_process_group()
