@@ -323,7 +323,12 @@ static void launch_rowblock(const ibh_weighted *w, const double *dA, int nvar, l
     }
     IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
     IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
-    const int unroll = get_tuning("rowblock_unroll", 8);
+    // loads in flight per lane and field: enough 64-entry slots to cover a typical row in one batch
+    int unroll = get_tuning("rowblock_unroll", 0);
+    if (unroll == 0) {
+        const double mean = w->nrow ? (double)w->nnz / (double)w->nrow / (64.0 * WK) : 1.0;
+        unroll = mean > 4.0 ? 8 : mean > 2.0 ? 4 : mean > 1.0 ? 2 : 1;
+    }
 #define IBH_RB(U)                                                                                        \
     hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U>), dim3((unsigned)nb), dim3(RB_THREADS), 0, stream, \
                        w->rowptr.p, w->colind.p, w->val.p, dA, lda, w->ncol, dB, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill)
@@ -345,7 +350,7 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
     int kernel = w->kernel_override;
     if (kernel == 0) {
         const double mean = w->nrow ? (double)w->nnz / (double)w->nrow : 0.0;
-        kernel = mean >= (double)get_tuning("rowblock_min_mean_nnz", 12) ? 1 : 2;
+        kernel = mean >= (double)get_tuning("rowblock_min_mean_nnz", 6) ? 1 : 2;
     }
     w->last_kernel = kernel;
     if (kernel == 1) {
@@ -373,7 +378,7 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
         else if (fpw == 8 && wk == 2) launch_rowblock<8, 2>(w, dA, nvar, lda, dB, ldb, fill, stream);
         else launch_rowblock<1, 4>(w, dA, nvar, lda, dB, ldb, fill, stream);
     } else {
-        int fper = get_tuning("shortrow_fper", 16);
+        int fper = get_tuning("shortrow_fper", 8);
         if (fper < 1) fper = 1;
         dim3 grid((unsigned)ceil_div(w->nrow, SR_THREADS), (unsigned)ceil_div(nvar, fper));
         hipLaunchKernelGGL(spmm_shortrow_kernel, grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p,
