@@ -102,7 +102,7 @@ def main():
 
     def step(i):
         if use_dist:        # field-sharded SpMM + (grouped) all-gather, icebin_amd/distributed.py
-            sharded.apply(X[i % nbuf])
+            sharded.apply_ptr(xp[i % nbuf], ncol)
             return
         rc = fn(W._h, xp[i % nbuf], nf, ncol, yp[i & 1], nrow, nan, 0, cs)
         if rc != 0:

@@ -86,9 +86,7 @@ __device__ __forceinline__ bool block_to_task(int b, int nrow, int nfc, int mode
     return true;
 }
 
-constexpr int RB_THREADS = 256;
 constexpr int RB_SEG = 1024;    // nnz staged per pass: 12 KB of LDS
-constexpr int RB_STAGE = RB_SEG / RB_THREADS;
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -100,15 +98,18 @@ __device__ __forceinline__ double xload(__amdgpu_buffer_rsrc_t rs, int byte_off)
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0));
 }
 
-// FPW = fields per wave, WK = waves that split the nnz range of the row.
-// The 4 waves form WF = 4/WK groups over fields; a block covers FB = FPW*WF fields.
-template <int FPW, int WK, int UNROLL>
-__global__ __launch_bounds__(RB_THREADS) void spmm_rowblock_kernel(
+// FPW = fields per wave, WK = waves that split the nnz range of the row, NW = waves per workgroup.
+// The NW waves form WF = NW/WK groups over fields; a block covers FB = FPW*WF fields and stages
+// the row segment once for all of them.
+template <int FPW, int WK, int UNROLL, int NW>
+__global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
     const double *__restrict__ X, long ldx, int ncol, double *__restrict__ Y, long ldy, int nrow, int nf, int nfc,
     int xcd_mode, const double *__restrict__ wM, double fill)
 {
-    constexpr int WF = 4 / WK;
+    constexpr int RB_THREADS = NW * 64;
+    constexpr int RB_STAGE = RB_SEG / RB_THREADS;
+    constexpr int WF = NW / WK;
     constexpr int FB = FPW * WF;
     constexpr int STEP = WK * 64;
     constexpr int BATCH = UNROLL * STEP;
@@ -308,11 +309,11 @@ void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int6
 }
 
 // ---- dispatch ------------------------------------------------------------------------------
-template <int FPW, int WK>
+template <int FPW, int WK, int NW>
 static void launch_rowblock(const ibh_weighted *w, const double *dA, int nvar, long lda, double *dB, long ldb,
                             double fill, hipStream_t stream)
 {
-    constexpr int FB = FPW * (4 / WK);
+    constexpr int FB = FPW * (NW / WK);
     const int nfc = ceil_div(nvar, FB);
     int xcd_mode = (nfc % 8 == 0 || nfc == 1 || nfc == 2 || nfc == 4) ? 1 : 0;
     xcd_mode = get_tuning("rowblock_xcd_mode", xcd_mode);
@@ -330,7 +331,7 @@ static void launch_rowblock(const ibh_weighted *w, const double *dA, int nvar, l
         unroll = mean > 4.0 ? 8 : mean > 2.0 ? 4 : mean > 1.0 ? 2 : 1;
     }
 #define IBH_RB(U)                                                                                        \
-    hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U>), dim3((unsigned)nb), dim3(RB_THREADS), 0, stream, \
+    hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U, NW>), dim3((unsigned)nb), dim3(NW * 64), 0, stream, \
                        w->rowptr.p, w->colind.p, w->val.p, dA, lda, w->ncol, dB, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill)
     if (unroll == 1) IBH_RB(1);
     else if (unroll == 2) IBH_RB(2);
@@ -365,18 +366,23 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
             else if (nvar >= 2) { fpw = 1; wk = 2; }
             else { fpw = 1; wk = 4; }
         }
-        if (fpw == 4 && wk == 1) launch_rowblock<4, 1>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else if (fpw == 8 && wk == 1) launch_rowblock<8, 1>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else if (fpw == 2 && wk == 1) launch_rowblock<2, 1>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else if (fpw == 1 && wk == 1) launch_rowblock<1, 1>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else if (fpw == 4 && wk == 2) launch_rowblock<4, 2>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else if (fpw == 2 && wk == 2) launch_rowblock<2, 2>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else if (fpw == 1 && wk == 2) launch_rowblock<1, 2>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else if (fpw == 2 && wk == 4) launch_rowblock<2, 4>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else if (fpw == 4 && wk == 4) launch_rowblock<4, 4>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else if (fpw == 8 && wk == 4) launch_rowblock<8, 4>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else if (fpw == 8 && wk == 2) launch_rowblock<8, 2>(w, dA, nvar, lda, dB, ldb, fill, stream);
-        else launch_rowblock<1, 4>(w, dA, nvar, lda, dB, ldb, fill, stream);
+        const int nw = get_tuning("rowblock_waves", 4);
+#define IBH_L(F, K, N) launch_rowblock<F, K, N>(w, dA, nvar, lda, dB, ldb, fill, stream)
+        if (nw == 8 && wk == 1) {
+            if (fpw == 1) IBH_L(1, 1, 8); else if (fpw == 2) IBH_L(2, 1, 8); else IBH_L(4, 1, 8);
+        } else if (nw == 16 && wk == 1) {
+            if (fpw == 1) IBH_L(1, 1, 16); else if (fpw == 2) IBH_L(2, 1, 16); else IBH_L(4, 1, 16);
+        } else if (fpw == 4 && wk == 1) IBH_L(4, 1, 4);
+        else if (fpw == 8 && wk == 1) IBH_L(8, 1, 4);
+        else if (fpw == 2 && wk == 1) IBH_L(2, 1, 4);
+        else if (fpw == 1 && wk == 1) IBH_L(1, 1, 4);
+        else if (fpw == 4 && wk == 2) IBH_L(4, 2, 4);
+        else if (fpw == 2 && wk == 2) IBH_L(2, 2, 4);
+        else if (fpw == 1 && wk == 2) IBH_L(1, 2, 4);
+        else if (fpw == 2 && wk == 4) IBH_L(2, 4, 4);
+        else if (fpw == 4 && wk == 4) IBH_L(4, 4, 4);
+        else IBH_L(1, 4, 4);
+#undef IBH_L
     } else {
         int fper = get_tuning("shortrow_fper", 8);
         if (fper < 1) fper = 1;

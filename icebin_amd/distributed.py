@@ -73,6 +73,8 @@ class FieldShardedApply:
         self._free = [torch.cuda.Event() for _ in range(2)]
         self._used = [False, False]
         self._i = 0
+        self._cur = None
+        self._cur_ptr = None
         # raw C-ABI call, arguments prepared once: the per-apply host cost must stay below the ~10 us kernel
         self._fn = _capi.lib().ibh_weighted_apply_device
         self._check = _capi.check
@@ -82,15 +84,23 @@ class FieldShardedApply:
 
     def apply(self, x_local, fill=float("nan")):
         """x_local: torch.float64 CUDA tensor [nf_local, ncol_d], contiguous.  Returns (group, slot)."""
-        g, slot = (self._i // self.G) & 1, self._i % self.G
-        cur = torch.cuda.current_stream(self.device)
-        if slot == 0 and self._used[g]:
-            cur.wait_event(self._free[g])           # this group's buffers are still being gathered
-        rc = self._fn(self._h, self._C.c_void_p(x_local.data_ptr()), self.nl, x_local.stride(0), self._yp[g][slot],
-                      self.nrow, fill, 0, self._C.c_void_p(cur.cuda_stream))
+        return self.apply_ptr(x_local.data_ptr(), x_local.stride(0), fill)
+
+    def apply_ptr(self, x_ptr, ldx, fill=float("nan")):
+        """Same with a raw device pointer (int) and leading dimension: the lean path for callers that
+        keep their field batches resident and call this every few microseconds."""
+        i = self._i
+        g, slot = (i // self.G) & 1, i % self.G
+        cur = self._cur
+        if cur is None or slot == 0:
+            cur = self._cur = torch.cuda.current_stream(self.device)
+            self._cur_ptr = self._C.c_void_p(cur.cuda_stream)
+            if self._used[g]:
+                cur.wait_event(self._free[g])       # this group's buffers are still being gathered
+        rc = self._fn(self._h, x_ptr, self.nl, ldx, self._yp[g][slot], self.nrow, fill, 0, self._cur_ptr)
         if rc != 0:
             self._check(rc)
-        self._i += 1
+        self._i = i + 1
         if slot == self.G - 1:
             self._gather(g, cur)
         return g, slot
@@ -112,6 +122,7 @@ class FieldShardedApply:
             g = (self._i // self.G) & 1
             self._gather(g, torch.cuda.current_stream(self.device))
             self._i += self.G - self._i % self.G
+        self._cur = None
 
     def wait(self):
         torch.cuda.current_stream(self.device).wait_stream(self.comm)
