@@ -229,6 +229,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 
 constexpr int SR_THREADS = 256;
 
+template <bool NT, int G>
 __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
     const double *__restrict__ X, long ldx, double *__restrict__ Y, long ldy, int nrow, int nf, int fper,
@@ -247,7 +248,10 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     if (n > 1) { c1 = colind[beg + 1]; v1 = vals[beg + 1]; }
     if (n > 2) { c2 = colind[beg + 2]; v2 = vals[beg + 2]; }
     if (n > 3) { c3 = colind[beg + 3]; v3 = vals[beg + 3]; }
-    constexpr int G = 8;    // fields in flight per thread: G gathers issued before the first store
+    // G fields in flight per thread: all G gathers are issued before the first store.  vmcnt counts
+    // loads and stores together in issue order, so a gather issued after a store would wait for that
+    // store's (long) write acknowledgement; with G == fields per thread there is one load phase and
+    // one store phase per thread.
     for (int f0 = fbeg; f0 < fend; f0 += G) {
         double acc[G];
 #pragma unroll
@@ -265,7 +269,10 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
         }
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            if (f0 + g < fend) __builtin_nontemporal_store(dead ? fill : acc[g], &Y[(long)(f0 + g) * ldy + r]);
+            if (f0 + g < fend) {
+                if (NT) __builtin_nontemporal_store(dead ? fill : acc[g], &Y[(long)(f0 + g) * ldy + r]);
+                else Y[(long)(f0 + g) * ldy + r] = dead ? fill : acc[g];
+            }
     }
 }
 
@@ -384,11 +391,21 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
         else IBH_L(1, 4, 4);
 #undef IBH_L
     } else {
-        int fper = get_tuning("shortrow_fper", 8);
+        // fields per thread: small chunks = many short threads, which is what keeps enough stores in
+        // flight (measured: 4 for ~1 entry per row, 8 for 2-3)
+        int fper = get_tuning("shortrow_fper", (double)w->nnz <= 1.5 * (double)w->nrow ? 4 : 8);
         if (fper < 1) fper = 1;
         dim3 grid((unsigned)ceil_div(w->nrow, SR_THREADS), (unsigned)ceil_div(nvar, fper));
-        hipLaunchKernelGGL(spmm_shortrow_kernel, grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p,
-                           w->val.p, dA, (long)lda, dB, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill);
+        const int g = get_tuning("shortrow_group", fper >= 32 ? 32 : fper >= 16 ? 16 : fper >= 8 ? 8 : 4);
+#define IBH_SR(NT, GG)                                                                                          \
+    hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
+                       w->val.p, dA, (long)lda, dB, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill)
+        const bool nt = get_tuning("shortrow_nt", 1) != 0;
+        if (g >= 32) { if (nt) IBH_SR(true, 32); else IBH_SR(false, 32); }
+        else if (g >= 16) { if (nt) IBH_SR(true, 16); else IBH_SR(false, 16); }
+        else if (g >= 8) { if (nt) IBH_SR(true, 8); else IBH_SR(false, 8); }
+        else { if (nt) IBH_SR(true, 4); else IBH_SR(false, 4); }
+#undef IBH_SR
         IBH_HIP(hipGetLastError());
     }
     if (!w->conservative && force_conservation) {
