@@ -73,6 +73,9 @@ _SIGS = {
                                          C.c_double, C.c_int]),
     "ibh_weighted_apply_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
                                            C.c_double, C.c_int, C.c_void_p]),
+    "ibh_weighted_apply_transformed_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
+                                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_double,
+                                                       C.c_void_p]),
     "ibh_weighted_apply_weight_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     "ibh_weighted_device_view_get": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
     "ibh_weighted_set_kernel": (C.c_int, [C.c_void_p, C.c_char_p]),

@@ -424,6 +424,15 @@ int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nv
         IBH_HIP(hipStreamSynchronize(nullptr));
     });
 }
+int ibh_weighted_apply_transformed_device(const ibh_weighted *w, const double *dA, int32_t nvar_in, int64_t lda,
+                                          const double *T, const double *b, int32_t nvar_out, double *dB,
+                                          int64_t ldb, double fill, void *stream) {
+    return guarded([&] {
+        check_weighted_device(w);
+        IBH_CHECK(nvar_in >= 0 && nvar_out >= 0 && (nvar_out == 0 || (dA && dB && T && b)), "bad arguments");
+        spmm_transformed_launch(w, dA, nvar_in, lda, T, b, nvar_out, dB, ldb, fill, static_cast<hipStream_t>(stream));
+    });
+}
 int ibh_weighted_apply_weight_host(const ibh_weighted *w, int dim, const double *A_b, int32_t nvar, int64_t lda,
                                    double *out) {
     return guarded([&] {

@@ -169,6 +169,9 @@ struct ibh_weighted {
     // SpMM dispatch
     int kernel_override = 0;            // 0 auto, 1 rowblock, 2 shortrow
     mutable int last_kernel = 0;
+    // apply_transformed: scratch fields + small transform, and M*1 (row sums) for the offset term
+    mutable ibh::DevBuf<double> scratch, tbuf, rowsum1;
+    mutable bool have_rowsum1 = false;
     int32_t max_row_nnz = 0;
     ~ibh_weighted() {
         for (int k = 0; k < 2; ++k)
@@ -180,6 +183,8 @@ namespace ibh {
 // spmm.hip
 void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda, double *dB, int64_t ldb,
                  double fill, int force_conservation, hipStream_t stream);
+void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_in, int64_t lda, const double *T,
+                              const double *b, int nvar_out, double *dB, int64_t ldb, double fill, hipStream_t stream);
 void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int64_t lda, double *dout,
                        hipStream_t stream);
 int get_tuning(const char *key, int dflt);

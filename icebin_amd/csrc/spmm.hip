@@ -421,4 +421,72 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
     }
 }
 
+// ---- coupler-shaped product M * (V*T + b) ---------------------------------------------------
+// out[k, j] = sum_l T[l,k] * in[l, j] + b[k] * (scale ? scale[j] : 1): the variable transform, applied
+// on whichever side of M is small.  T entries that are exactly 0 are structural (skipped: a NaN in an
+// unused input variable must not reach the outputs).  One thread per column j, all k in registers.
+constexpr int TR_MAX = 64;      // max nvar_in / nvar_out handled in one launch
+__global__ void transform_kernel(const double *__restrict__ in, long ldin, int nin, const double *__restrict__ Tm,
+                                 const double *__restrict__ b, const double *__restrict__ scale,
+                                 const double *__restrict__ wM, double fill, double *__restrict__ out, long ldout,
+                                 int nout, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (j >= n) return;
+    double acc = 0.0;
+    for (int l = 0; l < nin; ++l) {
+        const double t = Tm[l * nout + k];
+        if (t != 0.0) acc = fma(t, in[(long)l * ldin + j], acc);
+    }
+    acc += scale ? b[k] * scale[j] : b[k];
+    if (wM && wM[j] == 0.0) acc = fill;
+    out[(long)k * ldout + j] = acc;
+}
+__global__ void fill_ones_kernel(double *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 1.0;
+}
+
+void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_in, int64_t lda, const double *T,
+                             const double *b, int nvar_out, double *dB, int64_t ldb, double fill, hipStream_t stream)
+{
+    if (nvar_out <= 0 || w->nrow == 0) return;
+    IBH_CHECK(nvar_in > 0 && T && b, "apply_transformed: empty transform");
+    IBH_CHECK(lda >= w->ncol && ldb >= w->nrow, "apply_transformed: leading dimensions too small");
+    // device copy of T (row-major nvar_in x nvar_out) followed by b
+    std::vector<double> tb((size_t)nvar_in * nvar_out + nvar_out);
+    std::copy(T, T + (size_t)nvar_in * nvar_out, tb.begin());
+    std::copy(b, b + nvar_out, tb.begin() + (size_t)nvar_in * nvar_out);
+    w->tbuf.alloc(tb.size());
+    IBH_HIP(hipMemcpyAsync(w->tbuf.p, tb.data(), sizeof(double) * tb.size(), hipMemcpyHostToDevice, stream));
+    IBH_HIP(hipStreamSynchronize(stream));      // tb is a stack-lifetime staging buffer
+    const double *dT = w->tbuf.p, *db = w->tbuf.p + (size_t)nvar_in * nvar_out;
+    if (w->ncol <= w->nrow) {
+        // inputs are the small side: X' = V*T + b, then B = M * X'
+        w->scratch.alloc((size_t)nvar_out * (size_t)w->ncol);
+        dim3 grid((unsigned)ceil_div(w->ncol, 256), (unsigned)nvar_out);
+        hipLaunchKernelGGL(transform_kernel, grid, dim3(256), 0, stream, dA, (long)lda, nvar_in, dT, db,
+                           (const double *)nullptr, (const double *)nullptr, 0.0, w->scratch.p, (long)w->ncol, nvar_out, w->ncol);
+        IBH_HIP(hipGetLastError());
+        spmm_launch(w, w->scratch.p, nvar_out, w->ncol, dB, ldb, fill, 0, stream);
+    } else {
+        // outputs are the small side: Z = M * V, then B = T^T Z + b * (M * 1), rows with wM == 0 -> fill
+        if (!w->have_rowsum1) {
+            DevBuf<double> ones((size_t)w->ncol);
+            hipLaunchKernelGGL(fill_ones_kernel, dim3(ceil_div(w->ncol, 256)), dim3(256), 0, stream, ones.p, w->ncol);
+            w->rowsum1.alloc((size_t)w->nrow);
+            spmm_launch(w, ones.p, 1, w->ncol, w->rowsum1.p, w->nrow, 0.0, 0, stream);
+            IBH_HIP(hipStreamSynchronize(stream));
+            w->have_rowsum1 = true;
+        }
+        w->scratch.alloc((size_t)nvar_in * (size_t)w->nrow);
+        spmm_launch(w, dA, nvar_in, lda, w->scratch.p, w->nrow, 0.0, 0, stream);
+        dim3 grid((unsigned)ceil_div(w->nrow, 256), (unsigned)nvar_out);
+        hipLaunchKernelGGL(transform_kernel, grid, dim3(256), 0, stream, w->scratch.p, (long)w->nrow, nvar_in, dT, db,
+                           (const double *)w->rowsum1.p, (const double *)w->wM.p, fill, dB, (long)ldb, nvar_out, w->nrow);
+        IBH_HIP(hipGetLastError());
+    }
+}
+
 }  // namespace ibh

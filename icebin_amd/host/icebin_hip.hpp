@@ -141,6 +141,14 @@ public:
         check(ibh_weighted_apply_host(h_, A_b.data, (int32_t)nvar, ncol, B.data(), sh[0], fill, force_conservation ? 1 : 0));
         return B;
     }
+    /** The coupler's fused product B = M * (A*T + b) (IceCoupler.cpp:203-252, :445) on HBM-resident
+        fields: T is the (sparse) variable transform as a dense row-major nvar_in x nvar_out host array
+        (exact zeros are structural), b the offsets. */
+    void apply_transformed_device(const double *dA_b, int nvar_in, long lda, std::vector<double> const &T,
+                                  std::vector<double> const &b, double *dB_b, long ldb, double fill, void *stream) const {
+        check(ibh_weighted_apply_transformed_device(h_, dA_b, nvar_in, lda, T.data(), b.data(), (int32_t)b.size(),
+                                                    dB_b, ldb, fill, stream));
+    }
     /** Device-resident variant: dA_b (nvar x lda) and dB_b (nvar x ldb) are HBM pointers; enqueues on stream. */
     void apply_device(const double *dA_b, int nvar, long lda, double *dB_b, long ldb, double fill,
                       bool force_conservation, void *stream) const {

@@ -195,6 +195,32 @@ class linear_Weighted:
                                              float(fill), int(force_conservation), C.c_void_p(s)))
         return out
 
+    def apply_transformed_device(self, dV, T, b, out=None, fill=float("nan"), stream=None):
+        """The coupler's fused product  M * (V*T + b)  on HBM-resident fields (IceCoupler.cpp:203-252,
+        :445): dV torch.float64 CUDA [nvar_in, ncol_d]; T [nvar_in, nvar_out] (the sparse variable
+        transform as a dense array, exact zeros are structural), b [nvar_out]; returns [nvar_out, nrow_d]."""
+        import torch
+        T = np.ascontiguousarray(T, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        assert dV.is_cuda and dV.dtype == torch.float64 and dV.dim() == 2 and dV.stride(1) == 1
+        assert dV.shape == (T.shape[0], self.ncol_d) and b.shape == (T.shape[1],)
+        nout = T.shape[1]
+        if out is None:
+            out = torch.empty((nout, self.nrow_d), dtype=torch.float64, device=dV.device)
+        s = torch.cuda.current_stream(dV.device).cuda_stream if stream is None else stream
+        check(lib().ibh_weighted_apply_transformed_device(
+            self._h, C.c_void_p(dV.data_ptr()), dV.shape[0], max(dV.stride(0), self.ncol_d), ptr(T), ptr(b), nout,
+            C.c_void_p(out.data_ptr()), max(out.stride(0), self.nrow_d), float(fill), C.c_void_p(s)))
+        return out
+
+    def apply_transformed(self, V_b, T, b, fill=np.nan):
+        """Host-array form of apply_transformed_device (dense index spaces)."""
+        import torch
+        dV = torch.from_numpy(np.ascontiguousarray(np.atleast_2d(V_b), np.float64)).cuda()
+        out = self.apply_transformed_device(dV, T, b, fill=fill)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
     def apply_M(self, A_s, fill=np.nan, force_conservation=True):
         """Applies the regrid matrix to A_s (vectors in the ORIGINAL sparse space of the input grid):
         a 1-D vector or a 2-D array of row vectors; un-set output cells get `fill`

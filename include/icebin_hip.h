@@ -161,6 +161,16 @@ int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nv
 int ibh_weighted_apply_device(const ibh_weighted *w, const double *dA_b, int32_t nvar, int64_t lda,
                               double *dB_b, int64_t ldb, double fill, int force_conservation,
                               void *stream);
+/* The coupler's fused product B = M * (A*T + b) (IceCoupler.cpp:203-252 construct_ice_ivalsI and
+ * :445 gcm_ivalsX = M * (ice_ovalsI*T + b)): dA_b [nvar_in x ncol_d] field-major device pointer,
+ * T [nvar_in x nvar_out] row-major HOST array holding the sparse variable transform (exact zeros are
+ * structural and skipped, as Eigen's dense*sparse product does), b [nvar_out] host, dB_b
+ * [nvar_out x nrow_d] device.  The small dense transform is applied on the SMALL side of M (inputs
+ * when ncol_d <= nrow_d, outputs otherwise), so no transformed copy of the large field array is
+ * ever written.  Uses scratch owned by the handle: calls on one handle must be stream-ordered. */
+int ibh_weighted_apply_transformed_device(const ibh_weighted *w, const double *dA_b, int32_t nvar_in, int64_t lda,
+                                          const double *T, const double *b, int32_t nvar_out,
+                                          double *dB_b, int64_t ldb, double fill, void *stream);
 /* linear_Weighted.apply_weight(dim, A) (matrix_formats.rst:167-186):
  * out[k] = sum_j w[j] * A_b[k*lda + j], w = wM (dim 0) or Mw (dim 1); host pointers. */
 int ibh_weighted_apply_weight_host(const ibh_weighted *w, int dim, const double *A_b,

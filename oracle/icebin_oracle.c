@@ -809,6 +809,25 @@ void orc_apply(const orc_weighted *w, const double *A_b, int nvar, double fill,
         for (int i = 0; i < nrow; ++i) if (w->wM[i] == 0.0) y[i] = fill;
     }
 }
+void orc_apply_transformed(const orc_weighted *w, const double *V_b, int nvar_in, const double *T,
+                           const double *b, int nvar_out, double fill, double *B_b)
+{
+    int ncol = w->M->ncol;
+    double *X = (double *)xmalloc(sizeof(double) * (size_t)nvar_out * (size_t)ncol);
+    for (int k = 0; k < nvar_out; ++k) {
+        double *x = X + (size_t)k * (size_t)ncol;
+        for (int j = 0; j < ncol; ++j) x[j] = 0.0;
+        for (int l = 0; l < nvar_in; ++l) {                 /* gcm_ovalsE0_e * T.M: stored entries only */
+            double t = T[(size_t)l * (size_t)nvar_out + k];
+            if (t == 0.0) continue;
+            const double *v = V_b + (size_t)l * (size_t)ncol;
+            for (int j = 0; j < ncol; ++j) x[j] = x[j] + t * v[j];
+        }
+        for (int j = 0; j < ncol; ++j) x[j] = x[j] + b[k];  /* + b.replicate(n,1) */
+    }
+    orc_apply(w, X, nvar_out, fill, 0, B_b);
+    free(X);
+}
 void orc_apply_weight(const orc_weighted *w, int dim, const double *A_b, int nvar, double *out) {
     int n = dim == 0 ? w->M->nrow : w->M->ncol;
     const double *wt = dim == 0 ? w->wM : w->Mw;

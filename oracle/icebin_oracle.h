@@ -94,6 +94,13 @@ orc_weighted *orc_weighted_from_coo(int nrow, int ncol, long nnz, const int *row
  * Summation order = Eigen's SparseMatrix<ColMajor> * Dense (column scatter). */
 void orc_apply(const orc_weighted *w, const double *A_b, int nvar, double fill,
                int force_conservation, double *B_b);
+/* The coupler's product M * (V*T + b) (IceCoupler.cpp:203-252 construct_ice_ivalsI, :445 gcm_ivalsX):
+ * V_b [nvar_in x ncol] field-major, T [nvar_in x nvar_out] row-major dense holding the SPARSE
+ * variable transform (exact zeros are structural: they are skipped, as Eigen's dense*sparse
+ * product skips them), b [nvar_out].  X' = V*T + b is formed first, in Eigen's order (per output
+ * variable, stored T entries by ascending input variable, then + b), then M is applied. */
+void orc_apply_transformed(const orc_weighted *w, const double *V_b, int nvar_in, const double *T,
+                           const double *b, int nvar_out, double fill, double *B_b);
 /* apply_weight(dim, A) (matrix_formats.rst:167-186): out[k] = sum_j w[j]*A[k,j] */
 void orc_apply_weight(const orc_weighted *w, int dim, const double *A_b, int nvar, double *out);
 

@@ -70,6 +70,8 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_weighted_from_coo.restype = C.c_void_p
         L.orc_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.orc_apply_transformed.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_double, C.c_void_p]
         L.orc_apply_weight.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_time_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_time_apply.restype = C.c_double
@@ -174,6 +176,15 @@ class Weighted:
         B = np.empty((A.shape[0], self.nrow), np.float64)
         lib().orc_apply(self._h, _p(A), A.shape[0], float(fill), int(force_conservation), _p(B))
         return B if np.ndim(A_b) == 2 else B[0]
+
+    def apply_transformed(self, V_b, T, b, fill=np.nan):
+        V = np.ascontiguousarray(V_b, np.float64)
+        T = np.ascontiguousarray(T, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        assert V.shape == (T.shape[0], self.ncol) and b.shape == (T.shape[1],)
+        B = np.empty((T.shape[1], self.nrow), np.float64)
+        lib().orc_apply_transformed(self._h, _p(V), V.shape[0], _p(T), _p(b), T.shape[1], float(fill), _p(B))
+        return B
 
     def apply_weight(self, dim, A_b):
         A = np.ascontiguousarray(np.atleast_2d(A_b), np.float64)

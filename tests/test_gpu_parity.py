@@ -353,3 +353,30 @@ def test_field_sharded_apply_rccl_world1():
                 assert rel_linf(y, o.apply(xs[j])) <= FIELD_RTOL, (G, j)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["IvE", "AvI", "EvI"])
+def test_coupler_shaped_fused_apply(name):
+    # IceCoupler.cpp:203-252 (ice_ivalsI = IvE0 * (gcm_ovalsE0*T + b)) and :445 (gcm_ivalsX = M * (ice_ovalsI*T + b)):
+    # the small dense variable transform is applied on the small side of M; result vs the oracle's
+    # reference-order evaluation (transform first, then M).
+    g, em, mm, rg = setup("g20")
+    w = mm.regrid_matrices("greenland", em, scale=True, correctA=True).matrix(name)
+    o = rg.matrix_d(name, em, scale=True, correctA=True)
+    rng = np.random.default_rng(11)
+    nin, nout = 5, 3
+    V = syn.fields(nin, w.ncol_d)
+    V[4, ::7] = np.nan                       # an input variable no output uses may carry NaN (contracts::ALLOW_NAN)
+    T = np.zeros((nin, nout))
+    T[0, 0], T[1, 0], T[2, 1], T[3, 2], T[0, 2] = 1.0, 0.5, 917.0, -2.0, 0.25     # sparse: row 4 is all structural zeros
+    b = np.array([0.0, 273.15, -1.0])
+    y = w.apply_transformed(V, T, b, fill=-9.0)
+    ref = o.apply_transformed(V, T, b, fill=-9.0)
+    assert y.shape == (nout, w.nrow_d) and np.all(np.isfinite(y))
+    assert rel_linf(y, ref) <= FIELD_RTOL
+    # second call reuses the handle's scratch and cached M*1
+    assert rel_linf(w.apply_transformed(2 * V, T, b, fill=-9.0), o.apply_transformed(2 * V, T, b, fill=-9.0)) <= FIELD_RTOL
+    # a NaN in a USED variable propagates exactly where the reference puts it
+    V2 = V.copy(); V2[2, 5] = np.nan
+    y2, r2 = w.apply_transformed(V2, T, b), o.apply_transformed(V2, T, b)
+    assert np.array_equal(np.isnan(y2), np.isnan(r2)) and np.isnan(y2).any()
