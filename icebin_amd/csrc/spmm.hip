@@ -101,12 +101,19 @@ __device__ __forceinline__ double xload(__amdgpu_buffer_rsrc_t rs, int byte_off)
 // FPW = fields per wave, WK = waves that split the nnz range of the row, NW = waves per workgroup.
 // The NW waves form WF = NW/WK groups over fields; a block covers FB = FPW*WF fields and stages
 // the row segment once for all of them.
-template <int FPW, int WK, int UNROLL, int NW>
+// DIAG builds (dev only, ibh_set_tuning("rowblock_diag_*")) stamp s_memtime at the phase boundaries
+// of wave 0 of every workgroup into a side buffer; the product kernel (DIAG == false) has no stamps.
+#define IBH_STAMP(slot)                                                                         \
+    do {                                                                                        \
+        if (DIAG && threadIdx.x == 0) diag[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+template <int FPW, int WK, int UNROLL, int NW, bool DIAG = false>
 __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
     const double *__restrict__ X, long ldx, int ncol, double *__restrict__ Y, long ldy, int nrow, int nf, int nfc,
-    int xcd_mode, const double *__restrict__ wM, double fill)
+    int xcd_mode, const double *__restrict__ wM, double fill, unsigned long long *__restrict__ diag = nullptr)
 {
+    IBH_STAMP(0);
     constexpr int RB_THREADS = NW * 64;
     constexpr int RB_STAGE = RB_SEG / RB_THREADS;
     constexpr int WF = NW / WK;
@@ -135,6 +142,8 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     for (int j = 0; j < FPW; ++j) acc[j] = 0.0;
 
     const int beg = rowptr[r], end = rowptr[r + 1];
+    if (DIAG && threadIdx.x == 0) { diag[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(end - beg); }
+    IBH_STAMP(1);
     for (int seg = beg; seg < end; seg += RB_SEG) {
         const int n = min(RB_SEG, end - seg);
         if (seg != beg) __syncthreads();
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
             }
         }
         __syncthreads();
+        IBH_STAMP(2);
         // Full batches: every lane issues UNROLL*FPW loads before the first FMA, no predication.
         const int nfull = n - n % BATCH;
         int kb = 0;
@@ -176,6 +186,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) acc[j] = fma(v[u], x[j][u], acc[j]);
         }
+        IBH_STAMP(3);
         // Tail batch: lanes past the end re-read the last entry and are masked at the FMA (never
         // multiplied by 0: 0*NaN must not leak into a row).
         if (kb + wk * 64 < n) {
@@ -201,8 +212,11 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
                 for (int u = 0; u < UNROLL; ++u) acc[j] = ok[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
         }
     }
+    if (DIAG) { double t = 0; for (int j = 0; j < FPW; ++j) t += acc[j]; if (t == 1.2345e301) diag[1 << 20] = 1; }   // consume the loads before stamping
+    IBH_STAMP(4);
 #pragma unroll
     for (int j = 0; j < FPW; ++j) acc[j] = wave_sum(acc[j]);
+    IBH_STAMP(5);
 
     const bool dead = wM[r] == 0.0;     // mask_result, IceCoupler.cpp:186-201
     if (WK == 1) {
@@ -211,6 +225,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
             for (int j = 0; j < FPW; ++j)
                 if (f0 + j < nf) Y[(long)(f0 + j) * ldy + r] = dead ? fill : acc[j];
         }
+        IBH_STAMP(6);
     } else {
         if (lane == 0) {
 #pragma unroll
@@ -336,6 +351,14 @@ static void launch_rowblock(const ibh_weighted *w, const double *dA, int nvar, l
     if (unroll == 0) {
         const double mean = w->nrow ? (double)w->nnz / (double)w->nrow / (64.0 * WK) : 1.0;
         unroll = mean > 4.0 ? 8 : mean > 2.0 ? 4 : mean > 1.0 ? 2 : 1;
+    }
+    if (get_tuning("rowblock_diag_lo", 0) || get_tuning("rowblock_diag_hi", 0)) {
+        auto *diag = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)get_tuning("rowblock_diag_hi", 0) << 32) |
+                                                            (unsigned)get_tuning("rowblock_diag_lo", 0));
+        hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, 8, NW, true>), dim3((unsigned)nb), dim3(NW * 64), 0, stream,
+                           w->rowptr.p, w->colind.p, w->val.p, dA, lda, w->ncol, dB, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill, diag);
+        IBH_HIP(hipGetLastError());
+        return;
     }
 #define IBH_RB(U)                                                                                        \
     hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U, NW>), dim3((unsigned)nb), dim3(NW * 64), 0, stream, \
