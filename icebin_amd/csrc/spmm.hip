@@ -40,10 +40,24 @@ int get_tuning(const char *key, int dflt) {
 void set_tuning(const char *key, int value) { tuning()[key] = value; }
 
 // ---- helpers -------------------------------------------------------------------------------
+// Sum over the 64 lanes of a wave, result valid in every lane.  DPP moves instead of ds_bpermute:
+// the shuffle form is six dependent trips through the LDS crossbar (0.6 us measured at the end of
+// every workgroup of the headline kernel, on its critical path); this is ~25 VALU instructions.
+// Fixed combination order -> bitwise reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_move<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]: pairs
+    v += dpp_move<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]: quads
+    v += dpp_move<0x141, 0xf>(v);    // row_half_mirror: 8 lanes
+    v += dpp_move<0x140, 0xf>(v);    // row_mirror: 16 lanes (every lane of a row holds the row sum)
+    v += dpp_move<0x142, 0xa>(v);    // row_bcast15 into rows 1,3: lanes 16-31 = rows 0+1, lanes 48-63 = rows 2+3
+    v += dpp_move<0x143, 0xc>(v);    // row_bcast31 into rows 2,3: lanes 48-63 = total
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one).  Give each
