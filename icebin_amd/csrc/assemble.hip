@@ -276,7 +276,7 @@ static Numbering number_set_begin(const RgView &rg, ibh_sparse_set *set, int64_t
     nb.first = A.get<uint32_t>((size_t)sparse_extent);
     nb.flag = A.get<uint32_t>((size_t)(2 * rg.nX));
     IBH_HIP(hipMemsetAsync(nb.first, 0xFF, sizeof(uint32_t) * (size_t)sparse_extent, st));
-    const dim3 grid(ceil_div(rg.nX, T));
+    const dim3 grid(rg.nX ? ceil_div(rg.nX, T) : 1);
     if (list == LIST_EP) {
         hipLaunchKernelGGL(k_number_first<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, nb.first, d_err);
         hipLaunchKernelGGL(k_number_flag<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, nb.first, nb.flag);
@@ -295,7 +295,7 @@ static void number_set_finish(const RgView &rg, Numbering &nb, uint32_t n_new, h
     IBH_CHECK((int64_t)n_new <= nb.max_new, "internal: more new keys (%u) than reserved (%ld)", n_new, (long)nb.max_new);
     IBH_CHECK((int64_t)ds.n_old + n_new < (1ll << 31), "dense extent overflows int32");
     const int T = 256;
-    const dim3 grid(ceil_div(rg.nX, T));
+    const dim3 grid(rg.nX ? ceil_div(rg.nX, T) : 1);
     if (nb.list == LIST_EP) hipLaunchKernelGGL(k_number_assign<true>, grid, dim3(T), 0, st, rg, nb.list, nb.key, ds.tab, nb.first, nb.flag, ds.n_old, ds.to_sparse);
     else hipLaunchKernelGGL(k_number_assign<false>, grid, dim3(T), 0, st, rg, nb.list, nb.key, ds.tab, nb.first, nb.flag, ds.n_old, ds.to_sparse);
     IBH_HIP(hipGetLastError());
@@ -630,7 +630,7 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
                                       (sp->col_list == LIST_EP ? 2 : 1) * g->nX, d_err, d_cnt + 2, st);
     // contributions in emission (x) order: count + scan do not depend on the numbering
     const int T = 256;
-    const dim3 grid(ceil_div(g->nX, T));
+    const dim3 grid(g->nX ? ceil_div(g->nX, T) : 1);
     uint32_t *cnt = A.get<uint32_t>((size_t)g->nX);
     if (uses_ep) hipLaunchKernelGGL(k_contrib_count<true>, grid, dim3(T), 0, st, rg, *sp, cnt);
     else hipLaunchKernelGGL(k_contrib_count<false>, grid, dim3(T), 0, st, rg, *sp, cnt);

@@ -380,3 +380,32 @@ def test_coupler_shaped_fused_apply(name):
     V2 = V.copy(); V2[2, 5] = np.nan
     y2, r2 = w.apply_transformed(V2, T, b), o.apply_transformed(V2, T, b)
     assert np.array_equal(np.isnan(y2), np.isnan(r2)) and np.isnan(y2).any()
+
+
+def test_empty_and_degenerate_inputs():
+    # everything masked -> empty matrices; one unmasked cell; zero fields; nX == 0
+    g = syn.make_grids("tiny")
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    em = np.full(g["nI"], np.nan)
+    rm = mm.regrid_matrices("greenland", em)
+    for name in ALL:
+        w = rm.matrix(name)
+        o = rg.matrix_d(name, em, scale=True, correctA=True)
+        assert (w.nrow_d, w.ncol_d, w.nnz) == (0, 0, 0) == (o.nrow, o.ncol, o.nnz), name
+        assert w.apply(np.zeros((3, 0))).shape == (3, 0)
+        assert w.shape == (o.sparse_extents[0], o.sparse_extents[1])
+    em1 = em.copy(); em1[g["nI"] // 2] = 1234.5          # a single ice cell
+    rm1 = mm.regrid_matrices("greenland", em1)
+    for name in ALL:
+        assert_same_weighted(rm1.matrix_d(name, scale=True, correctA=True), rg.matrix_d(name, em1, scale=True, correctA=True), name + " one cell")
+    w = rm1.matrix("AvI")
+    assert w.apply(np.zeros((0, w.ncol_d))).shape == (0, w.nrow_d)
+    # identity dims on an empty matrix: every row exists, all weights zero -> apply returns fill everywhere
+    dimI = icebin_amd.SparseSet.identity(g["nI"])
+    wi = rm.matrix_d("IvA", (dimI, None))
+    assert wi.nrow_d == g["nI"] and wi.ncol_d == 0 and wi.nnz == 0
+    assert np.all(wi.apply(np.zeros((2, 0)), fill=-3.0) == -3.0)
+    # an exchange grid with no cells at all
+    g0 = dict(g); g0["ex_indices"] = np.zeros((0, 2), np.int32); g0["ex_area"] = np.zeros(0)
+    w0 = icebin_amd.from_synthetic(g0).regrid_matrices("greenland", syn.dome_elevmask(g)).matrix("EvI")
+    assert (w0.nrow_d, w0.ncol_d, w0.nnz) == (0, 0, 0)
