@@ -264,9 +264,15 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     const double *__restrict__ X, long ldx, double *__restrict__ Y, long ldy, int nrow, int nf, int fper,
     const double *__restrict__ wM, double fill)
 {
-    const int r = blockIdx.x * SR_THREADS + threadIdx.x;
+    // 1-D grid, field chunk fastest, contiguous ranges per XCD: the nfy workgroups that walk the same
+    // 256 rows (one per field chunk) are neighbours on one XCD, so rowptr/colind/vals/wM of those rows
+    // come from HBM once and from that XCD's L2 for the other chunks.
+    const int nfy = (nf + fper - 1) / fper;
+    const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int rb = logical / nfy, fy = logical - rb * nfy;
+    const int r = rb * SR_THREADS + threadIdx.x;
     if (r >= nrow) return;
-    const int fbeg = blockIdx.y * fper;
+    const int fbeg = fy * fper;
     const int fend = min(nf, fbeg + fper);
     const int beg = rowptr[r], end = rowptr[r + 1];
     const int n = end - beg;
@@ -432,7 +438,9 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
         // flight (measured: 4 for ~1 entry per row, 8 for 2-3)
         int fper = get_tuning("shortrow_fper", (double)w->nnz <= 1.5 * (double)w->nrow ? 4 : 8);
         if (fper < 1) fper = 1;
-        dim3 grid((unsigned)ceil_div(w->nrow, SR_THREADS), (unsigned)ceil_div(nvar, fper));
+        const long nblk = (long)ceil_div(w->nrow, SR_THREADS) * ceil_div(nvar, fper);
+        IBH_CHECK(nblk < (1l << 31), "spmm grid too large (%ld blocks)", nblk);
+        dim3 grid((unsigned)nblk);
         const int g = get_tuning("shortrow_group", fper >= 32 ? 32 : fper >= 16 ? 16 : fper >= 8 ? 8 : 4);
 #define IBH_SR(NT, GG)                                                                                          \
     hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
