@@ -162,58 +162,72 @@ __global__ void k_scatter_existing(int32_t *tab, const int64_t *to_sparse, int n
     if (i < n) tab[to_sparse[i]] = i;
 }
 
-template <bool WITH_EP>
-__global__ void k_number_first(RgView rg, int list, int key, const int32_t *__restrict__ tab,
-                               uint32_t *__restrict__ first, int *__restrict__ err_x) {
-    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// The three numbering passes handle BOTH sets of a matrix (rows and columns) per exchange-cell visit,
+// and the flag pass also counts the cell's contributions: 4 generator passes per build instead of 8.
+struct SetArgs {
+    int enabled, list, key, base;
+    int32_t *tab;           // [sparse_extent] sparse -> dense (-1 missing)
+    uint32_t *first;        // [sparse_extent] smallest emission position 2x+j that names the key
+    uint32_t *flag;         // [2*nX] 1 where position 2x+j is a first occurrence; scanned in place -> rank
+    int64_t *to_sparse;     // [capacity] dense -> sparse
+};
+
+__device__ __forceinline__ void first_one(const SetArgs &a, const XCell &c, long x, bool valid, bool lane0) {
     long keys[2] = {-1, -1};
-    int n = 0;                                  // no early return: every lane takes part in the shuffle
-    if (x < rg.nX) {
-        const XCell c = load_cell<WITH_EP>(rg, x);
-        if (WITH_EP && c.range_error) atomicMin(err_x, (int)x);
-        else n = list_entries(c, x, list, key, keys);
-    }
+    const int n = valid ? list_entries(c, x, a.list, a.key, keys) : 0;
     // Sorted exchange grids give long runs of equal keys (one atmosphere cell per ~10^2..10^3
     // consecutive x): the lane below already carries a smaller position for the same key, so only
     // the first lane of a run inside the wave needs the atomic.
     const long prev0 = __shfl_up(n > 0 ? keys[0] : -1l, 1, 64);
-    const bool lane0 = (threadIdx.x & 63) == 0;
     for (int j = 0; j < n; ++j) {
         if (j == 0 && !lane0 && prev0 == keys[0]) continue;
-        if (tab[keys[j]] < 0) atomicMin(&first[keys[j]], (uint32_t)(2 * x + j));
+        if (a.tab[keys[j]] < 0) atomicMin(&a.first[keys[j]], (uint32_t)(2 * x + j));
     }
 }
 template <bool WITH_EP>
-__global__ void k_number_flag(RgView rg, int list, int key, const int32_t *__restrict__ tab,
-                              const uint32_t *__restrict__ first, uint32_t *__restrict__ flag) {
+__global__ void k_first2(RgView rg, SetArgs a, SetArgs b, int *__restrict__ err_x) {
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= rg.nX) return;
-    const XCell c = load_cell<WITH_EP>(rg, x);
-    long keys[2];
-    const int n = (WITH_EP && c.range_error) ? 0 : list_entries(c, x, list, key, keys);
-    uint32_t f0 = 0, f1 = 0;
-    if (n > 0 && tab[keys[0]] < 0 && first[keys[0]] == (uint32_t)(2 * x)) f0 = 1;
-    if (n > 1 && tab[keys[1]] < 0 && first[keys[1]] == (uint32_t)(2 * x + 1)) f1 = 1;
-    flag[2 * x] = f0;
-    flag[2 * x + 1] = f1;
+    XCell c;
+    bool valid = false;                         // no early return: every lane takes part in the shuffles
+    if (x < rg.nX) {
+        c = load_cell<WITH_EP>(rg, x);
+        if (WITH_EP && c.range_error) atomicMin(err_x, (int)x);
+        else valid = true;
+    }
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    if (a.enabled) first_one(a, c, x, valid, lane0);
+    if (b.enabled) first_one(b, c, x, valid, lane0);
 }
-template <bool WITH_EP>
-__global__ void k_number_assign(RgView rg, int list, int key, int32_t *__restrict__ tab,
-                                const uint32_t *__restrict__ first, const uint32_t *__restrict__ rank, int base,
-                                int64_t *__restrict__ to_sparse) {
-    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= rg.nX) return;
-    const XCell c = load_cell<WITH_EP>(rg, x);
+
+__device__ __forceinline__ void flag_one(const SetArgs &a, const XCell &c, long x, bool valid) {
     long keys[2];
-    const int n = (WITH_EP && c.range_error) ? 0 : list_entries(c, x, list, key, keys);
+    const int n = valid ? list_entries(c, x, a.list, a.key, keys) : 0;
+    uint32_t f0 = 0, f1 = 0;
+    if (n > 0 && a.tab[keys[0]] < 0 && a.first[keys[0]] == (uint32_t)(2 * x)) f0 = 1;
+    if (n > 1 && a.tab[keys[1]] < 0 && a.first[keys[1]] == (uint32_t)(2 * x + 1)) f1 = 1;
+    a.flag[2 * x] = f0;
+    a.flag[2 * x + 1] = f1;
+}
+__device__ __forceinline__ void assign_one(const SetArgs &a, const XCell &c, long x) {
+    long keys[2];
+    const int n = list_entries(c, x, a.list, a.key, keys);
     for (int j = 0; j < n; ++j) {
         // first[] still holds the winner; tab is only written at the winner's key
-        if (first[keys[j]] == (uint32_t)(2 * x + j)) {
-            const int id = base + (int)rank[2 * x + j];
-            tab[keys[j]] = id;
-            to_sparse[id] = keys[j];
+        if (a.first[keys[j]] == (uint32_t)(2 * x + j)) {
+            const int id = a.base + (int)a.flag[2 * x + j];
+            a.tab[keys[j]] = id;
+            a.to_sparse[id] = keys[j];
         }
     }
+}
+template <bool WITH_EP>
+__global__ void k_assign2(RgView rg, SetArgs a, SetArgs b) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= rg.nX) return;
+    const XCell c = load_cell<WITH_EP>(rg, x);
+    if (WITH_EP && c.range_error) return;
+    if (a.enabled) assign_one(a, c, x);
+    if (b.enabled) assign_one(b, c, x);
 }
 
 struct DeviceSet {
@@ -222,24 +236,22 @@ struct DeviceSet {
     int n_old = 0, n = 0;
 };
 
-// Number `set` through the entries of `list` (keys of kind `key`), appending new keys first-seen.
-// Two phases around ONE host sync shared by the whole build: begin() enqueues everything up to the
-// scan (the number of new keys lands in *d_new), finish() assigns the ids once the host knows it.
+// Host side of the dense numbering of one set (spsparse::SparseSet::add_dense in emission order,
+// appending to whatever the caller's set already holds): prepare() builds the device tables,
+// the fused kernels above do the work, finish() adopts the new keys once the host knows how many.
 struct Numbering {
     DeviceSet ds;
     ibh_sparse_set *set = nullptr;
-    uint32_t *first = nullptr, *flag = nullptr;
-    int list = 0, key = 0;
+    SetArgs args{};
     int64_t max_new = 0;
-    bool done = false;          // identity set that already covers the whole sparse space
 };
 
-static Numbering number_set_begin(const RgView &rg, ibh_sparse_set *set, int64_t sparse_extent, int list, int key,
-                                  int64_t max_new, int *d_err, uint32_t *d_new, hipStream_t st) {
+static Numbering number_set_prepare(const RgView &rg, ibh_sparse_set *set, int64_t sparse_extent, int list, int key,
+                                    int64_t max_new, hipStream_t st) {
     Arena &A = arena();
     set->sparse_extent = sparse_extent;                       // set_sparse_extent, RegridMatrices_Dynamic.cpp:69-72
     Numbering nb;
-    nb.set = set; nb.list = list; nb.key = key;
+    nb.set = set;
     DeviceSet &ds = nb.ds;
     ds.n_old = set->dense_extent();
     if (set->identity) {
@@ -271,34 +283,21 @@ static Numbering number_set_begin(const RgView &rg, ibh_sparse_set *set, int64_t
         }
     }
     ds.n = ds.n_old;
-    IBH_HIP(hipMemsetAsync(d_new, 0, sizeof(uint32_t), st));
-    if (set->identity && ds.n_old == sparse_extent) { nb.done = true; return nb; }   // nothing can be new
-    nb.first = A.get<uint32_t>((size_t)sparse_extent);
-    nb.flag = A.get<uint32_t>((size_t)(2 * rg.nX));
-    IBH_HIP(hipMemsetAsync(nb.first, 0xFF, sizeof(uint32_t) * (size_t)sparse_extent, st));
-    const dim3 grid(rg.nX ? ceil_div(rg.nX, T) : 1);
-    if (list == LIST_EP) {
-        hipLaunchKernelGGL(k_number_first<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, nb.first, d_err);
-        hipLaunchKernelGGL(k_number_flag<true>, grid, dim3(T), 0, st, rg, list, key, ds.tab, nb.first, nb.flag);
-    } else {
-        hipLaunchKernelGGL(k_number_first<false>, grid, dim3(T), 0, st, rg, list, key, ds.tab, nb.first, d_err);
-        hipLaunchKernelGGL(k_number_flag<false>, grid, dim3(T), 0, st, rg, list, key, ds.tab, nb.first, nb.flag);
+    SetArgs &a = nb.args;
+    a.list = list; a.key = key; a.base = ds.n_old; a.tab = ds.tab; a.to_sparse = ds.to_sparse;
+    a.enabled = !(set->identity && ds.n_old == sparse_extent);      // an identity set that covers everything gains nothing
+    if (a.enabled) {
+        a.first = A.get<uint32_t>((size_t)sparse_extent);
+        a.flag = A.get<uint32_t>((size_t)(2 * rg.nX));
+        IBH_HIP(hipMemsetAsync(a.first, 0xFF, sizeof(uint32_t) * (size_t)sparse_extent, st));
     }
-    exclusive_scan_u32(nb.flag, nb.flag, (size_t)(2 * rg.nX), d_new, st);
     return nb;
 }
 
-static void number_set_finish(const RgView &rg, Numbering &nb, uint32_t n_new, hipStream_t st) {
+static void number_set_finish(Numbering &nb, uint32_t n_new, hipStream_t st) {
     DeviceSet &ds = nb.ds;
     ibh_sparse_set *set = nb.set;
-    if (nb.done || n_new == 0) return;
-    IBH_CHECK((int64_t)n_new <= nb.max_new, "internal: more new keys (%u) than reserved (%ld)", n_new, (long)nb.max_new);
-    IBH_CHECK((int64_t)ds.n_old + n_new < (1ll << 31), "dense extent overflows int32");
-    const int T = 256;
-    const dim3 grid(rg.nX ? ceil_div(rg.nX, T) : 1);
-    if (nb.list == LIST_EP) hipLaunchKernelGGL(k_number_assign<true>, grid, dim3(T), 0, st, rg, nb.list, nb.key, ds.tab, nb.first, nb.flag, ds.n_old, ds.to_sparse);
-    else hipLaunchKernelGGL(k_number_assign<false>, grid, dim3(T), 0, st, rg, nb.list, nb.key, ds.tab, nb.first, nb.flag, ds.n_old, ds.to_sparse);
-    IBH_HIP(hipGetLastError());
+    if (!nb.args.enabled || n_new == 0) return;
     ds.n = ds.n_old + (int)n_new;
     // the set keeps its table on the device; the host copy is completed only when somebody asks
     DevBuf<int64_t> grown((size_t)ds.n);
@@ -352,12 +351,15 @@ __device__ __forceinline__ int contributions(const XCell &c, long x, const MatSp
 }
 
 template <bool WITH_EP>
-__global__ void k_contrib_count(RgView rg, MatSpec s, uint32_t *__restrict__ cnt) {
+__global__ void k_flag2(RgView rg, SetArgs a, SetArgs b, MatSpec s, uint32_t *__restrict__ cnt) {
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= rg.nX) return;
     const XCell c = load_cell<WITH_EP>(rg, x);
+    const bool valid = !(WITH_EP && c.range_error);
+    if (a.enabled) flag_one(a, c, x, valid);
+    if (b.enabled) flag_one(b, c, x, valid);
     long rk[2], ck[2]; double t[2];
-    cnt[x] = (WITH_EP && c.range_error) ? 0u : (uint32_t)contributions(c, x, s, rk, ck, t);
+    cnt[x] = valid ? (uint32_t)contributions(c, x, s, rk, ck, t) : 0u;
 }
 template <bool WITH_EP>
 __global__ void k_contrib_emit(RgView rg, MatSpec s, const uint32_t *__restrict__ pos, const int32_t *__restrict__ rtab,
@@ -624,16 +626,24 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
 
     // dense numbering in emission order; each user-visible set is numbered by exactly one Ur matrix
     // (RegridMatrices_Dynamic.cpp:75-81, 86-90, 178-183, 187-190, 270-277), so the two are independent.
-    Numbering rnum = number_set_begin(rg, dims[0], extent_of(sp->row_key), sp->row_list, sp->row_key,
-                                      (sp->row_list == LIST_EP ? 2 : 1) * g->nX, d_err, d_cnt + 1, st);
-    Numbering cnum = number_set_begin(rg, dims[1], extent_of(sp->col_key), sp->col_list, sp->col_key,
-                                      (sp->col_list == LIST_EP ? 2 : 1) * g->nX, d_err, d_cnt + 2, st);
-    // contributions in emission (x) order: count + scan do not depend on the numbering
+    Numbering rnum = number_set_prepare(rg, dims[0], extent_of(sp->row_key), sp->row_list, sp->row_key,
+                                        (sp->row_list == LIST_EP ? 2 : 1) * g->nX, st);
+    Numbering cnum = number_set_prepare(rg, dims[1], extent_of(sp->col_key), sp->col_list, sp->col_key,
+                                        (sp->col_list == LIST_EP ? 2 : 1) * g->nX, st);
+    IBH_HIP(hipMemsetAsync(d_cnt + 1, 0, 3 * sizeof(uint32_t), st));
     const int T = 256;
     const dim3 grid(g->nX ? ceil_div(g->nX, T) : 1);
     uint32_t *cnt = A.get<uint32_t>((size_t)g->nX);
-    if (uses_ep) hipLaunchKernelGGL(k_contrib_count<true>, grid, dim3(T), 0, st, rg, *sp, cnt);
-    else hipLaunchKernelGGL(k_contrib_count<false>, grid, dim3(T), 0, st, rg, *sp, cnt);
+    if (uses_ep) {
+        hipLaunchKernelGGL(k_first2<true>, grid, dim3(T), 0, st, rg, rnum.args, cnum.args, d_err);
+        hipLaunchKernelGGL(k_flag2<true>, grid, dim3(T), 0, st, rg, rnum.args, cnum.args, *sp, cnt);
+    } else {
+        hipLaunchKernelGGL(k_first2<false>, grid, dim3(T), 0, st, rg, rnum.args, cnum.args, d_err);
+        hipLaunchKernelGGL(k_flag2<false>, grid, dim3(T), 0, st, rg, rnum.args, cnum.args, *sp, cnt);
+    }
+    if (rnum.args.enabled) exclusive_scan_u32(rnum.args.flag, rnum.args.flag, (size_t)(2 * g->nX), d_cnt + 1, st);
+    if (cnum.args.enabled) exclusive_scan_u32(cnum.args.flag, cnum.args.flag, (size_t)(2 * g->nX), d_cnt + 2, st);
+    // contributions in emission (x) order: count (done in k_flag2) + scan do not depend on the numbering
     exclusive_scan_u32(cnt, cnt, (size_t)g->nX, d_cnt + 3, st);
     uint32_t h_cnt[4];
     IBH_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
@@ -647,8 +657,20 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
         IBH_HIP(hipMemcpy(&e, rm->elevmaskI.p + ij[1], sizeof(double), hipMemcpyDeviceToHost));
         fail(IBH_ERANGE, "Elevation %g out of bounds (%g, %g)", e < 0 ? 0.0 : e, g->hcdefs_h.front(), g->hcdefs_h.back());
     }
-    number_set_finish(rg, rnum, h_cnt[1], st);
-    number_set_finish(rg, cnum, h_cnt[2], st);
+    for (Numbering *nb : {&rnum, &cnum}) {
+        const uint32_t n_new = nb == &rnum ? h_cnt[1] : h_cnt[2];
+        IBH_CHECK((int64_t)n_new <= nb->max_new, "internal: more new keys (%u) than reserved (%ld)", n_new, (long)nb->max_new);
+        IBH_CHECK((int64_t)nb->ds.n_old + n_new < (1ll << 31), "dense extent overflows int32");
+    }
+    if ((rnum.args.enabled && h_cnt[1]) || (cnum.args.enabled && h_cnt[2])) {
+        SetArgs ra = rnum.args, ca = cnum.args;
+        ra.enabled = ra.enabled && h_cnt[1]; ca.enabled = ca.enabled && h_cnt[2];
+        if (uses_ep) hipLaunchKernelGGL(k_assign2<true>, grid, dim3(T), 0, st, rg, ra, ca);
+        else hipLaunchKernelGGL(k_assign2<false>, grid, dim3(T), 0, st, rg, ra, ca);
+        IBH_HIP(hipGetLastError());
+    }
+    number_set_finish(rnum, h_cnt[1], st);
+    number_set_finish(cnum, h_cnt[2], st);
     const DeviceSet &rset = rnum.ds, &cset = cnum.ds;
     const int nrow = rset.n, ncol = cset.n;
     const uint32_t ncontrib = h_cnt[3];
