@@ -409,3 +409,40 @@ def test_empty_and_degenerate_inputs():
     g0 = dict(g); g0["ex_indices"] = np.zeros((0, 2), np.int32); g0["ex_area"] = np.zeros(0)
     w0 = icebin_amd.from_synthetic(g0).regrid_matrices("greenland", syn.dome_elevmask(g)).matrix("EvI")
     assert (w0.nrow_d, w0.ncol_d, w0.nnz) == (0, 0, 0)
+
+
+def test_alternate_indexingHC_and_proj_alias():
+    # a file-loaded regridder may carry indexingHC with HC as the FASTEST index (iE = iA*nhc + ihc);
+    # and sproj == "" aliases proj_area to native_area (IceRegridder.cpp:106-108) -> correctA is a no-op
+    g = syn.make_grids("g50")
+    g["hc_stride_A"], g["hc_stride_HC"] = 40, 1
+    em = syn.dome_elevmask(g)
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    rm = mm.regrid_matrices("greenland", em)
+    for name in ("EvI", "IvE", "EvA", "AvE", "XvE", "EvX"):
+        for correctA in (True, False):
+            assert_same_weighted(rm.matrix_d(name, scale=True, correctA=correctA),
+                                 rg.matrix_d(name, em, scale=True, correctA=correctA), name + " HC-fastest")
+    g2 = syn.make_grids("g50")
+    g2["A_proj_area"] = g2["A_native_area"]
+    mm2, rg2 = icebin_amd.from_synthetic(g2), orc.Regridder(g2)
+    rm2 = mm2.regrid_matrices("greenland", em)
+    for name in ("AvI", "IvA", "EvA"):
+        a, b = rm2.matrix_d(name, scale=True, correctA=True), rm2.matrix_d(name, scale=True, correctA=False)
+        assert_same_weighted(a, rg2.matrix_d(name, em, scale=True, correctA=True), name + " proj alias")
+        np.testing.assert_allclose(a.coo_dense()[2], b.coo_dense()[2], rtol=1e-15)
+    with pytest.raises(icebin_amd.IcebinHipError, match="neither"):
+        g3 = syn.make_grids("tiny"); g3["hc_stride_A"], g3["hc_stride_HC"] = 3, 7
+        icebin_amd.from_synthetic(g3)
+
+
+def test_unsorted_prepopulated_and_reused_matrices_object():
+    # one RegridMatrices serves many matrix_d calls with different params (IceCoupler.cpp:361-468), in any order
+    g, em, mm, rg = setup("g50", order="shuffled")
+    rm = mm.regrid_matrices("greenland", em, scale=False, correctA=False)
+    calls = [("XvE", False, True), ("AvI", False, True), ("EvI", False, False), ("IvE", True, True), ("AvI", True, False)]
+    for name, scale, correctA in calls + calls[::-1]:
+        assert_same_weighted(rm.matrix_d(name, scale=scale, correctA=correctA),
+                             rg.matrix_d(name, em, scale=scale, correctA=correctA), "%s %d %d" % (name, scale, correctA))
+    # RegridMatrices.matrix() uses the params given to regrid_matrices (RegridMatrices_Dynamic.cpp:433)
+    assert_same_weighted(rm.matrix("IvA"), rg.matrix_d("IvA", em, scale=False, correctA=False), "matrix() params")
