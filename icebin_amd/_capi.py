@@ -25,7 +25,7 @@ class RegridderDesc(C.Structure):
         ("nA", C.c_int64), ("nA_dense", C.c_int32), ("A_to_sparse", C.c_void_p),
         ("A_native_area", C.c_void_p), ("A_proj_area", C.c_void_p),
         ("nhc", C.c_int32), ("hcdefs", C.c_void_p), ("hc_stride_A", C.c_int64), ("hc_stride_HC", C.c_int64),
-        ("interp_style", C.c_int32),
+        ("interp_style", C.c_int32), ("I_centroid_xy", C.c_void_p),
     ]
 
 

@@ -585,15 +585,205 @@ static void compute_max_row(ibh_weighted *w, hipStream_t st) {
     (void)st; w->max_row_nnz = 0;   // dispatch uses the mean row length only
 }
 
+// ---- smoothing (sigma != 0): M <- smoothI * M  (smoother.cpp:8-99, RegridMatrices_Dynamic.cpp:237-248) ------
+// smoothI[i,j] = exp(-.5 d2(i,j)) * area_j / sum_j(...) over the unmasked ice cells j of dimI with
+// d2 = sum_k ((c_j[k]-c_i[k])/sigma[k])^2 < 4, c = (x, y, elevation), area = wM.  The reference finds
+// neighbours with an RTree; here: uniform bins of 2*sigma_x x 2*sigma_y, 3x3 bins searched per cell.
+// Everything downstream reuses the assembly machinery: neighbour triplets -> sort by (i,j) -> row
+// denominators (sequential) -> products with the rows of M as contributions -> sort by (i,a) ->
+// sequential sums.  exp() is the device library's: entries agree with the oracle to rounding, not bitwise.
+struct SmoothView {
+    const int64_t *row_s;       // dense ice id -> sparse
+    const double *em, *cen, *area;
+    int n;                      // dense ice cells
+    double sx, sy, sz, x0, y0, bw, bh;
+    int nbx, nby;
+};
+__device__ __forceinline__ bool smooth_tuple(const SmoothView &v, int d, double c[3]) {
+    const int64_t s = v.row_s[d];
+    const double e = v.em[s];
+    if (e != e) return false;               // masked cells are not tuples (smoother.cpp:83-84)
+    c[0] = v.cen[2 * s]; c[1] = v.cen[2 * s + 1]; c[2] = e;
+    return true;
+}
+__device__ __forceinline__ int smooth_bin(const SmoothView &v, const double c[3]) {
+    int bx = (int)((c[0] - v.x0) / v.bw), by = (int)((c[1] - v.y0) / v.bh);
+    bx = bx < 0 ? 0 : bx >= v.nbx ? v.nbx - 1 : bx;
+    by = by < 0 ? 0 : by >= v.nby ? v.nby - 1 : by;
+    return by * v.nbx + bx;
+}
+__global__ void k_smooth_bin_count(SmoothView v, uint32_t *__restrict__ bincnt, int *__restrict__ bad) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= v.n) return;
+    double c[3];
+    if (!smooth_tuple(v, d, c)) return;
+    if (v.area[d] == 0.0) atomicMin(bad, d);          // "Area of cell %ld must be non-zero", smoother.cpp:89-90
+    atomicAdd(&bincnt[smooth_bin(v, c)], 1u);
+}
+__global__ void k_smooth_bin_fill(SmoothView v, const uint32_t *__restrict__ binstart, uint32_t *__restrict__ cursor,
+                                  int32_t *__restrict__ members) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= v.n) return;
+    double c[3];
+    if (!smooth_tuple(v, d, c)) return;
+    const int b = smooth_bin(v, c);
+    members[binstart[b] + atomicAdd(&cursor[b], 1u)] = d;      // order inside a bin is irrelevant: triplets are sorted later
+}
+// pass 0: count neighbours of cell d; pass 1: emit (d<<32|j, w) at off[d]
+template <int PASS>
+__global__ void k_smooth_neighbours(SmoothView v, const uint32_t *__restrict__ binstart, const int32_t *__restrict__ members,
+                                    uint32_t *__restrict__ cnt, const uint32_t *__restrict__ off,
+                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, double *__restrict__ wraw) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= v.n) return;
+    double c[3];
+    uint32_t n = 0;
+    if (smooth_tuple(v, d, c)) {
+        const int b = smooth_bin(v, c), bx = b % v.nbx, by = b / v.nbx;
+        const uint32_t o = PASS ? off[d] : 0;
+        for (int yy = max(by - 1, 0); yy <= min(by + 1, v.nby - 1); ++yy)
+            for (int xx = max(bx - 1, 0); xx <= min(bx + 1, v.nbx - 1); ++xx) {
+                const int bb = yy * v.nbx + xx;
+                for (uint32_t q = binstart[bb]; q < binstart[bb + 1]; ++q) {
+                    const int j = members[q];
+                    double cj[3];
+                    (void)smooth_tuple(v, j, cj);
+                    const double d0 = (cj[0] - c[0]) / v.sx, d1 = (cj[1] - c[1]) / v.sy, d2 = (cj[2] - c[2]) / v.sz;
+                    double nds = 0;
+                    nds = nds + d0 * d0; nds = nds + d1 * d1; nds = nds + d2 * d2;      // smoother.cpp:29-33
+                    if (nds < 4.0) {                                                      // nsigma^2
+                        if (PASS) {
+                            keys[o + n] = ((uint64_t)(uint32_t)d << 32) | (uint32_t)j;
+                            idx[o + n] = o + n;
+                            wraw[o + n] = exp(-.5 * nds) * v.area[j];                     // :35-36
+                        }
+                        ++n;
+                    }
+                }
+            }
+    }
+    if (!PASS) cnt[d] = n;
+}
+__global__ void k_smooth_rowptr(const uint32_t *__restrict__ off, int n, uint32_t total, int32_t *__restrict__ rowptr) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n) rowptr[d] = (int32_t)off[d];
+    if (d == 0) rowptr[n] = (int32_t)total;
+}
+// number of M entries each smoothing entry (i,j) multiplies = length of row j of M
+__global__ void k_smooth_prod_count(const uint64_t *__restrict__ skeys, size_t ns, const int32_t *__restrict__ rowptr,
+                                    uint32_t *__restrict__ cnt) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ns) return;
+    const int j = (int)(skeys[q] & 0xffffffffu);
+    cnt[q] = (uint32_t)(rowptr[j + 1] - rowptr[j]);
+}
+__global__ void k_smooth_prod_emit(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ sidx,
+                                   const double *__restrict__ wraw, const double *__restrict__ denom, size_t ns,
+                                   const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                   const double *__restrict__ val, const uint32_t *__restrict__ pos,
+                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, double *__restrict__ term) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ns) return;
+    const uint64_t k = skeys[q];
+    const int i = (int)(k >> 32), j = (int)(k & 0xffffffffu);
+    const double factor = 1.0 / denom[i];
+    const double s = factor * wraw[sidx[q]];                     // factor * ii->second, smoother.cpp:62-64
+    uint32_t p = pos[q];
+    for (int e = rowptr[j]; e < rowptr[j + 1]; ++e, ++p) {
+        keys[p] = ((uint64_t)(uint32_t)i << 32) | (uint32_t)colind[e];
+        idx[p] = p;
+        term[p] = s * val[e];
+    }
+}
+
+static void smooth_matrix(ibh_weighted *w, const ibh_regrid_matrices *rm, const int64_t *row_s, const double sigma[3],
+                          hipStream_t st) {
+    const ibh_regridder *g = rm->rg;
+    IBH_CHECK(g->has_centroid, "smoothing (sigma != 0) needs the ice grid's centroid_xy (ibh_regridder_desc.I_centroid_xy)");
+    IBH_CHECK(sigma[0] > 0 && sigma[1] > 0 && sigma[2] > 0, "smoothing needs three positive sigmas, got (%g, %g, %g)", sigma[0], sigma[1], sigma[2]);
+    if (w->nrow == 0) return;
+    Arena &A = arena();
+    const int T = 256, n = w->nrow;
+    SmoothView v{row_s, rm->elevmaskI.p, g->I_centroid.p, w->wM.p, n, sigma[0], sigma[1], sigma[2],
+                 g->cmin[0], g->cmin[1], 2.0 * sigma[0], 2.0 * sigma[1], 1, 1};
+    v.nbx = (int)std::min(4096.0, std::floor((g->cmax[0] - g->cmin[0]) / v.bw) + 1.0);
+    v.nby = (int)std::min(4096.0, std::floor((g->cmax[1] - g->cmin[1]) / v.bh) + 1.0);
+    if (v.nbx == 4096) v.bw = (g->cmax[0] - g->cmin[0]) / 4096.0 * (1 + 1e-12);     // never finer than 4096 bins: bins only grow
+    if (v.nby == 4096) v.bh = (g->cmax[1] - g->cmin[1]) / 4096.0 * (1 + 1e-12);
+    const size_t nbins = (size_t)v.nbx * v.nby;
+    uint32_t *binstart = A.get<uint32_t>(nbins + 1), *cursor = A.get<uint32_t>(nbins);
+    int32_t *members = A.get<int32_t>((size_t)n);
+    uint32_t *d_cnt = A.get<uint32_t>(4);
+    int *d_bad = reinterpret_cast<int *>(d_cnt + 3);
+    const int big = 0x7fffffff;
+    IBH_HIP(hipMemsetAsync(binstart, 0, sizeof(uint32_t) * (nbins + 1), st));
+    IBH_HIP(hipMemsetAsync(cursor, 0, sizeof(uint32_t) * nbins, st));
+    IBH_HIP(hipMemcpyAsync(d_bad, &big, sizeof(int), hipMemcpyHostToDevice, st));
+    const dim3 grid(ceil_div(n, T));
+    hipLaunchKernelGGL(k_smooth_bin_count, grid, dim3(T), 0, st, v, binstart, d_bad);
+    exclusive_scan_u32(binstart, binstart, nbins + 1, nullptr, st);
+    hipLaunchKernelGGL(k_smooth_bin_fill, grid, dim3(T), 0, st, v, binstart, cursor, members);
+    uint32_t *ncnt = A.get<uint32_t>((size_t)n);
+    hipLaunchKernelGGL(k_smooth_neighbours<0>, grid, dim3(T), 0, st, v, binstart, members, ncnt, (const uint32_t *)nullptr,
+                       (uint64_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr);
+    exclusive_scan_u32(ncnt, ncnt, (size_t)n, d_cnt, st);
+    uint32_t h[4];
+    IBH_HIP(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+    IBH_HIP(hipStreamSynchronize(st));
+    if ((int)h[3] != big) {
+        int64_t s = 0;
+        IBH_HIP(hipMemcpy(&s, row_s + (int)h[3], sizeof(int64_t), hipMemcpyDeviceToHost));
+        fail(IBH_EINVAL, "Area of cell %ld must be non-zero", (long)s);
+    }
+    const size_t ns = h[0];
+    IBH_CHECK(ns < (1ul << 31), "smoothing matrix too large (%zu entries)", ns);
+    uint64_t *sk = A.get<uint64_t>(ns), *sk2 = A.get<uint64_t>(ns);
+    uint32_t *si = A.get<uint32_t>(ns), *si2 = A.get<uint32_t>(ns);
+    double *wraw = A.get<double>(ns);
+    hipLaunchKernelGGL(k_smooth_neighbours<1>, grid, dim3(T), 0, st, v, binstart, members, (uint32_t *)nullptr, ncnt, sk, si, wraw);
+    // order the triplets by (i, j): rows become contiguous with ascending columns
+    KeyField sf[2] = {{0, bits_for((uint64_t)n)}, {32, bits_for((uint64_t)n)}};
+    if (ns && sf[0].nbits > 0 && radix_sort_pairs(sk, sk2, si, si2, ns, sf, 2, st)) { std::swap(sk, sk2); std::swap(si, si2); }
+    int32_t *srowptr = A.get<int32_t>((size_t)n + 1);
+    hipLaunchKernelGGL(k_smooth_rowptr, grid, dim3(T), 0, st, ncnt, n, (uint32_t)ns, srowptr);
+    double *denom = A.get<double>((size_t)n);
+    seg_sums<true>(srowptr, si, wraw, n, (long)ns, denom, st);          // denom_sum, smoother.cpp:37,51
+    // smoothI * M as contributions in (i, j ascending) order
+    uint32_t *pcnt = A.get<uint32_t>(ns ? ns : 1);
+    if (ns) hipLaunchKernelGGL(k_smooth_prod_count, dim3(ceil_div(ns, T)), dim3(T), 0, st, sk, ns, w->rowptr.p, pcnt);
+    exclusive_scan_u32(pcnt, pcnt, ns, d_cnt + 1, st);
+    IBH_HIP(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+    IBH_HIP(hipStreamSynchronize(st));
+    Triplets t;
+    t.n = h[1];
+    IBH_CHECK(t.n < (1ul << 31), "smoothed matrix too large (%zu products)", t.n);
+    t.keys = A.get<uint64_t>(t.n); t.keys_alt = A.get<uint64_t>(t.n);
+    t.idx = A.get<uint32_t>(t.n); t.idx_alt = A.get<uint32_t>(t.n);
+    t.term = A.get<double>(t.n);
+    if (ns) hipLaunchKernelGGL(k_smooth_prod_emit, dim3(ceil_div(ns, T)), dim3(T), 0, st, sk, si, wraw, denom, ns, w->rowptr.p,
+                               w->colind.p, w->val.p, pcnt, t.keys, t.idx, t.term);
+    IBH_HIP(hipGetLastError());
+    // the products read w's CSR while the new one is being built: build into fresh buffers, then swap
+    ibh_weighted tmp;
+    int32_t *row = nullptr;
+    build_csr_from_contributions(&tmp, t, w->nrow, w->ncol, &row, st);
+    IBH_HIP(hipStreamSynchronize(st));
+    w->rowptr = std::move(tmp.rowptr); w->colind = std::move(tmp.colind); w->val = std::move(tmp.val);
+    w->nnz = tmp.nnz;
+    w->conservative = 0;            // conservative = !smooth, RegridMatrices_Dynamic.cpp:167
+}
+
 // ---- RegridMatrices_Dynamic::matrix_d ----------------------------------------------------------
 void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_sparse_set *dim0, ibh_sparse_set *dim1,
                      int scale, int correctA, const double sigma[3], ibh_weighted **out) {
     IBH_CHECK(rm && spec_name && out, "null argument");
-    if (sigma && sigma[0] != 0)      // RegridParams::smooth(), RegridMatrices.hpp:31
-        fail(IBH_ENOTIMPL, "smoothing (sigma != 0) is outside the hot-path scope of this build (SURVEY.md 8f)");
     const MatSpec *sp = nullptr;
     for (const auto &s : SPECS) if (!strcmp(s.name, spec_name)) sp = &s;
     if (!sp) fail(IBH_ENOKEY, "unknown regrid matrix '%s' (expected one of AvI IvA AvX XvA EvI IvE EvX XvE EvA AvE)", spec_name);
+    // RegridParams::smooth() (RegridMatrices.hpp:31): only compute_IvAE smooths (RegridMatrices_Dynamic.cpp:237-248)
+    const bool smooth = sigma && sigma[0] != 0 && sp->family == FAM_IVAE;
+    if (smooth && sp->row_key != KEY_I)
+        fail(IBH_ENOTIMPL, "smoothing of '%s' (rows on the exchange grid) is not supported: the smoother needs ice-grid centroids", spec_name);
     const ibh_regridder *g = rm->rg;
     const bool uses_ep = sp->row_list == LIST_EP || sp->col_list == LIST_EP;
     if (uses_ep && g->nhc == 0) fail(IBH_EINVAL, "IceRegridder_L0::GvEp(): hcdefs is zero-length!");   // IceRegridder_L0.cpp:108-109
@@ -715,6 +905,7 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
         hipLaunchKernelGGL(k_scale, dim3(ceil_div(nnz, T)), dim3(T), 0, st, row, w->colind.p, w->val.p, nnz, rowmul, colmul,
                            apply_row, apply_col);
     IBH_HIP(hipGetLastError());
+    if (smooth) smooth_matrix(w.get(), rm, rset.to_sparse, sigma, st);
     IBH_HIP(hipStreamSynchronize(st));
     compute_max_row(w.get(), st);
     *out = w.release();

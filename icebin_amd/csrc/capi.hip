@@ -227,6 +227,17 @@ int ibh_regridder_create(const ibh_regridder_desc *d, ibh_regridder **out) {
         g->ex_area.upload(d->ex_area, (size_t)d->nX);
         g->hcdefs.upload(d->hcdefs, (size_t)d->nhc);
         g->A_ratio_s.upload(ratio.data(), ratio.size());
+        if (d->I_centroid_xy) {
+            g->has_centroid = true;
+            for (int k = 0; k < 2; ++k) { g->cmin[k] = 1e300; g->cmax[k] = -1e300; }
+            for (int64_t i = 0; i < d->nI; ++i)
+                for (int k = 0; k < 2; ++k) {
+                    const double v = d->I_centroid_xy[2 * i + k];
+                    IBH_CHECK(std::isfinite(v), "ice cell %ld has a non-finite centroid", (long)i);
+                    g->cmin[k] = std::min(g->cmin[k], v); g->cmax[k] = std::max(g->cmax[k], v);
+                }
+            g->I_centroid.upload(d->I_centroid_xy, (size_t)(2 * d->nI));
+        }
         IBH_HIP(hipStreamSynchronize(nullptr));
         *out = g.release();
     });

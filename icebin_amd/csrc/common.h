@@ -148,6 +148,9 @@ struct ibh_regridder {
     std::vector<int64_t> A_to_sparse;   // host copies for wA()
     std::vector<double> A_native, A_proj, hcdefs_h;
     double hc_last = 0;
+    ibh::DevBuf<double> I_centroid;     // [2*nI] (x,y) by sparse ice index; empty when not supplied
+    bool has_centroid = false;
+    double cmin[2] = {0, 0}, cmax[2] = {0, 0};   // bounding box of the centroids
 };
 
 struct ibh_regrid_matrices {

@@ -275,7 +275,8 @@ public:
         the ice grid is given by its size, the exchange grid by value; gridA_proj_area (dense, like
         agridA.native_area) may be empty = no projection (IceRegridder.cpp:106-108). */
     size_t add_sheet(std::string const &name, long nI, ExchangeGrid const &aexgrid,
-                     std::vector<double> const &gridA_proj_area = {}, int interp_style = InterpStyle::Z_INTERP) {
+                     std::vector<double> const &gridA_proj_area = {}, int interp_style = InterpStyle::Z_INTERP,
+                     std::vector<double> const &gridI_centroid_xy = {} /* [2*nI], only for sigma != 0 */) {
         std::unique_ptr<IceRegridder> sheet(new IceRegridder);
         std::vector<int64_t> a2s(agridA_.dim_to_sparse.begin(), agridA_.dim_to_sparse.end());
         std::vector<double> const &proj = gridA_proj_area.empty() ? agridA_.native_area : gridA_proj_area;
@@ -286,6 +287,7 @@ public:
         d.A_to_sparse = a2s.data(); d.A_native_area = agridA_.native_area.data(); d.A_proj_area = proj.data();
         d.nhc = (int32_t)_hcdefs.size(); d.hcdefs = _hcdefs.data();
         d.hc_stride_A = hc_stride_A_; d.hc_stride_HC = hc_stride_HC_; d.interp_style = interp_style;
+        d.I_centroid_xy = gridI_centroid_xy.empty() ? nullptr : gridI_centroid_xy.data();
         check(ibh_regridder_create(&d, &sheet->h_));
         sheet->_name = name; sheet->_nI = nI; sheet->_nX = (long)d.nX; sheet->interp_style = interp_style;
         size_t ix = sheets_.size();

@@ -89,7 +89,8 @@ class GCMRegridder:
         return self._nA * len(self._hcdefs)      # GCMRegridder.hpp:273
 
     def add_sheet(self, name, gridI, exgrid, interp_style="Z_INTERP", gridA_proj_area=None):
-        """name: sheet name; gridI = dict(nI=); exgrid = dict(indices=int32[nX,2] (iA,iI), overlaps=f64[nX]);
+        """name: sheet name; gridI = dict(nI=[, centroid_xy=f64[nI,2] by sparse index, needed only for
+        sigma != 0]); exgrid = dict(indices=int32[nX,2] (iA,iI), overlaps=f64[nX]);
         gridA_proj_area: projected area of the realised A cells (IceRegridder::init computes it by
         projecting A's polygons, IceRegridder.cpp:109-118); None = no projection (== native, :106-108)."""
         if interp_style not in _INTERP:
@@ -97,12 +98,16 @@ class GCMRegridder:
         idx = np.ascontiguousarray(exgrid["indices"], np.int32).reshape(-1)
         area = np.ascontiguousarray(exgrid["overlaps"], np.float64)
         proj = self._A_native if gridA_proj_area is None else np.ascontiguousarray(gridA_proj_area, np.float64)
+        cen = gridI.get("centroid_xy")
+        cen = None if cen is None else np.ascontiguousarray(cen, np.float64).reshape(-1)
+        assert cen is None or len(cen) == 2 * int(gridI["nI"])
         d = _capi.RegridderDesc(
             nX=len(area), ex_indices=ptr(idx).value, ex_area=ptr(area).value, nI=int(gridI["nI"]),
             nA=self._nA, nA_dense=len(self._A_to_sparse), A_to_sparse=ptr(self._A_to_sparse).value,
             A_native_area=ptr(self._A_native).value, A_proj_area=ptr(proj).value,
             nhc=len(self._hcdefs), hcdefs=ptr(self._hcdefs).value,
-            hc_stride_A=self._hc_strides[0], hc_stride_HC=self._hc_strides[1], interp_style=_INTERP[interp_style])
+            hc_stride_A=self._hc_strides[0], hc_stride_HC=self._hc_strides[1], interp_style=_INTERP[interp_style],
+            I_centroid_xy=None if cen is None else ptr(cen).value)
         h = C.c_void_p()
         check(lib().ibh_regridder_create(C.byref(d), C.byref(h)))
         self._sheets[name] = _Sheet(h, int(gridI["nI"]), (idx, area, proj))
@@ -143,6 +148,6 @@ def from_synthetic(grids):
     g = grids
     mm = GCMRegridder(dict(nA=g["nA"], to_sparse=g["A_to_sparse"], native_area=g["A_native_area"]), g["hcdefs"], True)
     mm._hc_strides = (int(g["hc_stride_A"]), int(g["hc_stride_HC"]))
-    mm.add_sheet("greenland", dict(nI=g["nI"]), dict(indices=g["ex_indices"], overlaps=g["ex_area"]),
+    mm.add_sheet("greenland", dict(nI=g["nI"], centroid_xy=g.get("I_centroid_xy")), dict(indices=g["ex_indices"], overlaps=g["ex_area"]),
                  "Z_INTERP" if g.get("interp_style", 0) == 0 else "ELEV_CLASS_INTERP", g["A_proj_area"])
     return mm

@@ -99,6 +99,11 @@ def make_grids(config="g5", nhc=40, x_fastest=False, ratio_amp=0.03, order="sort
     ratio = 1.0 + ratio_amp * np.cos(np.pi * (KY.ravel() + 0.5) / nAy)      # in [1-amp, 1+amp]
     native_area = proj_area * ratio
     hcdefs = np.arange(nhc, dtype=np.float64) * 100.0 - 50.0   # write_icebin_in_base.py:44
+    # centroids of the ice cells by sparse index (AbbrGrid::centroid_xy; read only by the smoother)
+    CX, CY = np.meshgrid((np.arange(nx) + 0.5) * d, (np.arange(ny) + 0.5) * d, indexing="ij")
+    if x_fastest:
+        CX, CY = CX.T, CY.T
+    centroid = np.stack([CX.ravel(), CY.ravel()], axis=1)
 
     return dict(
         config=config, nx=int(nx), ny=int(ny), dx=d, x_fastest=x_fastest,
@@ -106,7 +111,7 @@ def make_grids(config="g5", nhc=40, x_fastest=False, ratio_amp=0.03, order="sort
         ex_indices=np.stack([iA, iI], axis=1).astype(np.int32), ex_area=area,
         A_to_sparse=A_to_sparse, A_native_area=native_area, A_proj_area=proj_area,
         hcdefs=hcdefs, hc_stride_A=1, hc_stride_HC=int(im * jm),   # icebin_cython.cpp:69
-        interp_style=0,
+        interp_style=0, I_centroid_xy=centroid,
     )
 
 

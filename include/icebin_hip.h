@@ -41,7 +41,7 @@ extern "C" {
 #define IBH_EHIP       -3   /* a HIP runtime call failed                               */
 #define IBH_ERANGE     -4   /* elevation above the last height class                   */
                             /*   (IceRegridder_L0.cpp:84-85)                           */
-#define IBH_ENOTIMPL   -5   /* feature outside the hot-path scope (sigma != 0)         */
+#define IBH_ENOTIMPL   -5   /* feature outside the hot-path scope                      */
 #define IBH_ENOKEY     -6   /* unknown matrix name (regrids.at(), RegridMatrices_Dynamic.cpp:419) */
 
 const char *ibh_last_error(void);
@@ -88,6 +88,9 @@ typedef struct ibh_regridder_desc {
     int64_t        hc_stride_A;   /* indexingHC.tuple_to_index: iE = iA*stride_A + ihc*stride_HC */
     int64_t        hc_stride_HC;  /*   (icebin_cython.cpp:69 -> 1 and nA)            */
     int32_t        interp_style;  /* 0 Z_INTERP, 1 ELEV_CLASS_INTERP (IceRegridder.hpp:36-39) */
+    /* agridI.centroid_xy (AbbrGrid.hpp:108-109) by SPARSE ice index, [2*nI] (x, y); only the smoother
+     * (sigma != 0, smoother.cpp:69-99) reads it; may be NULL */
+    const double  *I_centroid_xy;
 } ibh_regridder_desc;
 
 typedef struct ibh_regridder ibh_regridder;

@@ -543,6 +543,9 @@ static csc *make_diag(const urae *u, const orc_regridder *rg, orc_sset *dim) {
     return m;
 }
 
+static csc *smoothing_matrix(const orc_regridder *rg, const orc_sset *dimI, const double *em,
+                             const double *area_d, const double sigma[3], errctx *e);
+
 /* compute_AEvI, RegridMatrices_Dynamic.cpp:50-151 -- AvI, EvI, AvX, EvX */
 static orc_weighted *compute_AEvI(const orc_regridder *rg, orc_sset *dims[2], int scale,
                                   int correctA, const double *em, char Igrid,
@@ -617,10 +620,11 @@ static orc_weighted *compute_AEvI(const orc_regridder *rg, orc_sset *dims[2], in
 
 /* compute_IvAE, RegridMatrices_Dynamic.cpp:154-252 -- IvA, IvE, XvA, XvE */
 static orc_weighted *compute_IvAE(const orc_regridder *rg, orc_sset *dims[2], int scale,
-                                  int correctA, const double *em, char Igrid,
+                                  int correctA, const double *sigma, const double *em, char Igrid,
                                   const urae *AE, errctx *e)
 {
-    orc_weighted *ret = weighted_new(dims[0], dims[1], 1);  /* conservative = !smooth, :167 */
+    const int smooth = sigma && sigma[0] != 0;              /* RegridParams::smooth(), RegridMatrices.hpp:31 */
+    orc_weighted *ret = weighted_new(dims[0], dims[1], !smooth);  /* conservative = !smooth, :167 */
     orc_sset *dimA = ret->dims[1], *dimI = ret->dims[0];              /* :168 */
     orc_sset *dimG = orc_sset_new(-1);
     orc_sset_set_sparse_extent(dimA, AE->nfull);
@@ -678,7 +682,72 @@ static orc_weighted *compute_IvAE(const orc_regridder *rg, orc_sset *dims[2], in
             ret->M = IvAp;                                            /* :232 */
         }
     }
+    if (smooth) {                                                     /* :237-248 */
+        csc *smoothI = smoothing_matrix(rg, dimI, em, ret->wM, sigma, e);
+        if (!smoothI) { orc_weighted_free(ret); return NULL; }
+        csc *Ms = spgemm(smoothI, ret->M);                            /* smoothI * M */
+        csc_free(smoothI); csc_free(ret->M);
+        ret->M = Ms;
+    }
     return ret;
+}
+
+/* smoothing_matrix + Smoother::matrix, smoother.cpp:43-99 (hook RegridMatrices_Dynamic.cpp:237-248).
+ * Tuples: the ice cells of agridI (all cells of the rectilinear sheet, ascending sparse index) that are
+ * in dimI and unmasked, with centroid (x, y, elevation) and area = wM[dense id].  Row of cell t0:
+ * every tuple t with sum_k ((t.c[k]-t0.c[k])/sigma[k])^2 < nsigma^2 = 4 gets w = exp(-.5*d2) * t.area,
+ * the row is scaled by 1/sum(w).  The reference finds the neighbours with an RTree (ibmisc, absent) and
+ * sums the denominator in the RTree's visiting order; here neighbours are visited in ascending tuple
+ * order [PARITY UNPINNED at rounding level].  Brute-force search: the oracle is for test sizes. */
+static csc *smoothing_matrix(const orc_regridder *rg, const orc_sset *dimI, const double *em,
+                             const double *area_d, const double sigma[3], errctx *e)
+{
+    int nd = orc_sset_dense_extent(dimI);
+    int nt = 0;
+    int *tid = (int *)xmalloc(sizeof(int) * (size_t)(nd ? nd : 1));
+    double *cx = (double *)xmalloc(sizeof(double) * 3 * (size_t)(nd ? nd : 1));
+    if (!rg->I_centroid_xy) { set_err(e, "smoothing needs the ice grid's centroid_xy"); free(tid); free(cx); return NULL; }
+    for (long iXs = 0; iXs < rg->nI; ++iXs) {               /* agridX.dim: dense == sparse for the sheet grid */
+        int d = orc_sset_to_dense(dimI, iXs);
+        if (d < 0) continue;
+        double elev = em[iXs];
+        if (isnan(elev)) continue;
+        if (area_d[d] == 0.) { set_err(e, "Area of cell %ld must be non-zero\n", iXs); free(tid); free(cx); return NULL; }
+        tid[nt] = d;
+        cx[3 * nt] = rg->I_centroid_xy[2 * iXs]; cx[3 * nt + 1] = rg->I_centroid_xy[2 * iXs + 1]; cx[3 * nt + 2] = elev;
+        nt++;
+    }
+    dtrip t; t.n = 0;
+    long cap = 1024;
+    t.r = (int *)xmalloc(sizeof(int) * (size_t)cap); t.c = (int *)xmalloc(sizeof(int) * (size_t)cap);
+    t.v = (double *)xmalloc(sizeof(double) * (size_t)cap);
+    const double nsigma_squared = 2. * 2.;
+    for (int i = 0; i < nt; ++i) {
+        long start = t.n;
+        double denom_sum = 0;
+        for (int j = 0; j < nt; ++j) {
+            double nds = 0;
+            for (int k = 0; k < 3; ++k) {
+                double d = (cx[3 * j + k] - cx[3 * i + k]) / sigma[k];
+                nds = nds + d * d;
+            }
+            if (nds < nsigma_squared) {
+                double w = exp(-.5 * nds) * area_d[tid[j]];
+                if (t.n == cap) {
+                    cap *= 2;
+                    t.r = (int *)xrealloc(t.r, sizeof(int) * (size_t)cap); t.c = (int *)xrealloc(t.c, sizeof(int) * (size_t)cap);
+                    t.v = (double *)xrealloc(t.v, sizeof(double) * (size_t)cap);
+                }
+                t.r[t.n] = tid[i]; t.c[t.n] = tid[j]; t.v[t.n] = w; t.n++;
+                denom_sum = denom_sum + w;
+            }
+        }
+        double factor = 1. / denom_sum;
+        for (long q = start; q < t.n; ++q) t.v[q] = factor * t.v[q];
+    }
+    csc *m = to_eigen(&t, nd, nd);
+    dtrip_free(&t); free(tid); free(cx);
+    return m;
 }
 
 /* compute_EvA, RegridMatrices_Dynamic.cpp:254-332 -- EvA, and AvE with the
@@ -752,22 +821,18 @@ int orc_matrix_d(const orc_regridder *rg, const double *elevmaskI,
 {
     errctx e = { err, errlen, 0 };
     *out = NULL;
-    if (sigma && sigma[0] != 0) {   /* RegridParams::smooth(), RegridMatrices.hpp:31 */
-        set_err(&e, "oracle: smoothing (sigma != 0) is out of scope (SURVEY.md 8f rank 3)");
-        return -1;
-    }
     urae urA = { 'A', rg->nA };                                       /* :354-356 */
     urae urE = { 'E', rg->nA * (long)rg->nhc };                       /* :358-360; nE = nA*nhc, GCMRegridder.hpp:273 */
     orc_sset *dims[2] = { dim0, dim1 };
     orc_weighted *w = NULL;
     if      (!strcmp(spec, "AvI")) w = compute_AEvI(rg, dims, scale, correctA, elevmaskI, 'I', &urA, &e);
-    else if (!strcmp(spec, "IvA")) w = compute_IvAE(rg, dims, scale, correctA, elevmaskI, 'I', &urA, &e);
+    else if (!strcmp(spec, "IvA")) w = compute_IvAE(rg, dims, scale, correctA, sigma, elevmaskI, 'I', &urA, &e);
     else if (!strcmp(spec, "AvX")) w = compute_AEvI(rg, dims, scale, correctA, elevmaskI, 'X', &urA, &e);
-    else if (!strcmp(spec, "XvA")) w = compute_IvAE(rg, dims, scale, correctA, elevmaskI, 'X', &urA, &e);
+    else if (!strcmp(spec, "XvA")) w = compute_IvAE(rg, dims, scale, correctA, sigma, elevmaskI, 'X', &urA, &e);
     else if (!strcmp(spec, "EvI")) w = compute_AEvI(rg, dims, scale, correctA, elevmaskI, 'I', &urE, &e);
-    else if (!strcmp(spec, "IvE")) w = compute_IvAE(rg, dims, scale, correctA, elevmaskI, 'I', &urE, &e);
+    else if (!strcmp(spec, "IvE")) w = compute_IvAE(rg, dims, scale, correctA, sigma, elevmaskI, 'I', &urE, &e);
     else if (!strcmp(spec, "EvX")) w = compute_AEvI(rg, dims, scale, correctA, elevmaskI, 'X', &urE, &e);
-    else if (!strcmp(spec, "XvE")) w = compute_IvAE(rg, dims, scale, correctA, elevmaskI, 'X', &urE, &e);
+    else if (!strcmp(spec, "XvE")) w = compute_IvAE(rg, dims, scale, correctA, sigma, elevmaskI, 'X', &urE, &e);
     else if (!strcmp(spec, "EvA")) w = compute_EvA(rg, dims, scale, correctA, elevmaskI, &urE, &urA, &e);
     else if (!strcmp(spec, "AvE")) w = compute_EvA(rg, dims, scale, correctA, elevmaskI, &urA, &urE, &e);
     else { set_err(&e, "unknown regrid matrix '%s'", spec); return -1; }  /* regrids.at() throws, :419 */

@@ -58,6 +58,9 @@ typedef struct orc_regridder {
     long          hc_stride_A;  /* indexingHC: iE = iA*hc_stride_A + ihc*hc_stride_HC */
     long          hc_stride_HC;
     int           interp_style; /* ORC_Z_INTERP | ORC_ELEV_CLASS_INTERP */
+    /* agridI.centroid_xy (AbbrGrid.hpp:108-109) by SPARSE ice index, [2*nI] (x,y); may be NULL when
+     * no smoothing is requested (only smoother.cpp reads it) */
+    const double *I_centroid_xy;
 } orc_regridder;
 
 /* ---- ibmisc::linear::Weighted_Eigen (shape visible at RegridMatrices_Dynamic.cpp:63-65,100,115,123) */

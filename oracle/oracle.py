@@ -34,6 +34,7 @@ class _Regridder(C.Structure):
         ("nhc", C.c_int), ("hcdefs", C.c_void_p),
         ("hc_stride_A", C.c_long), ("hc_stride_HC", C.c_long),
         ("interp_style", C.c_int),
+        ("I_centroid_xy", C.c_void_p),
     ]
 
 
@@ -215,6 +216,8 @@ class Regridder:
             A_proj_area=np.ascontiguousarray(g["A_proj_area"], np.float64),
             hcdefs=np.ascontiguousarray(g["hcdefs"], np.float64),
         )
+        if g.get("I_centroid_xy") is not None:
+            self._arrs["I_centroid_xy"] = np.ascontiguousarray(g["I_centroid_xy"], np.float64).reshape(-1)
         a = self._arrs
         self.nI, self.nA, self.nhc = int(g["nI"]), int(g["nA"]), len(a["hcdefs"])
         self.c = _Regridder(
@@ -223,7 +226,8 @@ class Regridder:
             A_to_sparse=_p(a["A_to_sparse"]).value, A_native_area=_p(a["A_native_area"]).value,
             A_proj_area=_p(a["A_proj_area"]).value, nhc=self.nhc, hcdefs=_p(a["hcdefs"]).value,
             hc_stride_A=int(g.get("hc_stride_A", 1)), hc_stride_HC=int(g.get("hc_stride_HC", g["nA"])),
-            interp_style=int(g.get("interp_style", 0)))
+            interp_style=int(g.get("interp_style", 0)),
+            I_centroid_xy=_p(a["I_centroid_xy"]).value if "I_centroid_xy" in a else None)
 
     def matrix_d(self, spec, elevmaskI, dims=(None, None), scale=True, correctA=False, sigma=(0., 0., 0.)):
         em = np.ascontiguousarray(elevmaskI, np.float64).reshape(-1)

@@ -123,8 +123,10 @@ def test_errors_mirror_reference():
         rg.matrix_d("EvI", hi)
     assert rmh.matrix("AvI").nnz > 0                      # matrices that never call GvEp are unaffected
     with pytest.raises(icebin_amd.IcebinHipError) as ei:
-        mm.regrid_matrices("greenland", em, sigma=(50e3, 50e3, 100.)).matrix("IvA")
+        mm.regrid_matrices("greenland", em, sigma=(50e3, 50e3, 100.)).matrix("XvA")    # smoothing needs ice-grid rows
     assert ei.value.code == -5
+    with pytest.raises(icebin_amd.IcebinHipError, match="three positive sigmas"):
+        mm.regrid_matrices("greenland", em, sigma=(50e3, 0., 0.)).matrix("IvA")
 
 
 @pytest.mark.parametrize("nvar", [1, 2, 3, 5, 8, 16, 17, 64])
@@ -446,3 +448,37 @@ def test_unsorted_prepopulated_and_reused_matrices_object():
                              rg.matrix_d(name, em, scale=scale, correctA=correctA), "%s %d %d" % (name, scale, correctA))
     # RegridMatrices.matrix() uses the params given to regrid_matrices (RegridMatrices_Dynamic.cpp:433)
     assert_same_weighted(rm.matrix("IvA"), rg.matrix_d("IvA", em, scale=False, correctA=False), "matrix() params")
+
+
+@pytest.mark.parametrize("name", ["IvA", "IvE"])
+def test_smoothing_sigma_nonzero(name):
+    # RegridMatrices_Dynamic.cpp:237-248 + smoother.cpp: M <- smoothI * M, conservative = false, and the
+    # conservation correction of apply().  Structure is exact; entries agree to rounding (device exp()
+    # and the neighbour order of the absent RTree are not bit-reproducible: parity unpinned at 1e-13).
+    g, em, mm, rg = setup("g20")
+    sigma = (60e3, 60e3, 250.0)
+    for scale, correctA in ((True, True), (False, False)):
+        w = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA, sigma=sigma).matrix(name)
+        o = rg.matrix_d(name, em, scale=scale, correctA=correctA, sigma=sigma)
+        plain = rg.matrix_d(name, em, scale=scale, correctA=correctA)
+        assert not w.conservative and not o.conservative and w.scaled == scale
+        assert (w.nrow_d, w.ncol_d, w.nnz) == (o.nrow, o.ncol, o.nnz) and o.nnz > 3 * plain.nnz
+        np.testing.assert_array_equal(w.dim(0), o.dims[0])
+        np.testing.assert_array_equal(w.dim(1), o.dims[1])
+        row, col, val = w.coo_dense()
+        np.testing.assert_array_equal(row, o.row)
+        np.testing.assert_array_equal(col, o.col)
+        np.testing.assert_allclose(val, o.val, rtol=1e-12, atol=0)
+        np.testing.assert_array_equal(w.wM.view(np.uint64), plain.wM.view(np.uint64))     # weights are those of the unsmoothed matrix
+        np.testing.assert_array_equal(w.Mw.view(np.uint64), plain.Mw.view(np.uint64))
+        x = syn.fields(3, w.ncol_d) + 2.0
+        for fc in (False, True):
+            y, ref = w.apply(x, force_conservation=fc), o.apply(x, force_conservation=fc)
+            assert rel_linf(y, ref) <= FIELD_RTOL
+        y = w.apply(x, force_conservation=True)          # the correction restores sum(wM*y) == sum(Mw*x)
+        for k in range(3):
+            assert _conservation(w, x[k], y[k]) < 1e-13
+    # matrices whose build never smooths ignore sigma (compute_AEvI, compute_EvA)
+    a = mm.regrid_matrices("greenland", em, sigma=sigma).matrix("AvI")
+    assert a.conservative
+    assert_same_weighted(a, rg.matrix_d("AvI", em, scale=True, correctA=True), "AvI with sigma")
