@@ -34,6 +34,11 @@ def spmm_bytes(nnz, nrow, ncol, nf):
     return 12 * nnz + 4 * (nrow + 1) + 8 * nf * ncol + 8 * nf * nrow
 
 
+def asm_bytes(nX, nI, nnz, nrow, ncol):
+    """Algorithmic bytes of one matrix assembly."""
+    return 16 * nX + 8 * nI + 12 * nnz + 4 * (nrow + 1) + 8 * (nrow + ncol)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,7 +160,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, W.last_kernel()),
                          "kernel_us": kernel_ms * 1e3, "algorithmic_bytes": B},
-            "assembly_ms": {"first_call": t_asm_first * 1e3, "steady": t_asm * 1e3},
+            "assembly": {"first_call_ms": t_asm_first * 1e3, "steady_ms": t_asm * 1e3,
+                         "algorithmic_bytes": asm_bytes(len(grids["ex_area"]), grids["nI"], nnz, nrow, ncol),
+                         "GBps": asm_bytes(len(grids["ex_area"]), grids["nI"], nnz, nrow, ncol) / t_asm / 1e9},
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(grids, em, args, x_host, n_unmasked)

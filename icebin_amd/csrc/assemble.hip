@@ -581,10 +581,6 @@ static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, 
     *row_out = row;
 }
 
-static void compute_max_row(ibh_weighted *w, hipStream_t st) {
-    (void)st; w->max_row_nnz = 0;   // dispatch uses the mean row length only
-}
-
 // ---- smoothing (sigma != 0): M <- smoothI * M  (smoother.cpp:8-99, RegridMatrices_Dynamic.cpp:237-248) ------
 // smoothI[i,j] = exp(-.5 d2(i,j)) * area_j / sum_j(...) over the unmasked ice cells j of dimI with
 // d2 = sum_k ((c_j[k]-c_i[k])/sigma[k])^2 < 4, c = (x, y, elevation), area = wM.  The reference finds
@@ -907,7 +903,6 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     IBH_HIP(hipGetLastError());
     if (smooth) smooth_matrix(w.get(), rm, rset.to_sparse, sigma, st);
     IBH_HIP(hipStreamSynchronize(st));
-    compute_max_row(w.get(), st);
     *out = w.release();
 }
 

@@ -104,11 +104,6 @@ static void make_identity(ibh_sparse_set *s, int64_t n) {
     s->identity = true;
 }
 
-__global__ void k_max_row(const int32_t *rowptr, int nrow, int *out) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < nrow) atomicMax(out, rowptr[r + 1] - rowptr[r]);
-}
-
 }  // namespace ibh
 
 using namespace ibh;

@@ -175,7 +175,6 @@ struct ibh_weighted {
     // apply_transformed: scratch fields + small transform, and M*1 (row sums) for the offset term
     mutable ibh::DevBuf<double> scratch, tbuf, rowsum1;
     mutable bool have_rowsum1 = false;
-    int32_t max_row_nnz = 0;
     ~ibh_weighted() {
         for (int k = 0; k < 2; ++k)
             if (owns[k]) delete dims[k];
