@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--fields", type=int, default=64, help="fields per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steps-per-gather", type=int, default=16, help="N>1: applies per RCCL all-gather")
+    ap.add_argument("--all-unmasked", action="store_true", help="every ice cell carries ice (peak-size variant, SURVEY.md 8d)")
     ap.add_argument("--warm", action="store_true", help="reuse ONE field batch (Infinity-Cache-resident numbers)")
     args = ap.parse_args()
 
@@ -73,7 +74,7 @@ def main():
 
     # ---- the workload: assemble the matrix on this GPU (replicated on every rank) -----------------
     grids = syn.make_grids(args.config)
-    em = syn.dome_elevmask(grids)
+    em = syn.dome_elevmask(grids, all_unmasked=args.all_unmasked)
     mm = icebin_amd.from_synthetic(grids)
     t0 = time.perf_counter()
     rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
@@ -154,6 +155,7 @@ def main():
             "config": {"workload": "searise 5 km Greenland -> ModelE 2x2.5 %s, %d fields" % (args.matrix, nf)
                        if args.config == "g5" else "%s %s %d fields" % (args.config, args.matrix, nf),
                        "nI": grids["nI"], "nX": int(len(grids["ex_area"])), "unmasked_cells": n_unmasked,
+                       "mask": "all cells unmasked" if args.all_unmasked else "dome, ~45 % unmasked",
                        "nrow_d": nrow, "ncol_d": ncol, "nnz": nnz, "fields_per_gpu": nf, "field_batches": nbuf,
                        "cache": "warm" if args.warm else "cold (rotating batches > Infinity Cache)",
                        "kernel": W.last_kernel(), "parallelism": ("field-shard x%d + all-gather every %d steps" % (world, args.steps_per_gather)) if use_dist else "1 GPU"},
@@ -166,6 +168,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(grids, em, args, x_host, n_unmasked)
+        if not use_dist and not args.all_unmasked and not args.warm and args.config == "g5":
+            # the same launch on the peak-size variant of the same grids (every ice cell unmasked:
+            # X has all nI = 168 861 columns, the size BASELINE.md's byte table assumes); informational
+            result["variants"] = {"all_unmasked": variant_all_unmasked(torch, icebin_amd, _capi, syn, grids, args, dev)}
         if use_dist:
             y = sharded.result(0, 0).cpu().numpy()
         else:
@@ -177,12 +183,39 @@ def main():
         dist.destroy_process_group()
 
 
+def variant_all_unmasked(torch, icebin_amd, _capi, syn, grids, args, dev, steps=500):
+    em = syn.dome_elevmask(grids, all_unmasked=True)
+    W = icebin_amd.from_synthetic(grids).regrid_matrices("greenland", em, scale=True, correctA=True).matrix(args.matrix)
+    nf, nrow, ncol, nnz = args.fields, W.nrow_d, W.ncol_d, W.nnz
+    nbuf = max(2, -(-(512 << 20) // (8 * nf * ncol)))
+    x0 = torch.from_numpy(syn.fields(nf, ncol)).to(dev)
+    X = [x0 + 1e-3 * b for b in range(nbuf)]
+    Y = torch.empty((nf, nrow), dtype=torch.float64, device=dev)
+    fn = _capi.lib().ibh_weighted_apply_device
+    st = torch.cuda.current_stream(dev)
+    cs, yp = C.c_void_p(st.cuda_stream), C.c_void_p(Y.data_ptr())
+    xp = [C.c_void_p(x.data_ptr()) for x in X]
+    for i in range(50):
+        fn(W._h, xp[i % nbuf], nf, ncol, yp, nrow, float("nan"), 0, cs)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for i in range(steps):
+        fn(W._h, xp[i % nbuf], nf, ncol, yp, nrow, float("nan"), 0, cs)
+    e1.record(st)
+    torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) / steps * 1e3
+    B = spmm_bytes(nnz, nrow, ncol, nf)
+    return {"nrow_d": nrow, "ncol_d": ncol, "nnz": nnz, "algorithmic_bytes": B, "kernel_us": us,
+            "achieved_GBps": B / us / 1e3, "frac": B / us / 1e3 / HBM_PEAK_GBS, "cells_per_s": ncol * nf / us * 1e6}
+
+
 def pmc_traffic(args, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this very command,
     FETCH doubled per the gfx950 correction).  None when no profile matches this workload."""
     import glob
-    key = "spmm_%s_%s_%s_%df" % (kernel, args.config, args.matrix, args.fields)
+    key = "spmm_%s_%s_%s_%df%s" % (kernel, args.config, args.matrix, args.fields, "_allunmasked" if args.all_unmasked else "")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
