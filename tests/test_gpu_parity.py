@@ -482,3 +482,31 @@ def test_smoothing_sigma_nonzero(name):
     a = mm.regrid_matrices("greenland", em, sigma=sigma).matrix("AvI")
     assert a.conservative
     assert_same_weighted(a, rg.matrix_d("AvI", em, scale=True, correctA=True), "AvI with sigma")
+
+
+def test_apply_is_graph_capturable():
+    # the device-resident apply only enqueues kernels (no allocation, no sync): it can be captured in a
+    # hipGraph together with the caller's own work and replayed
+    import torch
+    g, em, mm, rg = setup("g20")
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=False)
+    AvI, IvA = rm.matrix("AvI"), rm.matrix("IvA")
+    oA, oI = rg.matrix_d("AvI", em), rg.matrix_d("IvA", em)
+    x = torch.from_numpy(syn.fields(8, AvI.ncol_d)).cuda()
+    y = torch.empty((8, AvI.nrow_d), dtype=torch.float64, device="cuda")
+    z = torch.empty((8, IvA.nrow_d), dtype=torch.float64, device="cuda")
+    AvI.apply_device(x, out=y, force_conservation=False); IvA.apply_device(y, out=z, force_conservation=False)   # warm-up outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        AvI.apply_device(x, out=y, force_conservation=False)      # I -> A
+        IvA.apply_device(y, out=z, force_conservation=False)      # A -> I
+    for rep in range(3):
+        x.copy_(torch.from_numpy(syn.fields(8, AvI.ncol_d, seed=50 + rep)).cuda())
+        y.zero_(); z.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        xr = x.cpu().numpy()
+        yr = oA.apply(xr)
+        assert rel_linf(y.cpu().numpy(), yr) <= FIELD_RTOL
+        assert rel_linf(z.cpu().numpy(), oI.apply(yr)) <= 10 * FIELD_RTOL
