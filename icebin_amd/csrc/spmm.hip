@@ -158,26 +158,36 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     const int beg = rowptr[r], end = rowptr[r + 1];
     if (DIAG && threadIdx.x == 0) { diag[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(end - beg); }
     IBH_STAMP(1);
+    // The row is walked in segments of RB_SEG entries staged in LDS.  The loads of segment s+1 are
+    // issued before segment s is processed (they fly while X streams) and written to LDS after it.
+    int cc[RB_STAGE];
+    double vv[RB_STAGE];
+    auto stage_load = [&](int seg, int n) {       // all loads first (clamped, unconditional)
+#pragma unroll
+        for (int i = 0; i < RB_STAGE; ++i) {
+            const int k = min((int)threadIdx.x + i * RB_THREADS, n - 1);
+            cc[i] = colind[seg + k];
+            vv[i] = vals[seg + k];
+        }
+    };
+    auto stage_store = [&](int n) {
+#pragma unroll
+        for (int i = 0; i < RB_STAGE; ++i) {
+            const int k = threadIdx.x + i * RB_THREADS;
+            if (k < n) { s_col[k] = cc[i]; s_val[k] = vv[i]; }
+        }
+    };
+    if (beg < end) {
+        stage_load(beg, min(RB_SEG, end - beg));
+        stage_store(min(RB_SEG, end - beg));
+        __syncthreads();
+    }
+    IBH_STAMP(2);
     for (int seg = beg; seg < end; seg += RB_SEG) {
         const int n = min(RB_SEG, end - seg);
-        if (seg != beg) __syncthreads();
-        {   // stage the row segment: all loads first (clamped, unconditional), then the LDS writes
-            int cc[RB_STAGE];
-            double vv[RB_STAGE];
-#pragma unroll
-            for (int i = 0; i < RB_STAGE; ++i) {
-                const int k = min((int)threadIdx.x + i * RB_THREADS, n - 1);
-                cc[i] = colind[seg + k];
-                vv[i] = vals[seg + k];
-            }
-#pragma unroll
-            for (int i = 0; i < RB_STAGE; ++i) {
-                const int k = threadIdx.x + i * RB_THREADS;
-                if (k < n) { s_col[k] = cc[i]; s_val[k] = vv[i]; }
-            }
-        }
-        __syncthreads();
-        IBH_STAMP(2);
+        const int nxt = seg + RB_SEG;
+        const bool more = nxt < end;
+        if (more) stage_load(nxt, min(RB_SEG, end - nxt));
         // Full batches: every lane issues UNROLL*FPW loads before the first FMA, no predication.
         const int nfull = n - n % BATCH;
         int kb = 0;
@@ -224,6 +234,11 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
             for (int j = 0; j < FPW; ++j)
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) acc[j] = ok[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
+        }
+        if (more) {
+            __syncthreads();                      // every wave is done reading this segment
+            stage_store(min(RB_SEG, end - nxt));
+            __syncthreads();
         }
     }
     if (DIAG) { double t = 0; for (int j = 0; j < FPW; ++j) t += acc[j]; if (t == 1.2345e301) diag[1 << 20] = 1; }   // consume the loads before stamping
