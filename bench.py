@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--fields", type=int, default=64, help="fields per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steps-per-gather", type=int, default=16, help="N>1: applies per RCCL all-gather")
+    ap.add_argument("--variants", action="store_true", help="also time the peak-size (all-unmasked) variant; informational")
     ap.add_argument("--all-unmasked", action="store_true", help="every ice cell carries ice (peak-size variant, SURVEY.md 8d)")
     ap.add_argument("--warm", action="store_true", help="reuse ONE field batch (Infinity-Cache-resident numbers)")
     args = ap.parse_args()
@@ -168,7 +169,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(grids, em, args, x_host, n_unmasked)
-        if not use_dist and not args.all_unmasked and not args.warm and args.config == "g5":
+        if args.variants and not use_dist and not args.all_unmasked and not args.warm and args.config == "g5":
             # the same launch on the peak-size variant of the same grids (every ice cell unmasked:
             # X has all nI = 168 861 columns, the size BASELINE.md's byte table assumes); informational
             result["variants"] = {"all_unmasked": variant_all_unmasked(torch, icebin_amd, _capi, syn, grids, args, dev)}
