@@ -72,6 +72,7 @@ def main():
     from icebin_amd import _capi
     from icebin_amd import synthetic as syn
     from icebin_amd.distributed import FieldShardedApply
+    _capi.check(_capi.lib().ibh_set_device(local_rank))     # handles bind to the device current at creation
 
     # ---- the workload: assemble the matrix on this GPU (replicated on every rank) -----------------
     grids = syn.make_grids(args.config)

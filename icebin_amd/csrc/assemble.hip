@@ -556,10 +556,8 @@ static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, 
         *row_out = nullptr;
         return;
     }
-    KeyField fields[2] = {{0, bits_for((uint64_t)ncol)}, {32, bits_for((uint64_t)nrow)}};
-    KeyField nz[2]; int nf = 0;
-    for (auto &f : fields) if (f.nbits > 0) nz[nf++] = f;
-    if (radix_sort_pairs(t.keys, t.keys_alt, t.idx, t.idx_alt, t.n, nz, nf, st)) {
+    if (adaptive_sort_pairs(t.keys, t.keys_alt, t.idx, t.idx_alt, t.n, bits_for((uint64_t)ncol), bits_for((uint64_t)nrow),
+                            A.get<OrderInfo>(1), st)) {
         std::swap(t.keys, t.keys_alt); std::swap(t.idx, t.idx_alt);
     }
     uint32_t *head = A.get<uint32_t>(t.n);

@@ -7,6 +7,8 @@
 // HBM-bound: a scan moves 12 B/element, a sort pass 2 x 12 B/element + a
 // histogram read.  Everything is deterministic (no float atomics, stable sort).
 #include "prims.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace ibh {
 
@@ -243,6 +245,349 @@ bool radix_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32
         }
     }
     return in_alt;
+}
+
+
+// ---- adaptive ordering ------------------------------------------------------------------------
+// A sorted exchange grid (ExchangeGrid's constructor sorts the cells, AbbrGrid.cpp:10-21) emits
+// contributions that are already ALMOST in (row, col) order: the first-seen dense numbering is
+// monotone along the emission order except where an ice cell straddles two atmosphere cells.  A
+// full radix sort moves every element ~10 times to fix that.  Instead:
+//   1. one analysis pass finds every position k with max(keys[0,k)) <= min(keys[k,n)) ("cuts"):
+//      the pieces between cuts can be sorted independently;
+//   2. pieces of <= 8192 elements are sorted in LDS (a stable LSD radix sort of the piece: the same order the device-wide
+//      radix sort would give);
+//   3. if a piece is larger, nothing is touched and the caller falls back to the radix sort,
+//      skipping the low field when it is already non-decreasing along the sequence.
+// Everything is integer work; the result is identical to radix_sort_pairs by construction.
+constexpr int OA_T = 256, OA_I = 8, OA_TILE = OA_T * OA_I;
+constexpr int CS_SMALL = 2048, CS_BIG = 8192;
+
+__device__ __forceinline__ uint64_t u64max(uint64_t a, uint64_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint64_t u64min(uint64_t a, uint64_t b) { return a < b ? a : b; }
+
+__global__ __launch_bounds__(OA_T) void oa_tiles(const uint64_t *__restrict__ keys, size_t n,
+                                                 uint64_t *__restrict__ tmin, uint64_t *__restrict__ tmax,
+                                                 uint32_t *__restrict__ tflags) {
+    __shared__ uint64_t s_mn[OA_T / 64], s_mx[OA_T / 64];
+    __shared__ uint32_t s_fl[OA_T / 64];
+    const size_t base = (size_t)blockIdx.x * OA_TILE;
+    uint64_t mn = ~0ull, mx = 0;
+    uint32_t fl = 0;
+#pragma unroll
+    for (int i = 0; i < OA_I; ++i) {
+        const size_t idx = base + (size_t)i * OA_T + threadIdx.x;
+        if (idx < n) {
+            const uint64_t k = keys[idx];
+            mn = u64min(mn, k); mx = u64max(mx, k);
+            if (idx > 0) {
+                const uint64_t p = keys[idx - 1];
+                if (k < p) fl |= ORD_FULL_DEC;
+                if ((k >> 32) < (p >> 32)) fl |= ORD_HI_DEC;
+                if ((uint32_t)k < (uint32_t)p) fl |= ORD_LO_DEC;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = u64min(mn, __shfl_xor(mn, off, 64));
+        mx = u64max(mx, __shfl_xor(mx, off, 64));
+        fl |= __shfl_xor(fl, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; s_fl[wave] = fl; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < OA_T / 64; ++w) { mn = u64min(mn, s_mn[w]); mx = u64max(mx, s_mx[w]); fl |= s_fl[w]; }
+        tmin[blockIdx.x] = mn; tmax[blockIdx.x] = mx; tflags[blockIdx.x] = fl;
+    }
+}
+
+// pm[t] = max over tiles before t, sm[t] = min over tiles after t (one workgroup; nt <= n/2048)
+__global__ __launch_bounds__(1024) void oa_tile_prefix(const uint64_t *__restrict__ tmin,
+                                                       const uint64_t *__restrict__ tmax,
+                                                       const uint32_t *__restrict__ tflags, long nt,
+                                                       uint64_t *__restrict__ pm, uint64_t *__restrict__ sm,
+                                                       OrderInfo *__restrict__ info) {
+    __shared__ uint64_t s[1024];
+    const int t = threadIdx.x;
+    uint32_t fl = 0;
+    for (long i = t; i < nt; i += 1024) fl |= tflags[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fl |= __shfl_xor(fl, off, 64);
+    if ((t & 63) == 0 && fl) atomicOr(&info->flags, fl);
+    uint64_t carry = 0;
+    for (long base = 0; base < nt; base += 1024) {
+        const long i = base + t;
+        s[t] = i < nt ? tmax[i] : 0;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint64_t o = t >= off ? s[t - off] : 0;
+            __syncthreads();
+            s[t] = u64max(s[t], o);
+            __syncthreads();
+        }
+        const uint64_t excl = t ? s[t - 1] : 0;
+        if (i < nt) pm[i] = u64max(carry, excl);
+        carry = u64max(carry, s[1023]);
+        __syncthreads();
+    }
+    carry = ~0ull;
+    for (long top = nt; top > 0; top -= 1024) {
+        const long i = top - 1 - t;                   // thread 0 holds the LAST tile of this block of tiles
+        s[t] = i >= 0 ? tmin[i] : ~0ull;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint64_t o = t >= off ? s[t - off] : ~0ull;
+            __syncthreads();
+            s[t] = u64min(s[t], o);
+            __syncthreads();
+        }
+        const uint64_t excl = t ? s[t - 1] : ~0ull;
+        if (i >= 0) sm[i] = u64min(carry, excl);
+        carry = u64min(carry, s[1023]);
+        __syncthreads();
+    }
+}
+
+// cut[k] = 1 where max(keys[0,k)) <= min(keys[k,n)); thread t owns elements [8t, 8t+8) of the tile
+__global__ __launch_bounds__(OA_T) void oa_cut_flags(const uint64_t *__restrict__ keys, size_t n,
+                                                     const uint64_t *__restrict__ pm, const uint64_t *__restrict__ sm,
+                                                     uint32_t *__restrict__ cut) {
+    __shared__ uint64_t tile[OA_TILE + OA_T];
+    __shared__ uint64_t s_mx[OA_T / 64], s_mn[OA_T / 64];
+    const size_t base = (size_t)blockIdx.x * OA_TILE;
+#pragma unroll
+    for (int i = 0; i < OA_I; ++i) {
+        const int e = i * OA_T + threadIdx.x;
+        const size_t idx = base + e;
+        tile[e + (e >> 3)] = idx < n ? keys[idx] : ~0ull;      // the tail never lowers a min; it follows every real key
+    }
+    __syncthreads();
+    uint64_t v[OA_I], tmx = 0, tmn = ~0ull;
+#pragma unroll
+    for (int i = 0; i < OA_I; ++i) { v[i] = tile[threadIdx.x * 9 + i]; tmx = u64max(tmx, v[i]); tmn = u64min(tmn, v[i]); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t imx = tmx, imn = tmn;                  // inclusive prefix max / inclusive suffix min over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t a = __shfl_up(imx, off, 64), b = __shfl_down(imn, off, 64);
+        if (lane >= off) imx = u64max(imx, a);
+        if (lane + off < 64) imn = u64min(imn, b);
+    }
+    if (lane == 63) s_mx[wave] = imx;
+    if (lane == 0) s_mn[wave] = imn;
+    uint64_t emx = __shfl_up(imx, 1, 64), emn = __shfl_down(imn, 1, 64);
+    if (lane == 0) emx = 0;
+    if (lane == 63) emn = ~0ull;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < OA_T / 64; ++w) {
+        if (w < wave) emx = u64max(emx, s_mx[w]);
+        if (w > wave) emn = u64min(emn, s_mn[w]);
+    }
+    uint64_t before = u64max(pm[blockIdx.x], emx);
+    uint64_t sfx[OA_I + 1];
+    sfx[OA_I] = u64min(sm[blockIdx.x], emn);
+#pragma unroll
+    for (int i = OA_I - 1; i >= 0; --i) sfx[i] = u64min(v[i], sfx[i + 1]);
+#pragma unroll
+    for (int i = 0; i < OA_I; ++i) {
+        const size_t idx = base + (size_t)threadIdx.x * OA_I + i;
+        if (idx < n) cut[idx] = (idx == 0 || before <= sfx[i]) ? 1u : 0u;
+        before = u64max(before, v[i]);
+    }
+}
+
+// Pieces of one element need no work; the others are listed as [wstart, wend).  A piece of >= 2
+// elements has exactly one head (cut[k] && !cut[k+1]) and one end (the next cut, or n), in the same
+// order, so the rank of an end is (#heads before it) - 1: one scan serves both.
+__global__ void oa_heads(const uint32_t *__restrict__ cut, size_t n, uint32_t *__restrict__ head) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) head[k] = (cut[k] && k + 1 < n && !cut[k + 1]) ? 1u : 0u;
+}
+__global__ void oa_work_list(const uint32_t *__restrict__ cut, const uint32_t *__restrict__ head,
+                             const uint32_t *__restrict__ wpos, size_t n, const OrderInfo *__restrict__ info,
+                             uint32_t *__restrict__ wstart, uint32_t *__restrict__ wend) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (head[k]) wstart[wpos[k]] = (uint32_t)k;
+    if (k > 0 && cut[k] && !cut[k - 1]) wend[wpos[k] - 1] = (uint32_t)k;
+    if (k == n - 1 && !cut[k]) wend[info->nchunks - 1] = (uint32_t)n;
+}
+__global__ void oa_work_maxlen(const uint32_t *__restrict__ wstart, const uint32_t *__restrict__ wend,
+                               OrderInfo *__restrict__ info) {
+    const uint32_t nch = info->nchunks;
+    uint32_t m = 0;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += gridDim.x * blockDim.x)
+        m = max(m, wend[c] - wstart[c]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&info->maxlen, m);
+}
+
+// One workgroup per piece with LO < len <= CAP: stable LSD radix sort in LDS of a permutation of the
+// piece (keys stay put in LDS; only 16-bit positions move), 8-bit digits, skipping digits whose
+// bits do not vary inside the piece (one atmosphere row => the whole high field).  Ranking is the
+// wave-ballot scheme of rs_scatter.  Nothing happens at all when any piece exceeds CS_BIG.
+template <int CAP, int LO, int THREADS>
+__global__ __launch_bounds__(THREADS) void oa_chunk_sort(uint64_t *__restrict__ keys, uint32_t *__restrict__ idx,
+                                                         const uint32_t *__restrict__ wstart,
+                                                         const uint32_t *__restrict__ wend,
+                                                         const OrderInfo *__restrict__ info) {
+    constexpr int NW = THREADS / 64, ROWS = CAP / THREADS;
+    extern __shared__ uint64_t cs_lds[];
+    uint64_t *sk = cs_lds;                                                   // [CAP]
+    uint16_t *perm0 = reinterpret_cast<uint16_t *>(cs_lds + CAP);            // [CAP]
+    uint16_t *perm1 = perm0 + CAP;                                           // [CAP]
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(perm1 + CAP);               // [NW][256]
+    uint32_t *s_wave = cnt + NW * 256;                                       // [NW]
+    uint32_t *s_var = s_wave + NW;                                           // [2]
+    if (info->maxlen > (uint32_t)CS_BIG) return;
+    const uint32_t nch = info->nchunks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
+        const uint32_t b = wstart[c], len = wend[c] - b;
+        if (len <= (uint32_t)LO || len > (uint32_t)CAP) continue;
+        if (threadIdx.x < 2) s_var[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t k0 = keys[b];
+        uint64_t var = 0;
+        for (uint32_t i = threadIdx.x; i < len; i += THREADS) {
+            const uint64_t k = keys[b + i];
+            sk[i] = k; perm0[i] = (uint16_t)i;
+            var |= k ^ k0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) var |= __shfl_xor(var, off, 64);
+        if (lane == 0 && var) { atomicOr(&s_var[0], (uint32_t)var); atomicOr(&s_var[1], (uint32_t)(var >> 32)); }
+        __syncthreads();
+        var = ((uint64_t)s_var[1] << 32) | s_var[0];
+        // wave w owns positions [w*per, (w+1)*per), walked in rows of 64: (wave, row, lane) order == sequence order
+        const uint32_t per = ((len + NW * 64 - 1) / (NW * 64)) * 64;
+        uint16_t *pin = perm0, *pout = perm1;
+        for (int shift = 0; shift < 64; shift += 8) {
+            const uint32_t m = (uint32_t)(var >> shift) & 0xffu;
+            if (!m) continue;
+            const int nbits = 32 - __clz(m);
+            for (int i = threadIdx.x; i < NW * 256; i += THREADS) cnt[i] = 0;
+            __syncthreads();
+            volatile uint32_t *wc = cnt + wave * 256;
+            uint32_t rank[ROWS], dig[ROWS];
+            uint16_t pv[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const uint32_t pos = wave * per + r * 64 + lane;
+                const bool ok = (uint32_t)(r * 64) < per && pos < len;
+                const uint16_t p = ok ? pin[pos] : (uint16_t)0;
+                const uint32_t d = ok ? (uint32_t)(sk[p] >> shift) & 0xffu : 0u;
+                unsigned long long peers = __ballot(ok);
+                for (int bb = 0; bb < nbits; ++bb) {
+                    const bool bit = (d >> bb) & 1u;
+                    const unsigned long long mm = __ballot(bit);
+                    peers &= bit ? mm : ~mm;
+                }
+                uint32_t old = 0;
+                const int leader = ok ? __ffsll((long long)peers) - 1 : 0;
+                if (ok && lane == leader) { old = wc[d]; wc[d] = old + (uint32_t)__popcll(peers); }
+                old = __shfl(old, leader, 64);
+                rank[r] = old + (uint32_t)__popcll(peers & lt);
+                dig[r] = d; pv[r] = p;
+            }
+            __syncthreads();
+            uint32_t tot = 0;
+            if (threadIdx.x < 256)
+                for (int w = 0; w < NW; ++w) tot += cnt[w * 256 + threadIdx.x];
+            uint32_t all;
+            uint32_t run = block_excl_scan<THREADS>(threadIdx.x < 256 ? tot : 0u, s_wave, all);
+            if (threadIdx.x < 256)
+                for (int w = 0; w < NW; ++w) {
+                    const uint32_t q = cnt[w * 256 + threadIdx.x];
+                    cnt[w * 256 + threadIdx.x] = run;
+                    run += q;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const uint32_t pos = wave * per + r * 64 + lane;
+                if ((uint32_t)(r * 64) < per && pos < len) pout[cnt[wave * 256 + dig[r]] + rank[r]] = pv[r];
+            }
+            __syncthreads();
+            uint16_t *tmp = pin; pin = pout; pout = tmp;
+        }
+        uint32_t vi[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t i = r * THREADS + threadIdx.x;
+            vi[r] = i < len ? idx[b + pin[i]] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t i = r * THREADS + threadIdx.x;
+            if (i < len) { keys[b + i] = sk[pin[i]]; idx[b + i] = vi[r]; }
+        }
+        __syncthreads();
+    }
+}
+template <int CAP, int THREADS> constexpr size_t chunk_sort_lds() {
+    return (size_t)CAP * 8 + (size_t)CAP * 4 + (size_t)(THREADS / 64) * 256 * 4 + (size_t)(THREADS / 64) * 4 + 8;
+}
+
+// Enqueues the analysis and the piece sorts.  Afterwards *d_info holds: flags (ORD_*), nchunks =
+// number of pieces with >= 2 elements, maxlen = the longest of them.  The data is in (key, idx)
+// order iff maxlen <= CS_BIG (8192); otherwise it is untouched.
+void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_info, hipStream_t st) {
+    IBH_HIP(hipMemsetAsync(d_info, 0, sizeof(OrderInfo), st));
+    if (n < 2) return;
+    IBH_CHECK(n < (1ul << 32), "sort too large");
+    constexpr size_t lds_small = chunk_sort_lds<CS_SMALL, 256>(), lds_big = chunk_sort_lds<CS_BIG, 1024>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&oa_chunk_sort<CS_BIG, CS_SMALL, 1024>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+        attr_set = true;
+    }
+    Arena &A = arena();
+    const size_t nt = (n + OA_TILE - 1) / OA_TILE;
+    uint64_t *tmin = A.get<uint64_t>(nt), *tmax = A.get<uint64_t>(nt), *pm = A.get<uint64_t>(nt), *sm = A.get<uint64_t>(nt);
+    uint32_t *cut = A.get<uint32_t>(n), *head = A.get<uint32_t>(n), *wpos = A.get<uint32_t>(n);
+    uint32_t *wstart = A.get<uint32_t>(n / 2 + 1), *wend = A.get<uint32_t>(n / 2 + 1);
+    const unsigned ge = (unsigned)((n + 255) / 256);
+    uint32_t *tflags = A.get<uint32_t>(nt);
+    hipLaunchKernelGGL(oa_tiles, dim3((unsigned)nt), dim3(OA_T), 0, st, keys, n, tmin, tmax, tflags);
+    hipLaunchKernelGGL(oa_tile_prefix, dim3(1), dim3(1024), 0, st, tmin, tmax, tflags, (long)nt, pm, sm, d_info);
+    hipLaunchKernelGGL(oa_cut_flags, dim3((unsigned)nt), dim3(OA_T), 0, st, keys, n, pm, sm, cut);
+    hipLaunchKernelGGL(oa_heads, dim3(ge), dim3(256), 0, st, cut, n, head);
+    exclusive_scan_u32(head, wpos, n, &d_info->nchunks, st);
+    hipLaunchKernelGGL(oa_work_list, dim3(ge), dim3(256), 0, st, cut, head, wpos, n, d_info, wstart, wend);
+    const unsigned gmax = (unsigned)std::min<size_t>((n + 1023) / 1024, 1024);
+    hipLaunchKernelGGL(oa_work_maxlen, dim3(gmax), dim3(256), 0, st, wstart, wend, d_info);
+    const unsigned gs = (unsigned)std::min<size_t>((n + 1) / 2, 256 * 12);
+    hipLaunchKernelGGL((oa_chunk_sort<CS_SMALL, 1, 256>), dim3(gs), dim3(256), lds_small, st, keys, idx, wstart, wend, d_info);
+    if (n > (size_t)CS_SMALL) {
+        const unsigned gb = (unsigned)std::min<size_t>((n + CS_SMALL - 1) / CS_SMALL, 512);
+        hipLaunchKernelGGL((oa_chunk_sort<CS_BIG, CS_SMALL, 1024>), dim3(gb), dim3(1024), lds_big, st, keys, idx, wstart, wend, d_info);
+    }
+    IBH_HIP(hipGetLastError());
+}
+
+bool adaptive_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt, size_t n,
+                         int lo_bits, int hi_bits, OrderInfo *d_info, hipStream_t st) {
+    if (n < 2) return false;
+    order_and_chunk_sort(keys, vals, n, d_info, st);
+    OrderInfo h;
+    IBH_HIP(hipMemcpyAsync(&h, d_info, sizeof(h), hipMemcpyDeviceToHost, st));
+    IBH_HIP(hipStreamSynchronize(st));
+    static const bool dbg = getenv("IBH_DEBUG_SORT") != nullptr;
+    if (dbg) fprintf(stderr, "[ibh sort] n=%zu flags=%u pieces=%u maxlen=%u lo_bits=%d hi_bits=%d\n", n, h.flags, h.nchunks, h.maxlen, lo_bits, hi_bits);
+    if (!(h.flags & ORD_FULL_DEC) || h.maxlen <= (uint32_t)CS_BIG) return false;      // in order / pieces sorted in place
+    KeyField f[2]; int nf = 0;
+    if (lo_bits > 0 && (h.flags & ORD_LO_DEC)) f[nf++] = KeyField{0, lo_bits};        // else: stable sort by the high field suffices
+    if (hi_bits > 0) f[nf++] = KeyField{32, hi_bits};
+    return radix_sort_pairs(keys, keys_alt, vals, vals_alt, n, f, nf, st);
 }
 
 }  // namespace ibh
