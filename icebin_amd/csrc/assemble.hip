@@ -162,15 +162,25 @@ __global__ void k_scatter_existing(int32_t *tab, const int64_t *to_sparse, int n
     if (i < n) tab[to_sparse[i]] = i;
 }
 
-// The three numbering passes handle BOTH sets of a matrix (rows and columns) per exchange-cell visit,
-// and the flag pass also counts the cell's contributions: 4 generator passes per build instead of 8.
+// The generator passes handle BOTH sets of a matrix (rows and columns) per exchange-cell visit:
+//   pass 1 (k_first2)  first[key] = smallest emission position 2x+j naming the key (atomicMin)
+//   pass 2 (k_flag2)   pk[x] = which of the cell's entries are first occurrences + its number of
+//                      contributions; ONE packed scan then ranks rows, columns and contributions
+//   pass 3 (k_contrib_emit) dense id of any key = old id, or base + rank of its first occurrence
+//                      (looked up through first[]); first occurrences also record to_sparse.
 struct SetArgs {
     int enabled, list, key, base;
-    int32_t *tab;           // [sparse_extent] sparse -> dense (-1 missing)
-    uint32_t *first;        // [sparse_extent] smallest emission position 2x+j that names the key
-    uint32_t *flag;         // [2*nX] 1 where position 2x+j is a first occurrence; scanned in place -> rank
-    int64_t *to_sparse;     // [capacity] dense -> sparse
+    long ident_n;               // >= 0: the set's old part is the identity on [0, ident_n)
+    const int32_t *tab;         // old sparse -> dense table (-1 missing); nullptr when there is no old part / identity
+    uint32_t *first;            // [sparse_extent] smallest emission position 2x+j that names the key
+    int64_t *to_sparse;         // [capacity] dense -> sparse
+    const uint32_t *off;        // [nX] new keys of this set emitted before cell x (after the scan)
+    int pkshift;                // this set's flag pair inside pk[x]
 };
+__device__ __forceinline__ int old_dense(const SetArgs &a, long key) {
+    if (a.ident_n >= 0) return key < a.ident_n ? (int)key : -1;
+    return a.tab ? a.tab[key] : -1;
+}
 
 __device__ __forceinline__ void first_one(const SetArgs &a, const XCell &c, long x, bool valid, bool lane0) {
     long keys[2] = {-1, -1};
@@ -181,7 +191,7 @@ __device__ __forceinline__ void first_one(const SetArgs &a, const XCell &c, long
     const long prev0 = __shfl_up(n > 0 ? keys[0] : -1l, 1, 64);
     for (int j = 0; j < n; ++j) {
         if (j == 0 && !lane0 && prev0 == keys[0]) continue;
-        if (a.tab[keys[j]] < 0) atomicMin(&a.first[keys[j]], (uint32_t)(2 * x + j));
+        if (old_dense(a, keys[j]) < 0) atomicMin(&a.first[keys[j]], (uint32_t)(2 * x + j));
     }
 }
 template <bool WITH_EP>
@@ -199,39 +209,37 @@ __global__ void k_first2(RgView rg, SetArgs a, SetArgs b, int *__restrict__ err_
     if (b.enabled) first_one(b, c, x, valid, lane0);
 }
 
-__device__ __forceinline__ void flag_one(const SetArgs &a, const XCell &c, long x, bool valid) {
-    long keys[2];
-    const int n = valid ? list_entries(c, x, a.list, a.key, keys) : 0;
-    uint32_t f0 = 0, f1 = 0;
-    if (n > 0 && a.tab[keys[0]] < 0 && a.first[keys[0]] == (uint32_t)(2 * x)) f0 = 1;
-    if (n > 1 && a.tab[keys[1]] < 0 && a.first[keys[1]] == (uint32_t)(2 * x + 1)) f1 = 1;
-    a.flag[2 * x] = f0;
-    a.flag[2 * x + 1] = f1;
-}
-__device__ __forceinline__ void assign_one(const SetArgs &a, const XCell &c, long x) {
+__device__ __forceinline__ uint32_t flag_one(const SetArgs &a, const XCell &c, long x) {
     long keys[2];
     const int n = list_entries(c, x, a.list, a.key, keys);
-    for (int j = 0; j < n; ++j) {
-        // first[] still holds the winner; tab is only written at the winner's key
-        if (a.first[keys[j]] == (uint32_t)(2 * x + j)) {
-            const int id = a.base + (int)a.flag[2 * x + j];
-            a.tab[keys[j]] = id;
-            a.to_sparse[id] = keys[j];
-        }
-    }
+    uint32_t f = 0;
+    if (n > 0 && old_dense(a, keys[0]) < 0 && a.first[keys[0]] == (uint32_t)(2 * x)) f |= 1u;
+    if (n > 1 && old_dense(a, keys[1]) < 0 && a.first[keys[1]] == (uint32_t)(2 * x + 1)) f |= 2u;
+    return f;
 }
-template <bool WITH_EP>
-__global__ void k_assign2(RgView rg, SetArgs a, SetArgs b) {
-    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= rg.nX) return;
-    const XCell c = load_cell<WITH_EP>(rg, x);
-    if (WITH_EP && c.range_error) return;
-    if (a.enabled) assign_one(a, c, x);
-    if (b.enabled) assign_one(b, c, x);
+// dense id of `key` (any cell may ask): old id, else base + rank of the key's first occurrence
+__device__ __forceinline__ int dense_of(const SetArgs &a, long key, const uint32_t *__restrict__ pk) {
+    if (!a.enabled) return (int)key;                       // identity over the whole sparse extent
+    const int t = old_dense(a, key);
+    if (t >= 0) return t;
+    const uint32_t p = a.first[key];
+    const uint32_t xf = p >> 1;
+    uint32_t r = a.off[xf];
+    if (p & 1u) r += (pk[xf] >> a.pkshift) & 1u;           // second entry of its cell: after the first if that one was new too
+    return a.base + (int)r;
+}
+// the cell's own first occurrences record dense -> sparse
+__device__ __forceinline__ void record_new(const SetArgs &a, const XCell &c, long x, uint32_t pkx) {
+    const uint32_t f = (pkx >> a.pkshift) & 3u;
+    if (!f) return;
+    long keys[2];
+    (void)list_entries(c, x, a.list, a.key, keys);
+    const uint32_t r = a.off[x];
+    if (f & 1u) a.to_sparse[a.base + r] = keys[0];
+    if (f & 2u) a.to_sparse[a.base + r + (f & 1u)] = keys[1];
 }
 
 struct DeviceSet {
-    int32_t *tab = nullptr;       // [sparse_extent] sparse -> dense (-1 missing)
     int64_t *to_sparse = nullptr; // [capacity] dense -> sparse
     int n_old = 0, n = 0;
 };
@@ -247,7 +255,7 @@ struct Numbering {
 };
 
 static Numbering number_set_prepare(const RgView &rg, ibh_sparse_set *set, int64_t sparse_extent, int list, int key,
-                                    int64_t max_new, hipStream_t st) {
+                                    int64_t max_new, int pkshift, hipStream_t st) {
     Arena &A = arena();
     set->sparse_extent = sparse_extent;                       // set_sparse_extent, RegridMatrices_Dynamic.cpp:69-72
     Numbering nb;
@@ -263,14 +271,15 @@ static Numbering number_set_prepare(const RgView &rg, ibh_sparse_set *set, int64
     }
     if (max_new > sparse_extent - ds.n_old) max_new = sparse_extent - ds.n_old;
     nb.max_new = max_new;
-    ds.tab = A.get<int32_t>((size_t)sparse_extent);
     const int64_t cap = (int64_t)ds.n_old + max_new;
     ds.to_sparse = A.get<int64_t>((size_t)cap);
     const int T = 256;
-    hipLaunchKernelGGL(k_fill_i32, dim3(ceil_div(sparse_extent, T)), dim3(T), 0, st, ds.tab, (size_t)sparse_extent, -1);
+    SetArgs &a = nb.args;
+    a.list = list; a.key = key; a.base = ds.n_old; a.to_sparse = ds.to_sparse; a.pkshift = pkshift;
+    a.ident_n = -1; a.tab = nullptr;
     if (ds.n_old) {
         if (set->identity) {
-            hipLaunchKernelGGL(k_iota_i32, dim3(ceil_div(ds.n_old, T)), dim3(T), 0, st, ds.tab, (size_t)ds.n_old);
+            a.ident_n = ds.n_old;
             hipLaunchKernelGGL(k_iota_i64, dim3(ceil_div(ds.n_old, T)), dim3(T), 0, st, ds.to_sparse, (size_t)ds.n_old);
         } else {
             if (set->dev_n == ds.n_old)
@@ -279,16 +288,16 @@ static Numbering number_set_prepare(const RgView &rg, ibh_sparse_set *set, int64
                 set->ensure_host();
                 IBH_HIP(hipMemcpyAsync(ds.to_sparse, set->host.data(), sizeof(int64_t) * (size_t)ds.n_old, hipMemcpyHostToDevice, st));
             }
-            hipLaunchKernelGGL(k_scatter_existing, dim3(ceil_div(ds.n_old, T)), dim3(T), 0, st, ds.tab, ds.to_sparse, ds.n_old);
+            int32_t *tab = A.get<int32_t>((size_t)sparse_extent);
+            hipLaunchKernelGGL(k_fill_i32, dim3(ceil_div(sparse_extent, T)), dim3(T), 0, st, tab, (size_t)sparse_extent, -1);
+            hipLaunchKernelGGL(k_scatter_existing, dim3(ceil_div(ds.n_old, T)), dim3(T), 0, st, tab, ds.to_sparse, ds.n_old);
+            a.tab = tab;
         }
     }
     ds.n = ds.n_old;
-    SetArgs &a = nb.args;
-    a.list = list; a.key = key; a.base = ds.n_old; a.tab = ds.tab; a.to_sparse = ds.to_sparse;
     a.enabled = !(set->identity && ds.n_old == sparse_extent);      // an identity set that covers everything gains nothing
     if (a.enabled) {
         a.first = A.get<uint32_t>((size_t)sparse_extent);
-        a.flag = A.get<uint32_t>((size_t)(2 * rg.nX));
         IBH_HIP(hipMemsetAsync(a.first, 0xFF, sizeof(uint32_t) * (size_t)sparse_extent, st));
     }
     return nb;
@@ -351,29 +360,35 @@ __device__ __forceinline__ int contributions(const XCell &c, long x, const MatSp
 }
 
 template <bool WITH_EP>
-__global__ void k_flag2(RgView rg, SetArgs a, SetArgs b, MatSpec s, uint32_t *__restrict__ cnt) {
+__global__ void k_flag2(RgView rg, SetArgs a, SetArgs b, MatSpec s, uint32_t *__restrict__ pk) {
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= rg.nX) return;
     const XCell c = load_cell<WITH_EP>(rg, x);
-    const bool valid = !(WITH_EP && c.range_error);
-    if (a.enabled) flag_one(a, c, x, valid);
-    if (b.enabled) flag_one(b, c, x, valid);
-    long rk[2], ck[2]; double t[2];
-    cnt[x] = valid ? (uint32_t)contributions(c, x, s, rk, ck, t) : 0u;
+    uint32_t v = 0;
+    if (!(WITH_EP && c.range_error)) {
+        if (a.enabled) v |= flag_one(a, c, x) << a.pkshift;
+        if (b.enabled) v |= flag_one(b, c, x) << b.pkshift;
+        long rk[2], ck[2]; double t[2];
+        v |= (uint32_t)contributions(c, x, s, rk, ck, t) << 4;
+    }
+    pk[x] = v;
 }
 template <bool WITH_EP>
-__global__ void k_contrib_emit(RgView rg, MatSpec s, const uint32_t *__restrict__ pos, const int32_t *__restrict__ rtab,
-                               const int32_t *__restrict__ ctab, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx,
+__global__ void k_contrib_emit(RgView rg, MatSpec s, SetArgs a, SetArgs b, const uint32_t *__restrict__ pk,
+                               const uint32_t *__restrict__ pos, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx,
                                double *__restrict__ term) {
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= rg.nX) return;
+    const uint32_t pkx = pk[x];
+    if (!pkx) return;                          // nothing new, nothing contributed (masked cells, range errors)
     const XCell c = load_cell<WITH_EP>(rg, x);
-    if (WITH_EP && c.range_error) return;
+    if (a.enabled) record_new(a, c, x, pkx);
+    if (b.enabled) record_new(b, c, x, pkx);
     long rk[2], ck[2]; double t[2];
     const int n = contributions(c, x, s, rk, ck, t);
     const uint32_t p = pos[x];
     for (int j = 0; j < n; ++j) {
-        keys[p + j] = ((uint64_t)(uint32_t)rtab[rk[j]] << 32) | (uint32_t)ctab[ck[j]];
+        keys[p + j] = ((uint64_t)(uint32_t)dense_of(a, rk[j], pk) << 32) | (uint32_t)dense_of(b, ck[j], pk);
         idx[p + j] = p + j;
         term[p + j] = t[j];
     }
@@ -811,24 +826,22 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     // dense numbering in emission order; each user-visible set is numbered by exactly one Ur matrix
     // (RegridMatrices_Dynamic.cpp:75-81, 86-90, 178-183, 187-190, 270-277), so the two are independent.
     Numbering rnum = number_set_prepare(rg, dims[0], extent_of(sp->row_key), sp->row_list, sp->row_key,
-                                        (sp->row_list == LIST_EP ? 2 : 1) * g->nX, st);
+                                        (sp->row_list == LIST_EP ? 2 : 1) * g->nX, 0, st);
     Numbering cnum = number_set_prepare(rg, dims[1], extent_of(sp->col_key), sp->col_list, sp->col_key,
-                                        (sp->col_list == LIST_EP ? 2 : 1) * g->nX, st);
-    IBH_HIP(hipMemsetAsync(d_cnt + 1, 0, 3 * sizeof(uint32_t), st));
+                                        (sp->col_list == LIST_EP ? 2 : 1) * g->nX, 2, st);
     const int T = 256;
     const dim3 grid(g->nX ? ceil_div(g->nX, T) : 1);
-    uint32_t *cnt = A.get<uint32_t>((size_t)g->nX);
+    uint32_t *pk = A.get<uint32_t>((size_t)g->nX);
+    uint32_t *roff = A.get<uint32_t>((size_t)g->nX), *coff = A.get<uint32_t>((size_t)g->nX), *poff = A.get<uint32_t>((size_t)g->nX);
+    rnum.args.off = roff; cnum.args.off = coff;
     if (uses_ep) {
         hipLaunchKernelGGL(k_first2<true>, grid, dim3(T), 0, st, rg, rnum.args, cnum.args, d_err);
-        hipLaunchKernelGGL(k_flag2<true>, grid, dim3(T), 0, st, rg, rnum.args, cnum.args, *sp, cnt);
+        hipLaunchKernelGGL(k_flag2<true>, grid, dim3(T), 0, st, rg, rnum.args, cnum.args, *sp, pk);
     } else {
         hipLaunchKernelGGL(k_first2<false>, grid, dim3(T), 0, st, rg, rnum.args, cnum.args, d_err);
-        hipLaunchKernelGGL(k_flag2<false>, grid, dim3(T), 0, st, rg, rnum.args, cnum.args, *sp, cnt);
+        hipLaunchKernelGGL(k_flag2<false>, grid, dim3(T), 0, st, rg, rnum.args, cnum.args, *sp, pk);
     }
-    if (rnum.args.enabled) exclusive_scan_u32(rnum.args.flag, rnum.args.flag, (size_t)(2 * g->nX), d_cnt + 1, st);
-    if (cnum.args.enabled) exclusive_scan_u32(cnum.args.flag, cnum.args.flag, (size_t)(2 * g->nX), d_cnt + 2, st);
-    // contributions in emission (x) order: count (done in k_flag2) + scan do not depend on the numbering
-    exclusive_scan_u32(cnt, cnt, (size_t)g->nX, d_cnt + 3, st);
+    exclusive_scan3(pk, (size_t)g->nX, roff, coff, poff, d_cnt + 1, st);
     uint32_t h_cnt[4];
     IBH_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
     IBH_HIP(hipStreamSynchronize(st));
@@ -846,27 +859,20 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
         IBH_CHECK((int64_t)n_new <= nb->max_new, "internal: more new keys (%u) than reserved (%ld)", n_new, (long)nb->max_new);
         IBH_CHECK((int64_t)nb->ds.n_old + n_new < (1ll << 31), "dense extent overflows int32");
     }
-    if ((rnum.args.enabled && h_cnt[1]) || (cnum.args.enabled && h_cnt[2])) {
-        SetArgs ra = rnum.args, ca = cnum.args;
-        ra.enabled = ra.enabled && h_cnt[1]; ca.enabled = ca.enabled && h_cnt[2];
-        if (uses_ep) hipLaunchKernelGGL(k_assign2<true>, grid, dim3(T), 0, st, rg, ra, ca);
-        else hipLaunchKernelGGL(k_assign2<false>, grid, dim3(T), 0, st, rg, ra, ca);
-        IBH_HIP(hipGetLastError());
-    }
-    number_set_finish(rnum, h_cnt[1], st);
-    number_set_finish(cnum, h_cnt[2], st);
-    const DeviceSet &rset = rnum.ds, &cset = cnum.ds;
-    const int nrow = rset.n, ncol = cset.n;
     const uint32_t ncontrib = h_cnt[3];
     Triplets t;
     t.n = ncontrib;
     t.keys = A.get<uint64_t>(t.n); t.keys_alt = A.get<uint64_t>(t.n);
     t.idx = A.get<uint32_t>(t.n); t.idx_alt = A.get<uint32_t>(t.n);
     t.term = A.get<double>(t.n);
-    if (t.n) {
-        if (uses_ep) hipLaunchKernelGGL(k_contrib_emit<true>, grid, dim3(T), 0, st, rg, *sp, cnt, rset.tab, cset.tab, t.keys, t.idx, t.term);
-        else hipLaunchKernelGGL(k_contrib_emit<false>, grid, dim3(T), 0, st, rg, *sp, cnt, rset.tab, cset.tab, t.keys, t.idx, t.term);
-    }
+    // emit also records the new keys' dense -> sparse entries, so it runs even with no contributions
+    if (uses_ep) hipLaunchKernelGGL(k_contrib_emit<true>, grid, dim3(T), 0, st, rg, *sp, rnum.args, cnum.args, pk, poff, t.keys, t.idx, t.term);
+    else hipLaunchKernelGGL(k_contrib_emit<false>, grid, dim3(T), 0, st, rg, *sp, rnum.args, cnum.args, pk, poff, t.keys, t.idx, t.term);
+    IBH_HIP(hipGetLastError());
+    number_set_finish(rnum, h_cnt[1], st);
+    number_set_finish(cnum, h_cnt[2], st);
+    const DeviceSet &rset = rnum.ds, &cset = cnum.ds;
+    const int nrow = rset.n, ncol = cset.n;
     int32_t *row = nullptr;
     build_csr_from_contributions(w.get(), t, nrow, ncol, &row, st);
     const long nnz = w->nnz;

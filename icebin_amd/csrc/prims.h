@@ -23,6 +23,11 @@ void release_workspace();
 // grand total is written there (device pointer).  All work is enqueued on `stream`.
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total, hipStream_t stream);
 
+// Three exclusive scans in one pass over a packed stream: pk[i] bits [0,2) and [2,4) are flag pairs
+// (channel value = number of set flags), bits [4,6) a count 0..3.  totals3: device uint32[3].
+void exclusive_scan3(const uint32_t *pk, size_t n, uint32_t *o0, uint32_t *o1, uint32_t *o2, uint32_t *totals3,
+                     hipStream_t stream);
+
 // Stable sort of n pairs by the key bits listed in `fields` (least significant field first);
 // each field is (shift, nbits) with nbits <= 32 and is split into digits of <= 8 bits.
 // Ping-pongs between (keys, vals) and (keys_alt, vals_alt); returns true when the sorted

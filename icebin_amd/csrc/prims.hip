@@ -133,6 +133,116 @@ void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *t
     IBH_HIP(hipGetLastError());
 }
 
+// ---- three-channel scan -----------------------------------------------------------------------
+// The generator passes of the assembly produce, per exchange cell, three tiny counts (new row keys,
+// new column keys, contributions).  Scanning them as ONE packed stream (4 B in, 12 B out per cell,
+// three kernels) replaces three separate scans.  pk bits: [0,2) row first-occurrence flags, [2,4)
+// column flags, [4,6) number of contributions.  Inside a tile the three running sums share a u64
+// (21 bits each: a tile sums to at most 2 * 2048).
+__device__ __forceinline__ uint64_t s3_unpack(uint32_t pk) {
+    return (uint64_t)__popc(pk & 3u) | ((uint64_t)__popc((pk >> 2) & 3u) << 21) | ((uint64_t)((pk >> 4) & 3u) << 42);
+}
+template <int THREADS>
+__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *s_wave, uint64_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint64_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) {
+        const uint64_t t = s_wave[w];
+        if (w < wave) wbase += t;
+        tot += t;
+    }
+    total = tot;
+    __syncthreads();
+    return wbase + inc - v;
+}
+__global__ __launch_bounds__(SC_T) void s3_tile_sums(const uint32_t *__restrict__ pk, size_t n, uint32_t *__restrict__ sums,
+                                                     size_t nb) {
+    __shared__ uint64_t s_wave[SC_T / 64];
+    const size_t base = (size_t)blockIdx.x * SC_TILE;
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SC_I; ++i) {
+        const size_t idx = base + (size_t)i * SC_T + threadIdx.x;
+        if (idx < n) s += s3_unpack(pk[idx]);
+    }
+    uint64_t tot;
+    (void)block_excl_scan_u64<SC_T>(s, s_wave, tot);
+    if (threadIdx.x == 0) {
+        sums[blockIdx.x] = (uint32_t)(tot & 0x1fffffu);
+        sums[nb + blockIdx.x] = (uint32_t)((tot >> 21) & 0x1fffffu);
+        sums[2 * nb + blockIdx.x] = (uint32_t)(tot >> 42);
+    }
+}
+__global__ __launch_bounds__(1024) void s3_sums_inplace(uint32_t *__restrict__ sums, int nb, uint32_t *__restrict__ totals) {
+    __shared__ uint32_t s_wave[16];
+    for (int ch = 0; ch < 3; ++ch) {
+        uint32_t *p = sums + (size_t)ch * nb;
+        uint32_t carry = 0;
+        for (int base = 0; base < nb; base += 1024) {
+            const int i = base + threadIdx.x;
+            const uint32_t v = i < nb ? p[i] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<1024>(v, s_wave, tot);
+            if (i < nb) p[i] = carry + ex;
+            carry += tot;
+        }
+        if (threadIdx.x == 0) totals[ch] = carry;
+    }
+}
+__global__ __launch_bounds__(SC_T) void s3_tile_apply(const uint32_t *__restrict__ pk, size_t n, const uint32_t *__restrict__ sums,
+                                                      size_t nb, uint32_t *__restrict__ o0, uint32_t *__restrict__ o1,
+                                                      uint32_t *__restrict__ o2) {
+    __shared__ uint32_t tile[SC_TILE + SC_T];
+    __shared__ uint64_t s_wave[SC_T / 64];
+    const size_t base = (size_t)blockIdx.x * SC_TILE;
+#pragma unroll
+    for (int i = 0; i < SC_I; ++i) {
+        const int e = i * SC_T + threadIdx.x;
+        const size_t idx = base + e;
+        tile[e + (e >> 3)] = idx < n ? pk[idx] : 0u;
+    }
+    __syncthreads();
+    uint64_t v[SC_I], sum = 0;
+#pragma unroll
+    for (int i = 0; i < SC_I; ++i) { v[i] = s3_unpack(tile[threadIdx.x * 9 + i]); sum += v[i]; }
+    uint64_t tot;
+    uint64_t run = block_excl_scan_u64<SC_T>(sum, s_wave, tot);
+    const uint32_t b0 = sums[blockIdx.x], b1 = sums[nb + blockIdx.x], b2 = sums[2 * nb + blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SC_I; ++i) {
+        const size_t idx = base + (size_t)threadIdx.x * SC_I + i;
+        if (idx < n) {
+            o0[idx] = b0 + (uint32_t)(run & 0x1fffffu);
+            o1[idx] = b1 + (uint32_t)((run >> 21) & 0x1fffffu);
+            o2[idx] = b2 + (uint32_t)(run >> 42);
+        }
+        run += v[i];
+    }
+}
+void exclusive_scan3(const uint32_t *pk, size_t n, uint32_t *o0, uint32_t *o1, uint32_t *o2, uint32_t *totals3,
+                     hipStream_t stream) {
+    if (n == 0) {
+        IBH_HIP(hipMemsetAsync(totals3, 0, 3 * sizeof(uint32_t), stream));
+        return;
+    }
+    const size_t nb = (n + SC_TILE - 1) / SC_TILE;
+    IBH_CHECK(nb < (1ul << 31), "scan too large");
+    uint32_t *sums = arena().get<uint32_t>(3 * nb);
+    hipLaunchKernelGGL(s3_tile_sums, dim3((unsigned)nb), dim3(SC_T), 0, stream, pk, n, sums, nb);
+    hipLaunchKernelGGL(s3_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, (int)nb, totals3);
+    hipLaunchKernelGGL(s3_tile_apply, dim3((unsigned)nb), dim3(SC_T), 0, stream, pk, n, sums, nb, o0, o1, o2);
+    IBH_HIP(hipGetLastError());
+}
+
 // ---- radix sort ----------------------------------------------------------------------------
 constexpr int RS_T = 256, RS_I = 16, RS_TILE = RS_T * RS_I;
 
