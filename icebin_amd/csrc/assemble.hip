@@ -83,6 +83,17 @@ __device__ __forceinline__ int dev_lower_bound(const double *__restrict__ xp, in
     return lo;
 }
 
+// hcdefs staged in LDS for the elevation-class generators (binary search per cell); falls back to
+// global memory for very long tables
+constexpr int HC_LDS = 512;
+template <bool WITH_EP>
+__device__ __forceinline__ void stage_hc(RgView &rg, double *s_hc) {
+    if (WITH_EP && rg.nhc <= HC_LDS) {
+        for (int i = threadIdx.x; i < rg.nhc; i += blockDim.x) s_hc[i] = rg.hc[i];
+        __syncthreads();
+        rg.hc = s_hc;
+    }
+}
 template <bool WITH_EP>
 __device__ __forceinline__ XCell load_cell(const RgView &rg, long x) {
     XCell c;
@@ -182,31 +193,66 @@ __device__ __forceinline__ int old_dense(const SetArgs &a, long key) {
     return a.tab ? a.tab[key] : -1;
 }
 
-__device__ __forceinline__ void first_one(const SetArgs &a, const XCell &c, long x, bool valid, bool lane0) {
+// Keys shared by many cells of a workgroup (atmosphere cells, elevation classes: ~10^2..10^3 cells
+// name each one) are first reduced in an LDS hash table, then flushed with ONE global atomicMin per
+// distinct key and workgroup; device-scope atomics are resolved beyond the per-XCD L2 and a
+// 38.8 M-cell grid would otherwise issue 7.7e7 of them on ~10^5 addresses.  Keys that are
+// (almost) unique per cell (ice cells, exchange cells) go to memory directly.
+constexpr int FH_SLOTS = 1024;          // >= 2 * entries per workgroup (256 cells x 2)
+struct FirstHash { uint32_t key[FH_SLOTS], pos[FH_SLOTS]; };
+__device__ __forceinline__ bool shared_keys(const SetArgs &a) { return a.key == KEY_A || a.key == KEY_E; }
+
+__device__ __forceinline__ void first_one(const SetArgs &a, const XCell &c, long x, bool valid, FirstHash *h) {
     long keys[2] = {-1, -1};
     const int n = valid ? list_entries(c, x, a.list, a.key, keys) : 0;
-    // Sorted exchange grids give long runs of equal keys (one atmosphere cell per ~10^2..10^3
-    // consecutive x): the lane below already carries a smaller position for the same key, so only
-    // the first lane of a run inside the wave needs the atomic.
-    const long prev0 = __shfl_up(n > 0 ? keys[0] : -1l, 1, 64);
     for (int j = 0; j < n; ++j) {
-        if (j == 0 && !lane0 && prev0 == keys[0]) continue;
-        if (old_dense(a, keys[j]) < 0) atomicMin(&a.first[keys[j]], (uint32_t)(2 * x + j));
+        if (old_dense(a, keys[j]) >= 0) continue;
+        const uint32_t pos = (uint32_t)(2 * x + j);
+        if (!h) { atomicMin(&a.first[keys[j]], pos); continue; }
+        const uint32_t k = (uint32_t)keys[j];
+        uint32_t slot = (k * 2654435761u) >> 22;                  // top 10 bits
+        for (;;) {
+            const uint32_t prev = atomicCAS(&h->key[slot], 0xffffffffu, k);
+            if (prev == 0xffffffffu || prev == k) { atomicMin(&h->pos[slot], pos); break; }
+            slot = (slot + 1) & (FH_SLOTS - 1);
+        }
+    }
+}
+__device__ __forceinline__ void first_flush(const SetArgs &a, FirstHash *h) {
+    for (int sl = threadIdx.x; sl < FH_SLOTS; sl += blockDim.x) {
+        const uint32_t k = h->key[sl];
+        if (k != 0xffffffffu) atomicMin(&a.first[k], h->pos[sl]);
     }
 }
 template <bool WITH_EP>
-__global__ void k_first2(RgView rg, SetArgs a, SetArgs b, int *__restrict__ err_x) {
+__global__ __launch_bounds__(256) void k_first2(RgView rg, SetArgs a, SetArgs b, int *__restrict__ err_x) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    __shared__ FirstHash s_h[2];
+    stage_hc<WITH_EP>(rg, s_hc);
+    // sparse extents of shared-key sets fit 32 bits (checked on the host)
+    const bool ha = a.enabled && shared_keys(a), hb = b.enabled && shared_keys(b);
+    if (ha || hb) {
+        for (int i = threadIdx.x; i < 2 * FH_SLOTS; i += blockDim.x) {
+            (&s_h[0].key[0])[i] = 0xffffffffu;
+            (&s_h[1].key[0])[i] = 0xffffffffu;
+        }
+        __syncthreads();
+    }
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
     XCell c;
-    bool valid = false;                         // no early return: every lane takes part in the shuffles
+    bool valid = false;
     if (x < rg.nX) {
         c = load_cell<WITH_EP>(rg, x);
         if (WITH_EP && c.range_error) atomicMin(err_x, (int)x);
         else valid = true;
     }
-    const bool lane0 = (threadIdx.x & 63) == 0;
-    if (a.enabled) first_one(a, c, x, valid, lane0);
-    if (b.enabled) first_one(b, c, x, valid, lane0);
+    if (a.enabled) first_one(a, c, x, valid, ha ? &s_h[0] : nullptr);
+    if (b.enabled) first_one(b, c, x, valid, hb ? &s_h[1] : nullptr);
+    if (ha || hb) {
+        __syncthreads();
+        if (ha) first_flush(a, &s_h[0]);
+        if (hb) first_flush(b, &s_h[1]);
+    }
 }
 
 __device__ __forceinline__ uint32_t flag_one(const SetArgs &a, const XCell &c, long x) {
@@ -269,6 +315,7 @@ static Numbering number_set_prepare(const RgView &rg, ibh_sparse_set *set, int64
             IBH_CHECK(set->host[(size_t)i] >= 0 && set->host[(size_t)i] < sparse_extent, "dims entry %ld outside sparse extent %ld",
                       (long)set->host[(size_t)i], (long)sparse_extent);
     }
+    IBH_CHECK(sparse_extent < 0xffffffffll, "sparse extent %ld does not fit 32 bits", (long)sparse_extent);
     if (max_new > sparse_extent - ds.n_old) max_new = sparse_extent - ds.n_old;
     nb.max_new = max_new;
     const int64_t cap = (int64_t)ds.n_old + max_new;
@@ -361,6 +408,8 @@ __device__ __forceinline__ int contributions(const XCell &c, long x, const MatSp
 
 template <bool WITH_EP>
 __global__ void k_flag2(RgView rg, SetArgs a, SetArgs b, MatSpec s, uint32_t *__restrict__ pk) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    stage_hc<WITH_EP>(rg, s_hc);
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= rg.nX) return;
     const XCell c = load_cell<WITH_EP>(rg, x);
@@ -377,6 +426,8 @@ template <bool WITH_EP>
 __global__ void k_contrib_emit(RgView rg, MatSpec s, SetArgs a, SetArgs b, const uint32_t *__restrict__ pk,
                                const uint32_t *__restrict__ pos, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx,
                                double *__restrict__ term) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    stage_hc<WITH_EP>(rg, s_hc);
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= rg.nX) return;
     const uint32_t pkx = pk[x];

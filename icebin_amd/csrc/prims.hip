@@ -526,15 +526,33 @@ __global__ void oa_work_list(const uint32_t *__restrict__ cut, const uint32_t *_
     if (k > 0 && cut[k] && !cut[k - 1]) wend[wpos[k] - 1] = (uint32_t)k;
     if (k == n - 1 && !cut[k]) wend[info->nchunks - 1] = (uint32_t)n;
 }
-__global__ void oa_work_maxlen(const uint32_t *__restrict__ wstart, const uint32_t *__restrict__ wend,
-                               OrderInfo *__restrict__ info) {
+// longest piece + the two size-class lists the sort kernels walk (order inside a list is irrelevant)
+__global__ void oa_work_classify(const uint32_t *__restrict__ wstart, const uint32_t *__restrict__ wend,
+                                 OrderInfo *__restrict__ info, uint32_t *__restrict__ small, uint32_t *__restrict__ big,
+                                 uint32_t small_cap) {
     const uint32_t nch = info->nchunks;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     uint32_t m = 0;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += gridDim.x * blockDim.x)
-        m = max(m, wend[c] - wstart[c]);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t c0 = blockIdx.x * blockDim.x; c0 < nch; c0 += stride) {      // whole waves iterate together
+        const uint32_t c = c0 + threadIdx.x;
+        const uint32_t len = c < nch ? wend[c] - wstart[c] : 0u;
+        m = max(m, len);
+        const bool is_s = len > 1 && len <= small_cap, is_b = len > small_cap;
+        const unsigned long long ms = __ballot(is_s), mb = __ballot(is_b);
+        uint32_t bs = 0, bb = 0;
+        if (lane == 0) {
+            if (ms) bs = atomicAdd(&info->nsmall, (uint32_t)__popcll(ms));
+            if (mb) bb = atomicAdd(&info->nbig, (uint32_t)__popcll(mb));
+        }
+        bs = __shfl(bs, 0, 64); bb = __shfl(bb, 0, 64);
+        if (is_s) small[bs + (uint32_t)__popcll(ms & lt)] = c;
+        if (is_b) big[bb + (uint32_t)__popcll(mb & lt)] = c;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(&info->maxlen, m);
+    if (lane == 0 && m) atomicMax(&info->maxlen, m);
 }
 
 // One workgroup per piece with LO < len <= CAP: stable LSD radix sort in LDS of a permutation of the
@@ -545,6 +563,7 @@ template <int CAP, int LO, int THREADS>
 __global__ __launch_bounds__(THREADS) void oa_chunk_sort(uint64_t *__restrict__ keys, uint32_t *__restrict__ idx,
                                                          const uint32_t *__restrict__ wstart,
                                                          const uint32_t *__restrict__ wend,
+                                                         const uint32_t *__restrict__ list,
                                                          const OrderInfo *__restrict__ info) {
     constexpr int NW = THREADS / 64, ROWS = CAP / THREADS;
     extern __shared__ uint64_t cs_lds[];
@@ -555,12 +574,13 @@ __global__ __launch_bounds__(THREADS) void oa_chunk_sort(uint64_t *__restrict__ 
     uint32_t *s_wave = cnt + NW * 256;                                       // [NW]
     uint32_t *s_var = s_wave + NW;                                           // [2]
     if (info->maxlen > (uint32_t)CS_BIG) return;
-    const uint32_t nch = info->nchunks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
+    const uint32_t nlist = LO > 1 ? info->nbig : info->nsmall;
+    {
+      for (uint32_t q = blockIdx.x; q < nlist; q += gridDim.x) {
+        const uint32_t c = list[q];
         const uint32_t b = wstart[c], len = wend[c] - b;
-        if (len <= (uint32_t)LO || len > (uint32_t)CAP) continue;
         if (threadIdx.x < 2) s_var[threadIdx.x] = 0;
         __syncthreads();
         const uint64_t k0 = keys[b];
@@ -640,6 +660,7 @@ __global__ __launch_bounds__(THREADS) void oa_chunk_sort(uint64_t *__restrict__ 
             if (i < len) { keys[b + i] = sk[pin[i]]; idx[b + i] = vi[r]; }
         }
         __syncthreads();
+      }
     }
 }
 template <int CAP, int THREADS> constexpr size_t chunk_sort_lds() {
@@ -673,13 +694,14 @@ void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_
     hipLaunchKernelGGL(oa_heads, dim3(ge), dim3(256), 0, st, cut, n, head);
     exclusive_scan_u32(head, wpos, n, &d_info->nchunks, st);
     hipLaunchKernelGGL(oa_work_list, dim3(ge), dim3(256), 0, st, cut, head, wpos, n, d_info, wstart, wend);
+    uint32_t *lsmall = A.get<uint32_t>(n / 2 + 1), *lbig = A.get<uint32_t>(n / CS_SMALL + 1);
     const unsigned gmax = (unsigned)std::min<size_t>((n + 1023) / 1024, 1024);
-    hipLaunchKernelGGL(oa_work_maxlen, dim3(gmax), dim3(256), 0, st, wstart, wend, d_info);
+    hipLaunchKernelGGL(oa_work_classify, dim3(gmax), dim3(256), 0, st, wstart, wend, d_info, lsmall, lbig, (uint32_t)CS_SMALL);
     const unsigned gs = (unsigned)std::min<size_t>((n + 1) / 2, 256 * 12);
-    hipLaunchKernelGGL((oa_chunk_sort<CS_SMALL, 1, 256>), dim3(gs), dim3(256), lds_small, st, keys, idx, wstart, wend, d_info);
+    hipLaunchKernelGGL((oa_chunk_sort<CS_SMALL, 1, 256>), dim3(gs), dim3(256), lds_small, st, keys, idx, wstart, wend, lsmall, d_info);
     if (n > (size_t)CS_SMALL) {
-        const unsigned gb = (unsigned)std::min<size_t>((n + CS_SMALL - 1) / CS_SMALL, 512);
-        hipLaunchKernelGGL((oa_chunk_sort<CS_BIG, CS_SMALL, 1024>), dim3(gb), dim3(1024), lds_big, st, keys, idx, wstart, wend, d_info);
+        const unsigned gb = (unsigned)std::min<size_t>(n / CS_SMALL, 512);
+        hipLaunchKernelGGL((oa_chunk_sort<CS_BIG, CS_SMALL, 1024>), dim3(gb), dim3(1024), lds_big, st, keys, idx, wstart, wend, lbig, d_info);
     }
     IBH_HIP(hipGetLastError());
 }
