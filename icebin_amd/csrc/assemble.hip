@@ -18,6 +18,7 @@
 // CSR structure, dims, wM, Mw and M are bit-identical to the oracle.
 #include "assemble.h"
 #include "prims.h"
+#include <cstdlib>
 
 namespace ibh {
 
@@ -68,8 +69,8 @@ struct XCell {
     double a;
     bool unmasked, inAp, inI;
     int nep;            // GvEp entries actually emitted (0..2)
-    long iE[2];
-    double vE[2];
+    long iE0, iE1;      // scalars, not arrays: dynamically indexed private arrays live in scratch memory
+    double vE0, vE1;
     double rsE;         // sum(GvEp row x): one entry -> v, two -> fl(v0 + v1)
     bool range_error;
 };
@@ -105,6 +106,8 @@ __device__ __forceinline__ XCell load_cell(const RgView &rg, long x) {
     c.inAp = c.unmasked && c.a > 0;               // :208-209
     c.inI = c.unmasked && c.a != 0;               // :186-187 (+ include_zero=false)
     c.nep = 0;
+    c.iE0 = c.iE1 = -1;
+    c.vE0 = c.vE1 = 0.0;
     c.rsE = 0.0;
     c.range_error = false;
     if (WITH_EP && c.unmasked) {
@@ -116,13 +119,16 @@ __device__ __forceinline__ XCell load_cell(const RgView &rg, long x) {
             const int i0 = i1 - 1;
             const double ratio = (elevation - rg.hc[i0]) / (rg.hc[i1] - rg.hc[i0]);
             const double w0 = 1.0 - ratio, w1 = ratio;
-            if (w0 != 0) {
-                const double v = c.a * w0;
-                if (v != 0) { c.iE[c.nep] = c.iA * rg.sA + (long)i0 * rg.sHC; c.vE[c.nep] = v; c.nep++; }
-            }
-            if (w1 != 0) {
-                const double v = c.a * w1;
-                if (v != 0) { c.iE[c.nep] = c.iA * rg.sA + (long)i1 * rg.sHC; c.vE[c.nep] = v; c.nep++; }
+            bool h0 = false, h1 = false;
+            double v0 = 0.0, v1 = 0.0;
+            if (w0 != 0) { v0 = c.a * w0; h0 = v0 != 0; }
+            if (w1 != 0) { v1 = c.a * w1; h1 = v1 != 0; }
+            const long k0 = c.iA * rg.sA + (long)i0 * rg.sHC, k1 = c.iA * rg.sA + (long)i1 * rg.sHC;
+            if (h0) {
+                c.iE0 = k0; c.vE0 = v0; c.nep = 1;
+                if (h1) { c.iE1 = k1; c.vE1 = v1; c.nep = 2; }
+            } else if (h1) {
+                c.iE0 = k1; c.vE0 = v1; c.nep = 1;
             }
         } else {                                             // ELEV_CLASS_INTERP, :146-150 + nearest_1d :43-67
             const int n = rg.nhc;
@@ -135,22 +141,23 @@ __device__ __forceinline__ XCell load_cell(const RgView &rg, long x) {
                 const double d0 = fabs(elevation - rg.hc[i0]), d1 = fabs(rg.hc[i1] - elevation);
                 ih = d0 <= d1 ? i0 : i1;
             }
-            if (c.a != 0) { c.iE[0] = c.iA * rg.sA + (long)ih * rg.sHC; c.vE[0] = c.a; c.nep = 1; }
+            if (c.a != 0) { c.iE0 = c.iA * rg.sA + (long)ih * rg.sHC; c.vE0 = c.a; c.nep = 1; }
         }
-        if (c.nep == 1) c.rsE = c.vE[0];
-        else if (c.nep == 2) c.rsE = c.vE[0] + c.vE[1];
+        if (c.nep == 1) c.rsE = c.vE0;
+        else if (c.nep == 2) c.rsE = c.vE0 + c.vE1;
     }
     return c;
 }
 
 // entries of `list` at cell c: count and sparse keys of kind `key`
-__device__ __forceinline__ int list_entries(const XCell &c, long x, int list, int key, long keys[2]) {
+__device__ __forceinline__ int list_entries(const XCell &c, long x, int list, int key, long &k0, long &k1) {
     int n;
     if (list == LIST_AP) n = c.inAp ? 1 : 0;
     else if (list == LIST_I) n = c.inI ? 1 : 0;
     else n = c.nep;
-    for (int j = 0; j < n; ++j)
-        keys[j] = key == KEY_A ? c.iA : key == KEY_I ? c.iI : key == KEY_X ? x : c.iE[j];
+    const long base = key == KEY_A ? c.iA : key == KEY_I ? c.iI : x;
+    k0 = key == KEY_E ? c.iE0 : base;
+    k1 = key == KEY_E ? c.iE1 : base;
     // an X key is emitted once per list entry; duplicates are harmless to first-seen numbering
     return n;
 }
@@ -187,80 +194,81 @@ struct SetArgs {
     int64_t *to_sparse;         // [capacity] dense -> sparse
     const uint32_t *off;        // [nX] new keys of this set emitted before cell x (after the scan)
     int pkshift;                // this set's flag pair inside pk[x]
+    int e_nhc;                  // > 0: elevation-class keys, first[] is laid out class-fastest (fslot)
+    int e_hc_outer;             // iE = ihc*sHC + iA (sA == 1) rather than iA*sA + ihc (sHC == 1)
+    long e_sA, e_sHC;
+    int dbg_mode;
 };
 __device__ __forceinline__ int old_dense(const SetArgs &a, long key) {
     if (a.ident_n >= 0) return key < a.ident_n ? (int)key : -1;
     return a.tab ? a.tab[key] : -1;
 }
 
-// Keys shared by many cells of a workgroup (atmosphere cells, elevation classes: ~10^2..10^3 cells
-// name each one) are first reduced in an LDS hash table, then flushed with ONE global atomicMin per
-// distinct key and workgroup; device-scope atomics are resolved beyond the per-XCD L2 and a
-// 38.8 M-cell grid would otherwise issue 7.7e7 of them on ~10^5 addresses.  Keys that are
-// (almost) unique per cell (ice cells, exchange cells) go to memory directly.
-constexpr int FH_SLOTS = 1024;          // >= 2 * entries per workgroup (256 cells x 2)
-struct FirstHash { uint32_t key[FH_SLOTS], pos[FH_SLOTS]; };
+// Keys shared by many cells (atmosphere cells, elevation classes: ~10^2..10^3 cells name each one)
+// are de-duplicated inside the wave first: lanes holding the same key elect the lowest lane, whose
+// position is the smallest (positions grow with the lane), and only that lane issues the global
+// atomicMin.  Device-scope atomics are resolved beyond the per-XCD L2; a 38.8 M-cell grid would
+// otherwise issue 7.7e7 of them on ~10^5 addresses.  Keys that are (almost) unique per cell (ice
+// cells, exchange cells) go to memory directly.
 __device__ __forceinline__ bool shared_keys(const SetArgs &a) { return a.key == KEY_A || a.key == KEY_E; }
-
-__device__ __forceinline__ void first_one(const SetArgs &a, const XCell &c, long x, bool valid, FirstHash *h) {
-    long keys[2] = {-1, -1};
-    const int n = valid ? list_entries(c, x, a.list, a.key, keys) : 0;
-    for (int j = 0; j < n; ++j) {
-        if (old_dense(a, keys[j]) >= 0) continue;
-        const uint32_t pos = (uint32_t)(2 * x + j);
-        if (!h) { atomicMin(&a.first[keys[j]], pos); continue; }
-        const uint32_t k = (uint32_t)keys[j];
-        uint32_t slot = (k * 2654435761u) >> 22;                  // top 10 bits
-        for (;;) {
-            const uint32_t prev = atomicCAS(&h->key[slot], 0xffffffffu, k);
-            if (prev == 0xffffffffu || prev == k) { atomicMin(&h->pos[slot], pos); break; }
-            slot = (slot + 1) & (FH_SLOTS - 1);
-        }
-    }
+// Position of a key's entry in first[].  Elevation-class keys iE = iA*sA + ihc*sHC of ONE atmosphere
+// cell are up to a megabyte apart in the natural layout; they are stored class-fastest instead, so the
+// ~40 keys a run of cells touches share a few cache lines.
+__device__ __forceinline__ long fslot(const SetArgs &a, long key) {
+    if (a.e_nhc <= 0) return key;
+    const long ihc = a.e_hc_outer ? key / a.e_sHC : key % a.e_sA;
+    const long iA = a.e_hc_outer ? key % a.e_sHC : key / a.e_sA;
+    return iA * a.e_nhc + ihc;
 }
-__device__ __forceinline__ void first_flush(const SetArgs &a, FirstHash *h) {
-    for (int sl = threadIdx.x; sl < FH_SLOTS; sl += blockDim.x) {
-        const uint32_t k = h->key[sl];
-        if (k != 0xffffffffu) atomicMin(&a.first[k], h->pos[sl]);
+
+__device__ __forceinline__ void first_entry(const SetArgs &a, long key, bool has, uint32_t pos, bool dedupe, int lane) {
+    if (!dedupe) {
+        if (has) atomicMin(&a.first[fslot(a, key)], pos);
+        return;
     }
+    unsigned long long todo = __ballot(has);          // every lane takes part in the ballots
+    bool is_leader = false;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const long k = __shfl(key, leader, 64);
+        const unsigned long long same = __ballot(has && key == k);
+        if (lane == leader) is_leader = true;
+        todo &= ~same;
+    }
+    // ONE atomic instruction for all elected lanes
+    if (is_leader) atomicMin(&a.first[fslot(a, key)], pos);
+}
+__device__ __forceinline__ void first_one(const SetArgs &a, const XCell &c, long x, bool valid) {
+    long k0 = -1, k1 = -1;
+    const int n = valid ? list_entries(c, x, a.list, a.key, k0, k1) : 0;
+    const bool dedupe = shared_keys(a);
+    const int lane = threadIdx.x & 63;
+    first_entry(a, k0, n > 0 && old_dense(a, k0) < 0, (uint32_t)(2 * x), dedupe, lane);
+    if (a.list == LIST_EP)          // uniform: only elevation-class lists have second entries
+        first_entry(a, k1, n > 1 && old_dense(a, k1) < 0, (uint32_t)(2 * x + 1), dedupe, lane);
 }
 template <bool WITH_EP>
 __global__ __launch_bounds__(256) void k_first2(RgView rg, SetArgs a, SetArgs b, int *__restrict__ err_x) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
-    __shared__ FirstHash s_h[2];
     stage_hc<WITH_EP>(rg, s_hc);
-    // sparse extents of shared-key sets fit 32 bits (checked on the host)
-    const bool ha = a.enabled && shared_keys(a), hb = b.enabled && shared_keys(b);
-    if (ha || hb) {
-        for (int i = threadIdx.x; i < 2 * FH_SLOTS; i += blockDim.x) {
-            (&s_h[0].key[0])[i] = 0xffffffffu;
-            (&s_h[1].key[0])[i] = 0xffffffffu;
-        }
-        __syncthreads();
-    }
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
     XCell c;
-    bool valid = false;
+    bool valid = false;                         // no early return: every lane takes part in the ballots
     if (x < rg.nX) {
         c = load_cell<WITH_EP>(rg, x);
         if (WITH_EP && c.range_error) atomicMin(err_x, (int)x);
         else valid = true;
     }
-    if (a.enabled) first_one(a, c, x, valid, ha ? &s_h[0] : nullptr);
-    if (b.enabled) first_one(b, c, x, valid, hb ? &s_h[1] : nullptr);
-    if (ha || hb) {
-        __syncthreads();
-        if (ha) first_flush(a, &s_h[0]);
-        if (hb) first_flush(b, &s_h[1]);
-    }
+    if (a.enabled) first_one(a, c, x, valid);
+    if (b.enabled) first_one(b, c, x, valid);
 }
 
 __device__ __forceinline__ uint32_t flag_one(const SetArgs &a, const XCell &c, long x) {
-    long keys[2];
-    const int n = list_entries(c, x, a.list, a.key, keys);
+    long k0, k1;
+    const int n = list_entries(c, x, a.list, a.key, k0, k1);
     uint32_t f = 0;
-    if (n > 0 && old_dense(a, keys[0]) < 0 && a.first[keys[0]] == (uint32_t)(2 * x)) f |= 1u;
-    if (n > 1 && old_dense(a, keys[1]) < 0 && a.first[keys[1]] == (uint32_t)(2 * x + 1)) f |= 2u;
+    if (n > 0 && old_dense(a, k0) < 0 && a.first[fslot(a, k0)] == (uint32_t)(2 * x)) f |= 1u;
+    if (n > 1 && old_dense(a, k1) < 0 && a.first[fslot(a, k1)] == (uint32_t)(2 * x + 1)) f |= 2u;
     return f;
 }
 // dense id of `key` (any cell may ask): old id, else base + rank of the key's first occurrence
@@ -268,7 +276,7 @@ __device__ __forceinline__ int dense_of(const SetArgs &a, long key, const uint32
     if (!a.enabled) return (int)key;                       // identity over the whole sparse extent
     const int t = old_dense(a, key);
     if (t >= 0) return t;
-    const uint32_t p = a.first[key];
+    const uint32_t p = a.first[fslot(a, key)];
     const uint32_t xf = p >> 1;
     uint32_t r = a.off[xf];
     if (p & 1u) r += (pk[xf] >> a.pkshift) & 1u;           // second entry of its cell: after the first if that one was new too
@@ -278,11 +286,11 @@ __device__ __forceinline__ int dense_of(const SetArgs &a, long key, const uint32
 __device__ __forceinline__ void record_new(const SetArgs &a, const XCell &c, long x, uint32_t pkx) {
     const uint32_t f = (pkx >> a.pkshift) & 3u;
     if (!f) return;
-    long keys[2];
-    (void)list_entries(c, x, a.list, a.key, keys);
+    long k0, k1;
+    (void)list_entries(c, x, a.list, a.key, k0, k1);
     const uint32_t r = a.off[x];
-    if (f & 1u) a.to_sparse[a.base + r] = keys[0];
-    if (f & 2u) a.to_sparse[a.base + r + (f & 1u)] = keys[1];
+    if (f & 1u) a.to_sparse[a.base + r] = k0;
+    if (f & 2u) a.to_sparse[a.base + r + (f & 1u)] = k1;
 }
 
 struct DeviceSet {
@@ -324,6 +332,12 @@ static Numbering number_set_prepare(const RgView &rg, ibh_sparse_set *set, int64
     SetArgs &a = nb.args;
     a.list = list; a.key = key; a.base = ds.n_old; a.to_sparse = ds.to_sparse; a.pkshift = pkshift;
     a.ident_n = -1; a.tab = nullptr;
+    a.e_nhc = 0; a.e_hc_outer = 0; a.e_sA = rg.sA; a.e_sHC = rg.sHC;
+    a.dbg_mode = 0;
+    if (key == KEY_E) {        // regridder creation admits exactly these two stride patterns
+        if (rg.sA == 1 && rg.sHC == rg.nA) { a.e_nhc = rg.nhc; a.e_hc_outer = 1; }
+        else if (rg.sHC == 1 && rg.sA == rg.nhc) { a.e_nhc = rg.nhc; a.e_hc_outer = 0; }
+    }
     if (ds.n_old) {
         if (set->identity) {
             a.ident_n = ds.n_old;
@@ -365,42 +379,41 @@ static void number_set_finish(Numbering &nb, uint32_t n_new, hipStream_t st) {
 }
 
 // ---- contributions ---------------------------------------------------------------------------
-__device__ __forceinline__ int contributions(const XCell &c, long x, const MatSpec &s, long rkey[2], long ckey[2],
-                                             double t[2]) {
+struct Contrib { long r0, r1, c0, c1; double t0, t1; };
+__device__ __forceinline__ int contributions(const XCell &c, long x, const MatSpec &s, Contrib &o) {
     if (s.need_list == LIST_I && !c.inI) return 0;
     if (s.need_list == LIST_AP && !c.inAp) return 0;
     switch (s.term) {
         case TERM_PLAIN_A:
             if (!c.inAp) return 0;
-            rkey[0] = s.row_key == KEY_X ? x : c.iA; ckey[0] = s.col_key == KEY_X ? x : c.iA; t[0] = c.a;
+            o.r0 = s.row_key == KEY_X ? x : c.iA; o.c0 = s.col_key == KEY_X ? x : c.iA; o.t0 = c.a;
             return 1;
         case TERM_PLAIN_E:
-            for (int j = 0; j < c.nep; ++j) {
-                rkey[j] = s.row_key == KEY_X ? x : c.iE[j]; ckey[j] = s.col_key == KEY_X ? x : c.iE[j]; t[j] = c.vE[j];
-            }
+            o.r0 = s.row_key == KEY_X ? x : c.iE0; o.c0 = s.col_key == KEY_X ? x : c.iE0; o.t0 = c.vE0;
+            o.r1 = s.row_key == KEY_X ? x : c.iE1; o.c1 = s.col_key == KEY_X ? x : c.iE1; o.t1 = c.vE1;
             return c.nep;
         case TERM_A_A: {
             if (!c.inAp) return 0;
             const double sinv = 1.0 / c.a;
             const double l = c.a * sinv;
-            rkey[0] = s.row_key == KEY_A ? c.iA : c.iI; ckey[0] = s.col_key == KEY_A ? c.iA : c.iI; t[0] = l * c.a;
+            o.r0 = s.row_key == KEY_A ? c.iA : c.iI; o.c0 = s.col_key == KEY_A ? c.iA : c.iI; o.t0 = l * c.a;
             return 1;
         }
         case TERM_E_A: {      // rows E; cols I (EvI) or A (EvA)
             const double sinv = 1.0 / c.a;
-            for (int j = 0; j < c.nep; ++j) {
-                const double l = c.vE[j] * sinv;
-                rkey[j] = c.iE[j]; ckey[j] = s.col_key == KEY_A ? c.iA : c.iI; t[j] = l * c.a;
-            }
+            const long ck = s.col_key == KEY_A ? c.iA : c.iI;
+            const double l0 = c.vE0 * sinv, l1 = c.vE1 * sinv;
+            o.r0 = c.iE0; o.c0 = ck; o.t0 = l0 * c.a;
+            o.r1 = c.iE1; o.c1 = ck; o.t1 = l1 * c.a;
             return c.nep;
         }
         default: {            // TERM_A_E: cols E; rows I (IvE) or A (AvE)
             if (c.nep == 0) return 0;
             const double sinv = 1.0 / c.rsE;
             const double l = c.a * sinv;
-            for (int j = 0; j < c.nep; ++j) {
-                rkey[j] = s.row_key == KEY_A ? c.iA : c.iI; ckey[j] = c.iE[j]; t[j] = l * c.vE[j];
-            }
+            const long rk = s.row_key == KEY_A ? c.iA : c.iI;
+            o.r0 = rk; o.c0 = c.iE0; o.t0 = l * c.vE0;
+            o.r1 = rk; o.c1 = c.iE1; o.t1 = l * c.vE1;
             return c.nep;
         }
     }
@@ -417,8 +430,8 @@ __global__ void k_flag2(RgView rg, SetArgs a, SetArgs b, MatSpec s, uint32_t *__
     if (!(WITH_EP && c.range_error)) {
         if (a.enabled) v |= flag_one(a, c, x) << a.pkshift;
         if (b.enabled) v |= flag_one(b, c, x) << b.pkshift;
-        long rk[2], ck[2]; double t[2];
-        v |= (uint32_t)contributions(c, x, s, rk, ck, t) << 4;
+        Contrib o;
+        v |= (uint32_t)contributions(c, x, s, o) << 4;
     }
     pk[x] = v;
 }
@@ -435,13 +448,18 @@ __global__ void k_contrib_emit(RgView rg, MatSpec s, SetArgs a, SetArgs b, const
     const XCell c = load_cell<WITH_EP>(rg, x);
     if (a.enabled) record_new(a, c, x, pkx);
     if (b.enabled) record_new(b, c, x, pkx);
-    long rk[2], ck[2]; double t[2];
-    const int n = contributions(c, x, s, rk, ck, t);
+    Contrib o;
+    const int n = contributions(c, x, s, o);
     const uint32_t p = pos[x];
-    for (int j = 0; j < n; ++j) {
-        keys[p + j] = ((uint64_t)(uint32_t)dense_of(a, rk[j], pk) << 32) | (uint32_t)dense_of(b, ck[j], pk);
-        idx[p + j] = p + j;
-        term[p + j] = t[j];
+    if (n > 0) {
+        keys[p] = ((uint64_t)(uint32_t)dense_of(a, o.r0, pk) << 32) | (uint32_t)dense_of(b, o.c0, pk);
+        idx[p] = p;
+        term[p] = o.t0;
+    }
+    if (n > 1) {
+        keys[p + 1] = ((uint64_t)(uint32_t)dense_of(a, o.r1, pk) << 32) | (uint32_t)dense_of(b, o.c1, pk);
+        idx[p + 1] = p + 1;
+        term[p + 1] = o.t1;
     }
 }
 

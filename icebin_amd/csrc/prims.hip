@@ -714,7 +714,7 @@ bool adaptive_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uin
     IBH_HIP(hipMemcpyAsync(&h, d_info, sizeof(h), hipMemcpyDeviceToHost, st));
     IBH_HIP(hipStreamSynchronize(st));
     static const bool dbg = getenv("IBH_DEBUG_SORT") != nullptr;
-    if (dbg) fprintf(stderr, "[ibh sort] n=%zu flags=%u pieces=%u maxlen=%u lo_bits=%d hi_bits=%d\n", n, h.flags, h.nchunks, h.maxlen, lo_bits, hi_bits);
+    if (dbg) fprintf(stderr, "[ibh sort] n=%zu flags=%u pieces=%u maxlen=%u small=%u big=%u lo_bits=%d hi_bits=%d\n", n, h.flags, h.nchunks, h.maxlen, h.nsmall, h.nbig, lo_bits, hi_bits);
     if (!(h.flags & ORD_FULL_DEC) || h.maxlen <= (uint32_t)CS_BIG) return false;      // in order / pieces sorted in place
     KeyField f[2]; int nf = 0;
     if (lo_bits > 0 && (h.flags & ORD_LO_DEC)) f[nf++] = KeyField{0, lo_bits};        // else: stable sort by the high field suffices
