@@ -451,16 +451,17 @@ __global__ void k_contrib_emit(RgView rg, MatSpec s, SetArgs a, SetArgs b, const
     Contrib o;
     const int n = contributions(c, x, s, o);
     const uint32_t p = pos[x];
-    if (n > 0) {
-        keys[p] = ((uint64_t)(uint32_t)dense_of(a, o.r0, pk) << 32) | (uint32_t)dense_of(b, o.c0, pk);
-        idx[p] = p;
-        term[p] = o.t0;
-    }
+    if (n == 0) return;
+    uint64_t q0 = ((uint64_t)(uint32_t)dense_of(a, o.r0, pk) << 32) | (uint32_t)dense_of(b, o.c0, pk);
     if (n > 1) {
-        keys[p + 1] = ((uint64_t)(uint32_t)dense_of(a, o.r1, pk) << 32) | (uint32_t)dense_of(b, o.c1, pk);
-        idx[p + 1] = p + 1;
-        term[p + 1] = o.t1;
+        // The two entries of a cell name different elevation classes, so they are never summed
+        // together and may be emitted in either order: ascending key keeps the sequence closer to
+        // sorted (the first-seen class numbering is not monotone in the class index).
+        uint64_t q1 = ((uint64_t)(uint32_t)dense_of(a, o.r1, pk) << 32) | (uint32_t)dense_of(b, o.c1, pk);
+        if (q1 < q0) { const uint64_t tq = q0; q0 = q1; q1 = tq; const double tt = o.t0; o.t0 = o.t1; o.t1 = tt; }
+        keys[p + 1] = q1; idx[p + 1] = p + 1; term[p + 1] = o.t1;
     }
+    keys[p] = q0; idx[p] = p; term[p] = o.t0;
 }
 
 // ---- sorted contributions -> unique CSR entries ------------------------------------------------

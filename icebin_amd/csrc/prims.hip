@@ -262,19 +262,27 @@ __global__ __launch_bounds__(RS_T) void rs_hist(const uint64_t *__restrict__ key
 }
 
 // Wave w of the block owns the contiguous chunk [w*64*RS_I, (w+1)*64*RS_I) of the tile and walks
-// it in rows of 64 keys, so (wave, row, lane) order == global order and ranks are stable.
+// it in rows of 64 keys, so (wave, row, lane) order == global order and ranks are stable.  The tile
+// is first put in digit order in LDS and then written out: consecutive threads store consecutive
+// addresses inside each digit's run (a 4096-key tile over 256 digits gives ~128-byte runs) instead
+// of scattering single 12-byte pairs.
 __global__ __launch_bounds__(RS_T) void rs_scatter(const uint64_t *__restrict__ keys_in,
                                                    const uint32_t *__restrict__ vals_in,
                                                    uint64_t *__restrict__ keys_out,
                                                    uint32_t *__restrict__ vals_out, size_t n, int shift,
                                                    int nbits, const uint32_t *__restrict__ table, int nblocks) {
+    __shared__ uint64_t sk[RS_TILE];
+    __shared__ uint32_t sv[RS_TILE];
     __shared__ uint32_t cnt[RS_T / 64][256];
+    __shared__ uint32_t gbase[256];          // global position of the digit's run minus its start inside the tile
+    __shared__ uint32_t s_wave[RS_T / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t mask = (1u << nbits) - 1u;
     for (int i = threadIdx.x; i < (RS_T / 64) * 256; i += RS_T) (&cnt[0][0])[i] = 0;
     __syncthreads();
 
-    const size_t wbase = (size_t)blockIdx.x * RS_TILE + (size_t)wave * 64 * RS_I;
+    const size_t tbase = (size_t)blockIdx.x * RS_TILE;
+    const size_t wbase = tbase + (size_t)wave * 64 * RS_I;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     volatile uint32_t *wc = cnt[wave];
     uint64_t key[RS_I];
@@ -302,9 +310,14 @@ __global__ __launch_bounds__(RS_T) void rs_scatter(const uint64_t *__restrict__ 
         rank[i] = old + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
-    // digit d: global start of this block's run, then running offsets over the 4 waves
-    if (threadIdx.x <= mask) {
-        uint32_t run = table[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    // digit d (thread d): start of its run inside the tile, then running offsets over the 4 waves
+    {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < RS_T / 64; ++w) tot += cnt[w][threadIdx.x];
+        uint32_t all;
+        uint32_t run = block_excl_scan<RS_T>(tot, s_wave, all);
+        gbase[threadIdx.x] = threadIdx.x <= mask ? table[(size_t)threadIdx.x * nblocks + blockIdx.x] - run : 0u;
 #pragma unroll
         for (int w = 0; w < RS_T / 64; ++w) {
             const uint32_t c = cnt[w][threadIdx.x];
@@ -318,9 +331,21 @@ __global__ __launch_bounds__(RS_T) void rs_scatter(const uint64_t *__restrict__ 
         const size_t idx = wbase + (size_t)i * 64 + lane;
         if (idx < n) {
             const uint32_t d = (uint32_t)(key[i] >> shift) & mask;
-            const uint32_t pos = cnt[wave][d] + rank[i];
-            keys_out[pos] = key[i];
-            vals_out[pos] = val[i];
+            const uint32_t lp = cnt[wave][d] + rank[i];
+            sk[lp] = key[i];
+            sv[lp] = val[i];
+        }
+    }
+    __syncthreads();
+    const uint32_t ntile = (uint32_t)(n - tbase < (size_t)RS_TILE ? n - tbase : (size_t)RS_TILE);
+#pragma unroll
+    for (int i = 0; i < RS_I; ++i) {
+        const uint32_t lp = (uint32_t)i * RS_T + threadIdx.x;
+        if (lp < ntile) {
+            const uint64_t k = sk[lp];
+            const uint32_t pos = gbase[(uint32_t)(k >> shift) & mask] + lp;
+            keys_out[pos] = k;
+            vals_out[pos] = sv[lp];
         }
     }
 }
