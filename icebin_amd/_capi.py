@@ -82,6 +82,7 @@ _SIGS = {
     "ibh_weighted_last_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "ibh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "ibh_release_cached_memory": (C.c_int, []),
+    "ibh_selftest_sort": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -7,6 +7,7 @@
 
 #include "assemble.h"
 #include "common.h"
+#include "prims.h"
 
 namespace ibh {
 
@@ -475,6 +476,29 @@ int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen) {
     return guarded([&] {
         IBH_CHECK(w && buf && buflen > 0, "bad argument");
         snprintf(buf, (size_t)buflen, "%s", w->last_kernel == 1 ? "rowblock" : w->last_kernel == 2 ? "shortrow" : "none");
+    });
+}
+int ibh_selftest_sort(const uint64_t *keys, int64_t n, int lo_bits, int hi_bits, uint32_t *perm_out, int *path_out) {
+    return guarded([&] {
+        IBH_CHECK(n >= 0 && n < (1ll << 31) && (n == 0 || (keys && perm_out)) && path_out, "bad arguments");
+        Arena &A = arena();
+        A.reset();
+        *path_out = 0;
+        if (n == 0) return;
+        hipStream_t st = nullptr;
+        uint64_t *k = A.get<uint64_t>((size_t)n), *k2 = A.get<uint64_t>((size_t)n);
+        uint32_t *v = A.get<uint32_t>((size_t)n), *v2 = A.get<uint32_t>((size_t)n);
+        OrderInfo *info = A.get<OrderInfo>(1);
+        IBH_HIP(hipMemcpyAsync(k, keys, sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+        std::vector<uint32_t> iota((size_t)n);
+        for (int64_t i = 0; i < n; ++i) iota[(size_t)i] = (uint32_t)i;
+        IBH_HIP(hipMemcpyAsync(v, iota.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+        const bool alt = adaptive_sort_pairs(k, k2, v, v2, (size_t)n, lo_bits, hi_bits, info, st);
+        OrderInfo h{};
+        if (n >= 2) IBH_HIP(hipMemcpyAsync(&h, info, sizeof(h), hipMemcpyDeviceToHost, st));
+        IBH_HIP(hipMemcpyAsync(perm_out, alt ? v2 : v, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+        IBH_HIP(hipStreamSynchronize(st));
+        *path_out = !(h.flags & ORD_FULL_DEC) ? 0 : h.maxlen <= (uint32_t)CS_BIG ? 1 : 2;
     });
 }
 int ibh_release_cached_memory(void) {

@@ -396,7 +396,6 @@ bool radix_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32
 //      skipping the low field when it is already non-decreasing along the sequence.
 // Everything is integer work; the result is identical to radix_sort_pairs by construction.
 constexpr int OA_T = 256, OA_I = 8, OA_TILE = OA_T * OA_I;
-constexpr int CS_SMALL = 2048, CS_BIG = 8192;
 
 __device__ __forceinline__ uint64_t u64max(uint64_t a, uint64_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint64_t u64min(uint64_t a, uint64_t b) { return a < b ? a : b; }

@@ -191,6 +191,12 @@ int ibh_weighted_device_view_get(const ibh_weighted *w, ibh_weighted_device_view
 int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow" */
 int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
 int ibh_set_tuning(const char *key, int value);
+/* Diagnostic: run the assembly's ordering primitive (order analysis + independent-piece LDS sort,
+ * falling back to the device-wide radix sort) on host keys with payload 0..n-1 and return the
+ * resulting permutation, which must equal a stable sort by key.  key = (hi field << 32) | lo field,
+ * fields below 2^hi_bits / 2^lo_bits.  *path_out: 0 already ordered, 1 pieces sorted in LDS,
+ * 2 device-wide radix sort.  Used by tests/test_gpu_parity.py. */
+int ibh_selftest_sort(const uint64_t *keys, int64_t n, int lo_bits, int hi_bits, uint32_t *perm_out, int *path_out);
 /* Return the per-thread workspace and all cached device blocks to the driver (the library keeps
  * freed device memory for reuse: a coupler rebuilds the same matrices every step). */
 int ibh_release_cached_memory(void);

@@ -510,3 +510,79 @@ def test_apply_is_graph_capturable():
         yr = oA.apply(xr)
         assert rel_linf(y.cpu().numpy(), yr) <= FIELD_RTOL
         assert rel_linf(z.cpu().numpy(), oI.apply(yr)) <= 10 * FIELD_RTOL
+
+
+# ---- the ordering primitive behind the assembly (prims.hip "adaptive ordering") ---------------------
+def _selftest_sort(keys, lo_bits, hi_bits):
+    import ctypes as C
+    from icebin_amd import _capi
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    perm = np.empty(len(keys), np.uint32)
+    path = C.c_int(-1)
+    _capi.check(_capi.lib().ibh_selftest_sort(keys.ctypes.data, len(keys), lo_bits, hi_bits, perm.ctypes.data, C.byref(path)))
+    return perm, path.value
+
+
+def _pieces(rng, n, max_piece, lo_bits, disorder):
+    """Keys whose high field grows piece by piece (cuts between pieces); inside a piece the low
+    field is ascending except for a `disorder` fraction of out-of-place entries and duplicates."""
+    keys = np.empty(n, np.uint64)
+    k, hi = 0, 0
+    while k < n:
+        m = int(min(n - k, rng.integers(1, max_piece + 1)))
+        lo = np.sort(rng.integers(0, 1 << lo_bits, m, dtype=np.uint64))
+        j = rng.random(m) < disorder
+        lo[j] = rng.integers(0, 1 << lo_bits, int(j.sum()), dtype=np.uint64)
+        nrows = int(rng.integers(1, 4))               # a piece may span a few rows, interleaved
+        keys[k:k + m] = ((hi + rng.integers(0, nrows, m).astype(np.uint64)) << np.uint64(32)) | lo
+        hi += nrows
+        k += m
+    return keys
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["empty", "one", "two", "sorted", "all_equal", "small_pieces", "mid_pieces",
+                                  "cap_piece", "over_cap", "random", "lo_sorted_hi_random", "tile_edges"])
+def test_ordering_primitive_equals_stable_sort(case):
+    rng = np.random.default_rng(20240501)
+    lo_bits, hi_bits, want_path = 20, 12, None
+    if case == "empty":
+        keys = np.zeros(0, np.uint64)
+    elif case == "one":
+        keys = np.array([5], np.uint64)
+    elif case == "two":
+        keys = np.array([7, 3], np.uint64); want_path = 1
+    elif case == "sorted":
+        keys = np.sort(rng.integers(0, 1 << 20, 300001, dtype=np.uint64)); want_path = 0
+    elif case == "all_equal":
+        keys = np.full(100000, 9, np.uint64); want_path = 0
+    elif case == "small_pieces":
+        keys = _pieces(rng, 500000, 300, lo_bits, 0.1); want_path = 1
+    elif case == "mid_pieces":
+        keys = _pieces(rng, 700000, 7000, lo_bits, 0.05); want_path = 1
+    elif case == "cap_piece":       # one piece of exactly 8192 and one of 2048 (the size-class edges), rest in order
+        a = np.arange(8192, dtype=np.uint64)[::-1].copy()
+        b = (np.uint64(1) << np.uint64(32)) | np.arange(2048, dtype=np.uint64)[::-1]
+        c = (np.uint64(2) << np.uint64(32)) | np.arange(5000, dtype=np.uint64)
+        keys = np.concatenate([a, b, c]); want_path = 1
+    elif case == "over_cap":        # a piece of 8193 -> nothing may be touched by the piece kernels; radix sort
+        a = np.arange(8193, dtype=np.uint64)[::-1].copy()
+        b = (np.uint64(1) << np.uint64(32)) | np.array([3, 1, 2], np.uint64)
+        keys = np.concatenate([a, b]); want_path = 2
+    elif case == "random":
+        keys = (rng.integers(0, 1 << hi_bits, 1 << 20, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 1 << lo_bits, 1 << 20, dtype=np.uint64)
+        want_path = 2
+    elif case == "lo_sorted_hi_random":   # the low field never decreases: only the high field is radix-sorted
+        n = 400000
+        keys = (rng.integers(0, 1 << hi_bits, n, dtype=np.uint64) << np.uint64(32)) | np.sort(rng.integers(0, 1 << lo_bits, n, dtype=np.uint64))
+        want_path = 2
+    else:                           # disorder straddling the 2048-element analysis tiles
+        keys = np.arange(3 * 2048 + 5, dtype=np.uint64)
+        for e in (2047, 2048, 4095, 4096, 6143):
+            keys[e], keys[e + 1] = keys[e + 1], keys[e]
+        want_path = 1
+    perm, path = _selftest_sort(keys, lo_bits, hi_bits)
+    ref = np.argsort(keys, kind="stable").astype(np.uint32)
+    assert np.array_equal(perm, ref)
+    if want_path is not None:
+        assert path == want_path
