@@ -422,11 +422,13 @@ int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nv
         IBH_CHECK(nvar >= 0 && (nvar == 0 || (A_b && B_b)), "bad arguments");
         IBH_CHECK(lda >= w->ncol && ldb >= w->nrow, "leading dimensions too small");
         if (nvar == 0) return;
-        DevBuf<double> dA((size_t)nvar * (size_t)w->ncol), dB((size_t)nvar * (size_t)w->nrow);
-        IBH_HIP(hipMemcpy2DAsync(dA.p, sizeof(double) * (size_t)w->ncol, A_b, sizeof(double) * (size_t)lda,
+        // device staging with 512-byte-aligned field planes (whole-line wave stores, see spmm.hip shortrow)
+        const size_t dlda = ((size_t)w->ncol + 63) & ~size_t(63), dldb = ((size_t)w->nrow + 63) & ~size_t(63);
+        DevBuf<double> dA((size_t)nvar * dlda), dB((size_t)nvar * dldb);
+        IBH_HIP(hipMemcpy2DAsync(dA.p, sizeof(double) * dlda, A_b, sizeof(double) * (size_t)lda,
                                  sizeof(double) * (size_t)w->ncol, (size_t)nvar, hipMemcpyHostToDevice, nullptr));
-        spmm_launch(w, dA.p, nvar, w->ncol, dB.p, w->nrow, fill, force_conservation, nullptr);
-        IBH_HIP(hipMemcpy2DAsync(B_b, sizeof(double) * (size_t)ldb, dB.p, sizeof(double) * (size_t)w->nrow,
+        spmm_launch(w, dA.p, nvar, (int64_t)dlda, dB.p, (int64_t)dldb, fill, force_conservation, nullptr);
+        IBH_HIP(hipMemcpy2DAsync(B_b, sizeof(double) * (size_t)ldb, dB.p, sizeof(double) * dldb,
                                  sizeof(double) * (size_t)w->nrow, (size_t)nvar, hipMemcpyDeviceToHost, nullptr));
         IBH_HIP(hipStreamSynchronize(nullptr));
     });

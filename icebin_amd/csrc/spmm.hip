@@ -273,25 +273,37 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 
 constexpr int SR_THREADS = 256;
 
-template <bool NT, int G>
+// REALIGN: the result planes Y[f, :] do not start on 64-byte lines (odd leading dimension: the
+// reference's A_b(nvar, n) is contiguous, so ldy = nrow_d).  A wave's 512-byte store would then
+// straddle nine lines and leave two of them partially written, to be completed by the neighbouring
+// wave: measured 4.0 instead of 6.0 TB/s of store bandwidth on this chip.  The workgroup therefore
+// computes 256 rows but OWNS, per plane, the line-aligned run of <= 255 rows that starts at the first
+// 64-byte boundary at or after its first row (consecutive workgroups advance by 248 rows, so the
+// runs tile the plane exactly); values cross lanes through LDS and every wave stores whole lines.
+constexpr int SR_STEP = SR_THREADS - 8;
+template <bool NT, int G, bool REALIGN>
 __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
     const double *__restrict__ X, long ldx, double *__restrict__ Y, long ldy, int nrow, int nf, int fper,
     const double *__restrict__ wM, double fill)
 {
+    __shared__ double s_y[REALIGN ? G : 1][SR_THREADS];
     // 1-D grid, field chunk fastest, contiguous ranges per XCD: the nfy workgroups that walk the same
     // 256 rows (one per field chunk) are neighbours on one XCD, so rowptr/colind/vals/wM of those rows
     // come from HBM once and from that XCD's L2 for the other chunks.
     const int nfy = (nf + fper - 1) / fper;
     const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
     const int rb = logical / nfy, fy = logical - rb * nfy;
-    const int r = rb * SR_THREADS + threadIdx.x;
-    if (r >= nrow) return;
+    const int rbase = rb * (REALIGN ? SR_STEP : SR_THREADS);
+    const int r = rbase + threadIdx.x;
+    const bool live = r < nrow;
+    if (!REALIGN && !live) return;
     const int fbeg = fy * fper;
     const int fend = min(nf, fbeg + fper);
-    const int beg = rowptr[r], end = rowptr[r + 1];
+    int beg = 0, end = 0;
+    bool dead = false;
+    if (live) { beg = rowptr[r]; end = rowptr[r + 1]; dead = wM[r] == 0.0; }
     const int n = end - beg;
-    const bool dead = wM[r] == 0.0;
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
     if (n > 0) { c0 = colind[beg]; v0 = vals[beg]; }
@@ -315,14 +327,36 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
             if (n > 2) a = fma(v2, xf[c2], a);
             if (n > 3) a = fma(v3, xf[c3], a);
             for (int k = beg + 4; k < end; ++k) a = fma(vals[k], xf[colind[k]], a);
-            acc[g] = a;
+            acc[g] = dead ? fill : a;
         }
+        if (!REALIGN) {
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-            if (f0 + g < fend) {
-                if (NT) __builtin_nontemporal_store(dead ? fill : acc[g], &Y[(long)(f0 + g) * ldy + r]);
-                else Y[(long)(f0 + g) * ldy + r] = dead ? fill : acc[g];
+            for (int g = 0; g < G; ++g)
+                if (f0 + g < fend) {
+                    if (NT) __builtin_nontemporal_store(acc[g], &Y[(long)(f0 + g) * ldy + r]);
+                    else Y[(long)(f0 + g) * ldy + r] = acc[g];
+                }
+        } else {
+            if (f0 != fbeg) __syncthreads();               // the previous group's values have been read
+#pragma unroll
+            for (int g = 0; g < G; ++g) s_y[g][threadIdx.x] = acc[g];
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (f0 + g >= fend) break;
+                double *yf = Y + (long)(f0 + g) * ldy;
+                // first row >= rbase whose address is a multiple of 64 bytes (the very first run starts at row 0)
+                const long a8 = (long)(reinterpret_cast<uintptr_t>(yf) >> 3);
+                const int s0 = rb == 0 ? 0 : rbase + (int)((-(a8 + rbase)) & 7);
+                int s1 = rbase + SR_STEP + (int)((-(a8 + rbase + SR_STEP)) & 7);
+                if (s1 > nrow || rbase + SR_STEP >= nrow) s1 = nrow;
+                const int rr = s0 + (int)threadIdx.x;
+                if (rr < s1) {
+                    const double v = s_y[g][rr - rbase];
+                    if (NT) __builtin_nontemporal_store(v, &yf[rr]); else yf[rr] = v;
+                }
             }
+        }
     }
 }
 
@@ -449,20 +483,31 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
         else IBH_L(1, 4, 4);
 #undef IBH_L
     } else {
-        // fields per thread: small chunks = many short threads, which is what keeps enough stores in
-        // flight (measured: 4 for ~1 entry per row, 8 for 2-3)
-        int fper = get_tuning("shortrow_fper", (double)w->nnz <= 1.5 * (double)w->nrow ? 4 : 8);
+        // fields per thread.  Small problems (5 km: 76 k rows) are latency-bound and want many short
+        // threads (4 fields for ~1 entry per row, 8 for 2-3); at 1 km (1.9 M rows) the stores dominate
+        // and 16-32 fields per thread amortise the row's CSR reads (measured, scratch/tune_shortrow.py).
+        const bool one_entry = (double)w->nnz <= 1.5 * (double)w->nrow;
+        const bool big = w->nrow >= (1 << 19);
+        int fper = get_tuning("shortrow_fper", big ? (one_entry ? 16 : 32) : (one_entry ? 4 : 8));
         if (fper < 1) fper = 1;
-        const long nblk = (long)ceil_div(w->nrow, SR_THREADS) * ceil_div(nvar, fper);
+        // planes of B that do not start on 64-byte lines are re-aligned through LDS (see the kernel)
+        const bool realign = get_tuning("shortrow_realign", -1) >= 0 ? get_tuning("shortrow_realign", -1) != 0
+                           : ((reinterpret_cast<uintptr_t>(dB) & 63) != 0 || (ldb & 7) != 0) && w->nrow >= (1 << 18);   // below: latency-bound, the two extra barriers cost more
+        const long nblk = (long)ceil_div(w->nrow, realign ? SR_STEP : SR_THREADS) * ceil_div(nvar, fper);
         IBH_CHECK(nblk < (1l << 31), "spmm grid too large (%ld blocks)", nblk);
         dim3 grid((unsigned)nblk);
-        const int g = get_tuning("shortrow_group", fper >= 32 ? 32 : fper >= 16 ? 16 : fper >= 8 ? 8 : 4);
+        const int g = get_tuning("shortrow_group", big ? (one_entry ? 8 : 4) : fper >= 8 ? 8 : 4);
 #define IBH_SR(NT, GG)                                                                                          \
-    hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
-                       w->val.p, dA, (long)lda, dB, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill)
+    do {                                                                                                        \
+        if (realign)                                                                                            \
+            hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, true>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
+                               w->val.p, dA, (long)lda, dB, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill);     \
+        else                                                                                                    \
+            hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, false>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
+                               w->val.p, dA, (long)lda, dB, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill);     \
+    } while (0)
         const bool nt = get_tuning("shortrow_nt", 1) != 0;
-        if (g >= 32) { if (nt) IBH_SR(true, 32); else IBH_SR(false, 32); }
-        else if (g >= 16) { if (nt) IBH_SR(true, 16); else IBH_SR(false, 16); }
+        if (g >= 16) { if (nt) IBH_SR(true, 16); else IBH_SR(false, 16); }
         else if (g >= 8) { if (nt) IBH_SR(true, 8); else IBH_SR(false, 8); }
         else { if (nt) IBH_SR(true, 4); else IBH_SR(false, 4); }
 #undef IBH_SR

@@ -586,3 +586,32 @@ def test_ordering_primitive_equals_stable_sort(case):
     assert np.array_equal(perm, ref)
     if want_path is not None:
         assert path == want_path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["IvA", "IvE"])
+def test_shortrow_realigned_result_planes(name):
+    """Result planes that do not start on 64-byte lines go through the LDS re-alignment of the
+    shortrow kernel (spmm.hip): same arithmetic, so bit-identical to the plain store path, for every
+    combination of odd leading dimension and base offset; nothing outside the planes is written."""
+    import torch
+    from icebin_amd.linear import set_tuning
+    g = syn.make_grids("g5")
+    W = icebin_amd.from_synthetic(g).regrid_matrices("greenland", syn.dome_elevmask(g)).matrix(name)
+    nf, nrow, ncol = 7, W.nrow_d, W.ncol_d
+    x = torch.from_numpy(syn.fields(nf, ncol)).cuda()
+    try:
+        set_tuning("shortrow_realign", 0)
+        ref = W.apply_device(x, out=torch.empty((nf, nrow), dtype=torch.float64, device="cuda")).cpu().numpy()
+        set_tuning("shortrow_realign", 1)
+        for ld in (nrow, nrow + 1, nrow + 3, nrow + 8):
+            for off in (0, 1, 5):
+                buf = torch.full((nf * ld + 16,), -7.0, dtype=torch.float64, device="cuda")
+                out = buf[off:off + nf * ld].view(nf, ld)[:, :nrow]
+                W.apply_device(x, out=out)
+                got = buf.cpu().numpy()
+                planes = got[off:off + nf * ld].reshape(nf, ld)
+                assert np.array_equal(planes[:, :nrow], ref, equal_nan=True)
+                assert np.all(planes[:, nrow:] == -7.0) and np.all(got[:off] == -7.0) and np.all(got[off + nf * ld:] == -7.0)
+    finally:
+        set_tuning("shortrow_realign", -1)
