@@ -64,11 +64,14 @@ class FieldShardedApply:
         self.comm = torch.cuda.Stream(device=device)
         nl, nrow = self.f1 - self.f0, weighted.nrow_d
         self.nl, self.nrow = nl, nrow
-        self._y = [torch.empty((self.G, nl, nrow), dtype=torch.float64, device=device) for _ in range(2)]
+        # field planes padded to 512 bytes: whole-line wave stores (spmm.hip, shortrow) and the padded
+        # buffers stay contiguous, which is what all_gather_into_tensor needs
+        ld = self.ld = (nrow + 63) // 64 * 64 if self.world == 1 or nf_total % self.world == 0 else nrow
+        self._y = [torch.empty((self.G, nl, ld), dtype=torch.float64, device=device) for _ in range(2)]
         if self.G == 1:
-            self._out = [torch.empty((nf_total, nrow), dtype=torch.float64, device=device) for _ in range(2)]
+            self._out = [torch.empty((nf_total, ld), dtype=torch.float64, device=device) for _ in range(2)]
         else:
-            self._out = [torch.empty((self.world, self.G, nl, nrow), dtype=torch.float64, device=device) for _ in range(2)]
+            self._out = [torch.empty((self.world, self.G, nl, ld), dtype=torch.float64, device=device) for _ in range(2)]
         self._done = [torch.cuda.Event() for _ in range(2)]
         self._free = [torch.cuda.Event() for _ in range(2)]
         self._used = [False, False]
@@ -97,7 +100,7 @@ class FieldShardedApply:
             self._cur_ptr = self._C.c_void_p(cur.cuda_stream)
             if self._used[g]:
                 cur.wait_event(self._free[g])       # this group's buffers are still being gathered
-        rc = self._fn(self._h, x_ptr, self.nl, ldx, self._yp[g][slot], self.nrow, fill, 0, self._cur_ptr)
+        rc = self._fn(self._h, x_ptr, self.nl, ldx, self._yp[g][slot], self.ld, fill, 0, self._cur_ptr)
         if rc != 0:
             self._check(rc)
         self._i = i + 1
@@ -110,7 +113,7 @@ class FieldShardedApply:
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self._done[g])
             if self.G == 1:
-                all_gather_fields(self._y[g][0], self.nf_total, self.group, out=self._out[g])
+                all_gather_fields(self._y[g][0], self.nf_total, self.group, out=self._out[g])      # planes of width ld
             else:
                 dist.all_gather_into_tensor(self._out[g], self._y[g], group=self.group)
             self._free[g].record(self.comm)
@@ -130,5 +133,5 @@ class FieldShardedApply:
     def result(self, g, slot):
         """[world, nf_local, nrow] view (rank-major == field-major) of the gathered fields of one apply."""
         if self.G == 1:
-            return self._out[g].view(self.world, self.nl, self.nrow)
-        return self._out[g][:, slot]
+            return self._out[g].view(self.world, self.nl, self.ld)[:, :, :self.nrow]
+        return self._out[g][:, slot, :, :self.nrow]
