@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--matrix", default="AvI")
     ap.add_argument("--fields", type=int, default=64, help="fields per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--steps-per-gather", type=int, default=16, help="N>1: applies per RCCL all-gather")
+    ap.add_argument("--steps-per-gather", type=int, default=64, help="N>1: applies per RCCL all-gather")
     ap.add_argument("--variants", action="store_true", help="also time the peak-size (all-unmasked) variant; informational")
     ap.add_argument("--all-unmasked", action="store_true", help="every ice cell carries ice (peak-size variant, SURVEY.md 8d)")
     ap.add_argument("--warm", action="store_true", help="reuse ONE field batch (Infinity-Cache-resident numbers)")
