@@ -558,6 +558,84 @@ __global__ void k_keys_to_i32(const uint64_t *__restrict__ keys, long n, int32_t
     if (u < n) out[u] = (int32_t)keys[u];
 }
 
+// ---- column sums for matrices with short columns (AvI, EvI, AvX, EvX, AvE: <= a few rows per column) ----
+// spsparse sum(M, 1, '+') visits a column in ascending row order.  Instead of reordering all nnz
+// entries by column (three radix passes), the entries are dropped into per-column slots
+// (integer atomics: which slot an entry gets is not deterministic, the SET in a column is) and each
+// column is summed by one thread: 1 or 2 entries need no order at all ((0+a)+b == (0+b)+a bit for
+// bit); longer columns pick their entries in ascending row order by repeated selection (rows are
+// unique inside a column).  Columns of more than 64 entries go to a wave each.  Only used when
+// nnz <= 4*ncol, so long columns are the exception (an ice cell under a GCM-cell corner: 4).
+__global__ void k_col_count(const int32_t *__restrict__ col, long nnz, uint32_t *__restrict__ cnt) {
+    const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < nnz) atomicAdd(&cnt[col[u]], 1u);
+}
+__global__ void k_col_scatter(const int32_t *__restrict__ row, const int32_t *__restrict__ col, long nnz,
+                              const uint32_t *__restrict__ colptr, uint32_t *__restrict__ fillc,
+                              int32_t *__restrict__ lrow, uint32_t *__restrict__ lidx) {
+    const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nnz) return;
+    const int c = col[u];
+    const uint32_t p = colptr[c] + atomicAdd(&fillc[c], 1u);
+    lrow[p] = row[u];
+    lidx[p] = (uint32_t)u;
+}
+__global__ void k_col_sums(const uint32_t *__restrict__ colptr, int ncol, const int32_t *__restrict__ lrow,
+                           const uint32_t *__restrict__ lidx, const double *__restrict__ val, double *__restrict__ cs,
+                           uint32_t *__restrict__ nlong, int32_t *__restrict__ longcols) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    const uint32_t b = colptr[c], e = colptr[c + 1];
+    const uint32_t n = e - b;
+    double s = 0.0;
+    if (n <= 2) {
+        if (n > 0) s = s + val[lidx[b]];
+        if (n > 1) s = s + val[lidx[b + 1]];
+    } else if (n <= 64) {
+        int prev = -1;
+        for (uint32_t k = 0; k < n; ++k) {
+            int best = 0x7fffffff; uint32_t at = b;
+            for (uint32_t j = b; j < e; ++j) {
+                const int r = lrow[j];
+                if (r > prev && r < best) { best = r; at = j; }
+            }
+            s = s + val[lidx[at]];
+            prev = best;
+        }
+    } else {
+        longcols[atomicAdd(nlong, 1u)] = c;
+        return;
+    }
+    cs[c] = s;
+}
+__global__ void k_col_sums_long(const uint32_t *__restrict__ colptr, const int32_t *__restrict__ lrow,
+                                const uint32_t *__restrict__ lidx, const double *__restrict__ val, double *__restrict__ cs,
+                                const uint32_t *__restrict__ nlong, const int32_t *__restrict__ longcols) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t nl = *nlong;
+    for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; q < nl; q += (gridDim.x * blockDim.x) >> 6) {
+        const int c = longcols[q];
+        const uint32_t b = colptr[c], e = colptr[c + 1];
+        double s = 0.0;
+        int prev = -1;
+        for (uint32_t k = b; k < e; ++k) {            // one selection round per entry, 64 candidates per step
+            int best = 0x7fffffff; uint32_t at = b;
+            for (uint32_t j = b + lane; j < e; j += 64) {
+                const int r = lrow[j];
+                if (r > prev && r < best) { best = r; at = j; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const int ob = __shfl_xor(best, off, 64); const uint32_t oa = __shfl_xor(at, off, 64);
+                if (ob < best) { best = ob; at = oa; }
+            }
+            s = s + val[lidx[at]];
+            prev = best;
+        }
+        if (lane == 0) cs[c] = s;
+    }
+}
+
 // ---- weights and scaling (RegridMatrices_Dynamic.cpp:100-146, 201-233, 290-329) ----------------
 __device__ __forceinline__ double ratio_of(const RgView &rg, int keykind, int64_t sparse) {
     long iA = sparse;
@@ -952,7 +1030,20 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     double *rowmul = A.get<double>((size_t)nrow), *colmul = A.get<double>((size_t)ncol);
     w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
     seg_sums<true>(w->rowptr.p, nullptr, w->val.p, nrow, nnz, rs, st);
-    if (nnz) {
+    if (nnz && nnz <= 4l * ncol) {
+        // short columns: per-column slots + one thread per column (see k_col_sums)
+        uint32_t *colptr = A.get<uint32_t>((size_t)ncol + 1), *cntc = A.get<uint32_t>((size_t)ncol), *fillc = A.get<uint32_t>((size_t)ncol);
+        int32_t *lrow = A.get<int32_t>((size_t)nnz), *longcols = A.get<int32_t>((size_t)ncol);
+        uint32_t *lidx = A.get<uint32_t>((size_t)nnz), *nlong = A.get<uint32_t>(1);
+        IBH_HIP(hipMemsetAsync(cntc, 0, sizeof(uint32_t) * (size_t)ncol, st));
+        IBH_HIP(hipMemsetAsync(fillc, 0, sizeof(uint32_t) * (size_t)ncol, st));
+        IBH_HIP(hipMemsetAsync(nlong, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_col_count, dim3(ceil_div(nnz, T)), dim3(T), 0, st, w->colind.p, nnz, cntc);
+        exclusive_scan_u32(cntc, colptr, (size_t)ncol, colptr + ncol, st);
+        hipLaunchKernelGGL(k_col_scatter, dim3(ceil_div(nnz, T)), dim3(T), 0, st, row, w->colind.p, nnz, colptr, fillc, lrow, lidx);
+        hipLaunchKernelGGL(k_col_sums, dim3(ceil_div(ncol, T)), dim3(T), 0, st, colptr, ncol, lrow, lidx, w->val.p, cs, nlong, longcols);
+        hipLaunchKernelGGL(k_col_sums_long, dim3(256), dim3(T), 0, st, colptr, lrow, lidx, w->val.p, cs, nlong, longcols);
+    } else if (nnz) {
         uint64_t *ck = A.get<uint64_t>((size_t)nnz), *ck2 = A.get<uint64_t>((size_t)nnz);
         uint32_t *ci = A.get<uint32_t>((size_t)nnz), *ci2 = A.get<uint32_t>((size_t)nnz);
         hipLaunchKernelGGL(k_col_keys, dim3(ceil_div(nnz, T)), dim3(T), 0, st, w->colind.p, nnz, ck, ci);
