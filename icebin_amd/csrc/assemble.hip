@@ -248,7 +248,7 @@ __device__ __forceinline__ void first_one(const SetArgs &a, const XCell &c, long
         first_entry(a, k1, n > 1 && old_dense(a, k1) < 0, (uint32_t)(2 * x + 1), dedupe, lane);
 }
 template <bool WITH_EP>
-__global__ __launch_bounds__(256) void k_first2(RgView rg, SetArgs a, SetArgs b, int *__restrict__ err_x) {
+__global__ __launch_bounds__(256) void k_first2(RgView rg, SetArgs a, SetArgs b, uint32_t *__restrict__ err_x) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     stage_hc<WITH_EP>(rg, s_hc);
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_first2(RgView rg, SetArgs a, SetArgs b,
     bool valid = false;                         // no early return: every lane takes part in the ballots
     if (x < rg.nX) {
         c = load_cell<WITH_EP>(rg, x);
-        if (WITH_EP && c.range_error) atomicMin(err_x, (int)x);
+        if (WITH_EP && c.range_error) atomicMin(err_x, (uint32_t)x);
         else valid = true;
     }
     if (a.enabled) first_one(a, c, x, valid);
@@ -309,7 +309,7 @@ struct Numbering {
 };
 
 static Numbering number_set_prepare(const RgView &rg, ibh_sparse_set *set, int64_t sparse_extent, int list, int key,
-                                    int64_t max_new, int pkshift, hipStream_t st) {
+                                    int64_t max_new, int pkshift, uint32_t *first_storage, hipStream_t st) {
     Arena &A = arena();
     set->sparse_extent = sparse_extent;                       // set_sparse_extent, RegridMatrices_Dynamic.cpp:69-72
     Numbering nb;
@@ -357,10 +357,7 @@ static Numbering number_set_prepare(const RgView &rg, ibh_sparse_set *set, int64
     }
     ds.n = ds.n_old;
     a.enabled = !(set->identity && ds.n_old == sparse_extent);      // an identity set that covers everything gains nothing
-    if (a.enabled) {
-        a.first = A.get<uint32_t>((size_t)sparse_extent);
-        IBH_HIP(hipMemsetAsync(a.first, 0xFF, sizeof(uint32_t) * (size_t)sparse_extent, st));
-    }
+    a.first = first_storage;            // [sparse_extent], preset to 0xFFFFFFFF by the caller (one fill for both sets)
     return nb;
 }
 
@@ -707,7 +704,7 @@ __global__ void k_scale(const int32_t *__restrict__ row, const int32_t *__restri
 struct Triplets { uint64_t *keys, *keys_alt; uint32_t *idx, *idx_alt; double *term; size_t n; };
 
 static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, int ncol, int32_t **row_out,
-                                         hipStream_t st) {
+                                         hipStream_t st, bool expect_local = true) {
     Arena &A = arena();
     const int T = 256;
     w->nrow = nrow; w->ncol = ncol;
@@ -719,17 +716,33 @@ static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, 
         *row_out = nullptr;
         return;
     }
-    if (adaptive_sort_pairs(t.keys, t.keys_alt, t.idx, t.idx_alt, t.n, bits_for((uint64_t)ncol), bits_for((uint64_t)nrow),
-                            A.get<OrderInfo>(1), st)) {
+    // Order analysis + piece sort, then (speculatively, on the data as it stands) the duplicate
+    // flags and their scan: ONE host synchronisation returns both the analysis and nnz.  Only when a
+    // piece was too long for LDS (nothing was touched) does the radix sort run and the tail repeat.
+    const int lo_bits = bits_for((uint64_t)ncol), hi_bits = bits_for((uint64_t)nrow);
+    struct Readback { OrderInfo info; uint32_t total; } rb;
+    Readback *d_rb = A.get<Readback>(1);
+    uint32_t *head = A.get<uint32_t>(t.n);
+    uint32_t *d_total = &d_rb->total;
+    order_and_chunk_sort(t.keys, t.idx, t.n, &d_rb->info, st, expect_local);
+    if (expect_local) {
+        hipLaunchKernelGGL(k_head_flags, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, head);
+        exclusive_scan_u32(head, head, t.n, d_total, st);
+    }
+    IBH_HIP(hipMemcpyAsync(&rb, d_rb, sizeof(rb), hipMemcpyDeviceToHost, st));
+    IBH_HIP(hipStreamSynchronize(st));
+    order_debug(rb.info, t.n, lo_bits, hi_bits);
+    const bool resort = t.n >= 2 && !order_is_final(rb.info);
+    if (resort && radix_after_analysis(rb.info, t.keys, t.keys_alt, t.idx, t.idx_alt, t.n, lo_bits, hi_bits, st)) {
         std::swap(t.keys, t.keys_alt); std::swap(t.idx, t.idx_alt);
     }
-    uint32_t *head = A.get<uint32_t>(t.n);
-    uint32_t *d_total = A.get<uint32_t>(1);
-    hipLaunchKernelGGL(k_head_flags, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, head);
-    exclusive_scan_u32(head, head, t.n, d_total, st);
-    uint32_t nnz = 0;
-    IBH_HIP(hipMemcpyAsync(&nnz, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    IBH_HIP(hipStreamSynchronize(st));
+    if (resort || !expect_local) {
+        hipLaunchKernelGGL(k_head_flags, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, head);
+        exclusive_scan_u32(head, head, t.n, d_total, st);
+        IBH_HIP(hipMemcpyAsync(&rb.total, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        IBH_HIP(hipStreamSynchronize(st));
+    }
+    const uint32_t nnz = rb.total;
     IBH_CHECK(nnz < (1u << 31), "nnz overflows int32");
     w->nnz = nnz;
     w->colind.alloc(nnz); w->val.alloc(nnz);
@@ -966,17 +979,20 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     };
     // counters read back with ONE sync: [0] first out-of-range exchange cell, [1] new row keys,
     // [2] new column keys, [3] number of contributions
-    uint32_t *d_cnt = A.get<uint32_t>(4);
-    int *d_err = reinterpret_cast<int *>(d_cnt);
-    const int big = 0x7fffffff;
-    IBH_HIP(hipMemcpyAsync(d_err, &big, sizeof(int), hipMemcpyHostToDevice, st));
+    // [first(rows) | first(cols) | counters] are one allocation, preset to 0xFF.. with one fill
+    const size_t er = (size_t)extent_of(sp->row_key), ec = (size_t)extent_of(sp->col_key);
+    uint32_t *first_r = A.get<uint32_t>(er + ec + 4), *first_c = first_r + er;
+    uint32_t *d_cnt = first_c + ec;
+    uint32_t *d_err = d_cnt;
+    const uint32_t big = 0xffffffffu;
+    IBH_HIP(hipMemsetAsync(first_r, 0xFF, sizeof(uint32_t) * (er + ec + 1), st));
 
     // dense numbering in emission order; each user-visible set is numbered by exactly one Ur matrix
     // (RegridMatrices_Dynamic.cpp:75-81, 86-90, 178-183, 187-190, 270-277), so the two are independent.
     Numbering rnum = number_set_prepare(rg, dims[0], extent_of(sp->row_key), sp->row_list, sp->row_key,
-                                        (sp->row_list == LIST_EP ? 2 : 1) * g->nX, 0, st);
+                                        (sp->row_list == LIST_EP ? 2 : 1) * g->nX, 0, first_r, st);
     Numbering cnum = number_set_prepare(rg, dims[1], extent_of(sp->col_key), sp->col_list, sp->col_key,
-                                        (sp->col_list == LIST_EP ? 2 : 1) * g->nX, 2, st);
+                                        (sp->col_list == LIST_EP ? 2 : 1) * g->nX, 2, first_c, st);
     const int T = 256;
     const dim3 grid(g->nX ? ceil_div(g->nX, T) : 1);
     uint32_t *pk = A.get<uint32_t>((size_t)g->nX);
@@ -993,7 +1009,7 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     uint32_t h_cnt[4];
     IBH_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
     IBH_HIP(hipStreamSynchronize(st));
-    const int err_x = (int)h_cnt[0];
+    const uint32_t err_x = h_cnt[0];
     if (err_x != big) {
         // message of linterp_1d_b, IceRegridder_L0.cpp:84-85
         std::vector<int32_t> ij(2);
@@ -1022,7 +1038,9 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     const DeviceSet &rset = rnum.ds, &cset = cnum.ds;
     const int nrow = rset.n, ncol = cset.n;
     int32_t *row = nullptr;
-    build_csr_from_contributions(w.get(), t, nrow, ncol, &row, st);
+    // ice-cell rows over shared columns (IvA, IvE): the re-visits of straddling ice cells are far apart
+    // in the emission order, the pieces would span the whole sequence -> straight to the radix sort
+    build_csr_from_contributions(w.get(), t, nrow, ncol, &row, st, sp->row_key != KEY_I);
     const long nnz = w->nnz;
 
     // weights
@@ -1032,12 +1050,11 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     seg_sums<true>(w->rowptr.p, nullptr, w->val.p, nrow, nnz, rs, st);
     if (nnz && nnz <= 4l * ncol) {
         // short columns: per-column slots + one thread per column (see k_col_sums)
-        uint32_t *colptr = A.get<uint32_t>((size_t)ncol + 1), *cntc = A.get<uint32_t>((size_t)ncol), *fillc = A.get<uint32_t>((size_t)ncol);
+        uint32_t *colptr = A.get<uint32_t>((size_t)ncol + 1);
+        uint32_t *cntc = A.get<uint32_t>(2 * (size_t)ncol + 1), *fillc = cntc + ncol, *nlong = fillc + ncol;    // zeroed together
         int32_t *lrow = A.get<int32_t>((size_t)nnz), *longcols = A.get<int32_t>((size_t)ncol);
-        uint32_t *lidx = A.get<uint32_t>((size_t)nnz), *nlong = A.get<uint32_t>(1);
-        IBH_HIP(hipMemsetAsync(cntc, 0, sizeof(uint32_t) * (size_t)ncol, st));
-        IBH_HIP(hipMemsetAsync(fillc, 0, sizeof(uint32_t) * (size_t)ncol, st));
-        IBH_HIP(hipMemsetAsync(nlong, 0, sizeof(uint32_t), st));
+        uint32_t *lidx = A.get<uint32_t>((size_t)nnz);
+        IBH_HIP(hipMemsetAsync(cntc, 0, sizeof(uint32_t) * (2 * (size_t)ncol + 1), st));
         hipLaunchKernelGGL(k_col_count, dim3(ceil_div(nnz, T)), dim3(T), 0, st, w->colind.p, nnz, cntc);
         exclusive_scan_u32(cntc, colptr, (size_t)ncol, colptr + ncol, st);
         hipLaunchKernelGGL(k_col_scatter, dim3(ceil_div(nnz, T)), dim3(T), 0, st, row, w->colind.p, nnz, colptr, fillc, lrow, lidx);

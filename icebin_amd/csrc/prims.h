@@ -42,7 +42,15 @@ bool radix_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32
 enum { ORD_FULL_DEC = 1, ORD_HI_DEC = 2, ORD_LO_DEC = 4 };
 constexpr int CS_SMALL = 2048, CS_BIG = 8192;       // size classes of the pieces sorted in LDS; longer pieces -> radix sort
 struct OrderInfo { uint32_t flags, nchunks, maxlen, nsmall, nbig, reserved; };
-void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_info, hipStream_t stream);
+void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_info, hipStream_t stream,
+                          bool try_pieces = true);
+// Pieces of the synchronous form, for callers that fold the read-back of *d_info into a host
+// synchronisation they need anyway: order_and_chunk_sort() [async]; read *d_info; if !order_is_final()
+// the data is untouched and radix_after_analysis() sorts it (returns true when the result is in *_alt).
+bool order_is_final(const OrderInfo &h);
+bool radix_after_analysis(const OrderInfo &h, uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
+                          size_t n, int lo_bits, int hi_bits, hipStream_t stream);
+void order_debug(const OrderInfo &h, size_t n, int lo_bits, int hi_bits);
 bool adaptive_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt, size_t n,
                          int lo_bits, int hi_bits, OrderInfo *d_info, hipStream_t stream);
 

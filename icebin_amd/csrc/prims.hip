@@ -488,7 +488,7 @@ __global__ __launch_bounds__(1024) void oa_tile_prefix(const uint64_t *__restric
 // cut[k] = 1 where max(keys[0,k)) <= min(keys[k,n)); thread t owns elements [8t, 8t+8) of the tile
 __global__ __launch_bounds__(OA_T) void oa_cut_flags(const uint64_t *__restrict__ keys, size_t n,
                                                      const uint64_t *__restrict__ pm, const uint64_t *__restrict__ sm,
-                                                     uint32_t *__restrict__ cut) {
+                                                     uint32_t *__restrict__ cut, uint32_t *__restrict__ head) {
     __shared__ uint64_t tile[OA_TILE + OA_T];
     __shared__ uint64_t s_mx[OA_T / 64], s_mn[OA_T / 64];
     const size_t base = (size_t)blockIdx.x * OA_TILE;
@@ -526,21 +526,24 @@ __global__ __launch_bounds__(OA_T) void oa_cut_flags(const uint64_t *__restrict_
     sfx[OA_I] = u64min(sm[blockIdx.x], emn);
 #pragma unroll
     for (int i = OA_I - 1; i >= 0; --i) sfx[i] = u64min(v[i], sfx[i + 1]);
+    // head[k] = cut[k] && !cut[k+1]: the first element of a piece of >= 2 elements.  cut[k+1] needs
+    // max(keys[0..k]) and min(keys[k+1..n)), both at hand (sfx[i+1] starts at the next element).
 #pragma unroll
     for (int i = 0; i < OA_I; ++i) {
         const size_t idx = base + (size_t)threadIdx.x * OA_I + i;
-        if (idx < n) cut[idx] = (idx == 0 || before <= sfx[i]) ? 1u : 0u;
+        const bool c = idx == 0 || before <= sfx[i];
         before = u64max(before, v[i]);
+        const bool cnext = before <= sfx[i + 1];
+        if (idx < n) {
+            cut[idx] = c ? 1u : 0u;
+            head[idx] = (c && idx + 1 < n && !cnext) ? 1u : 0u;
+        }
     }
 }
 
 // Pieces of one element need no work; the others are listed as [wstart, wend).  A piece of >= 2
 // elements has exactly one head (cut[k] && !cut[k+1]) and one end (the next cut, or n), in the same
 // order, so the rank of an end is (#heads before it) - 1: one scan serves both.
-__global__ void oa_heads(const uint32_t *__restrict__ cut, size_t n, uint32_t *__restrict__ head) {
-    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) head[k] = (cut[k] && k + 1 < n && !cut[k + 1]) ? 1u : 0u;
-}
 __global__ void oa_work_list(const uint32_t *__restrict__ cut, const uint32_t *__restrict__ head,
                              const uint32_t *__restrict__ wpos, size_t n, const OrderInfo *__restrict__ info,
                              uint32_t *__restrict__ wstart, uint32_t *__restrict__ wend) {
@@ -694,9 +697,20 @@ template <int CAP, int THREADS> constexpr size_t chunk_sort_lds() {
 // Enqueues the analysis and the piece sorts.  Afterwards *d_info holds: flags (ORD_*), nchunks =
 // number of pieces with >= 2 elements, maxlen = the longest of them.  The data is in (key, idx)
 // order iff maxlen <= CS_BIG (8192); otherwise it is untouched.
-void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_info, hipStream_t st) {
+void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_info, hipStream_t st, bool try_pieces) {
     IBH_HIP(hipMemsetAsync(d_info, 0, sizeof(OrderInfo), st));
     if (n < 2) return;
+    if (!try_pieces) {          // flags only (which fields ever decrease): the caller expects non-local disorder
+        Arena &A = arena();
+        const size_t nt = (n + OA_TILE - 1) / OA_TILE;
+        uint64_t *tmin = A.get<uint64_t>(nt), *tmax = A.get<uint64_t>(nt), *pm = A.get<uint64_t>(nt), *sm = A.get<uint64_t>(nt);
+        uint32_t *tflags = A.get<uint32_t>(nt);
+        hipLaunchKernelGGL(oa_tiles, dim3((unsigned)nt), dim3(OA_T), 0, st, keys, n, tmin, tmax, tflags);
+        hipLaunchKernelGGL(oa_tile_prefix, dim3(1), dim3(1024), 0, st, tmin, tmax, tflags, (long)nt, pm, sm, d_info);
+        const uint32_t huge = 0xffffffffu;
+        IBH_HIP(hipMemcpyAsync(&d_info->maxlen, &huge, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        return;
+    }
     IBH_CHECK(n < (1ul << 32), "sort too large");
     constexpr size_t lds_small = chunk_sort_lds<CS_SMALL, 256>(), lds_big = chunk_sort_lds<CS_BIG, 1024>();
     static bool attr_set = false;
@@ -714,8 +728,7 @@ void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_
     uint32_t *tflags = A.get<uint32_t>(nt);
     hipLaunchKernelGGL(oa_tiles, dim3((unsigned)nt), dim3(OA_T), 0, st, keys, n, tmin, tmax, tflags);
     hipLaunchKernelGGL(oa_tile_prefix, dim3(1), dim3(1024), 0, st, tmin, tmax, tflags, (long)nt, pm, sm, d_info);
-    hipLaunchKernelGGL(oa_cut_flags, dim3((unsigned)nt), dim3(OA_T), 0, st, keys, n, pm, sm, cut);
-    hipLaunchKernelGGL(oa_heads, dim3(ge), dim3(256), 0, st, cut, n, head);
+    hipLaunchKernelGGL(oa_cut_flags, dim3((unsigned)nt), dim3(OA_T), 0, st, keys, n, pm, sm, cut, head);
     exclusive_scan_u32(head, wpos, n, &d_info->nchunks, st);
     hipLaunchKernelGGL(oa_work_list, dim3(ge), dim3(256), 0, st, cut, head, wpos, n, d_info, wstart, wend);
     uint32_t *lsmall = A.get<uint32_t>(n / 2 + 1), *lbig = A.get<uint32_t>(n / CS_SMALL + 1);
@@ -730,6 +743,16 @@ void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_
     IBH_HIP(hipGetLastError());
 }
 
+bool order_is_final(const OrderInfo &h) { return !(h.flags & ORD_FULL_DEC) || h.maxlen <= (uint32_t)CS_BIG; }
+
+bool radix_after_analysis(const OrderInfo &h, uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt,
+                          size_t n, int lo_bits, int hi_bits, hipStream_t st) {
+    KeyField f[2]; int nf = 0;
+    if (lo_bits > 0 && (h.flags & ORD_LO_DEC)) f[nf++] = KeyField{0, lo_bits};        // else: stable sort by the high field suffices
+    if (hi_bits > 0) f[nf++] = KeyField{32, hi_bits};
+    return radix_sort_pairs(keys, keys_alt, vals, vals_alt, n, f, nf, st);
+}
+
 bool adaptive_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt, size_t n,
                          int lo_bits, int hi_bits, OrderInfo *d_info, hipStream_t st) {
     if (n < 2) return false;
@@ -737,13 +760,14 @@ bool adaptive_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uin
     OrderInfo h;
     IBH_HIP(hipMemcpyAsync(&h, d_info, sizeof(h), hipMemcpyDeviceToHost, st));
     IBH_HIP(hipStreamSynchronize(st));
+    order_debug(h, n, lo_bits, hi_bits);
+    if (order_is_final(h)) return false;                                              // in order / pieces sorted in place
+    return radix_after_analysis(h, keys, keys_alt, vals, vals_alt, n, lo_bits, hi_bits, st);
+}
+
+void order_debug(const OrderInfo &h, size_t n, int lo_bits, int hi_bits) {
     static const bool dbg = getenv("IBH_DEBUG_SORT") != nullptr;
     if (dbg) fprintf(stderr, "[ibh sort] n=%zu flags=%u pieces=%u maxlen=%u small=%u big=%u lo_bits=%d hi_bits=%d\n", n, h.flags, h.nchunks, h.maxlen, h.nsmall, h.nbig, lo_bits, hi_bits);
-    if (!(h.flags & ORD_FULL_DEC) || h.maxlen <= (uint32_t)CS_BIG) return false;      // in order / pieces sorted in place
-    KeyField f[2]; int nf = 0;
-    if (lo_bits > 0 && (h.flags & ORD_LO_DEC)) f[nf++] = KeyField{0, lo_bits};        // else: stable sort by the high field suffices
-    if (hi_bits > 0) f[nf++] = KeyField{32, hi_bits};
-    return radix_sort_pairs(keys, keys_alt, vals, vals_alt, n, f, nf, st);
 }
 
 }  // namespace ibh
