@@ -462,9 +462,13 @@ __global__ void k_contrib_emit(RgView rg, MatSpec s, SetArgs a, SetArgs b, const
 }
 
 // ---- sorted contributions -> unique CSR entries ------------------------------------------------
-__global__ void k_head_flags(const uint64_t *__restrict__ keys, size_t n, uint32_t *__restrict__ head) {
+__global__ void k_head_flags(const uint64_t *__restrict__ keys, size_t n, uint32_t *__restrict__ head,
+                             uint32_t *__restrict__ unsorted) {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) head[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1u : 0u;
+    if (k >= n) return;
+    const uint64_t key = keys[k], prev = k ? keys[k - 1] : 0;
+    head[k] = (k == 0 || key != prev) ? 1u : 0u;
+    if (unsorted && k && key < prev) *unsorted = 1u;        // verification of an optimistic (high-field-only) sort
 }
 // Duplicate (row,col) contributions are summed in sorted (== emission) order, the first term
 // ASSIGNED (Eigen's product and setFromTriplets both start from the first value, which keeps a
@@ -720,25 +724,45 @@ static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, 
     // flags and their scan: ONE host synchronisation returns both the analysis and nnz.  Only when a
     // piece was too long for LDS (nothing was touched) does the radix sort run and the tail repeat.
     const int lo_bits = bits_for((uint64_t)ncol), hi_bits = bits_for((uint64_t)nrow);
-    struct Readback { OrderInfo info; uint32_t total; } rb;
+    struct Readback { OrderInfo info; uint32_t total, unsorted; } rb;
     Readback *d_rb = A.get<Readback>(1);
     uint32_t *head = A.get<uint32_t>(t.n);
     uint32_t *d_total = &d_rb->total;
-    order_and_chunk_sort(t.keys, t.idx, t.n, &d_rb->info, st, expect_local);
-    if (expect_local) {
-        hipLaunchKernelGGL(k_head_flags, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, head);
+    auto flags_and_count = [&](bool verify) {
+        hipLaunchKernelGGL(k_head_flags, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, head, verify ? &d_rb->unsorted : nullptr);
         exclusive_scan_u32(head, head, t.n, d_total, st);
-    }
+    };
+    order_and_chunk_sort(t.keys, t.idx, t.n, &d_rb->info, st, expect_local);
+    IBH_HIP(hipMemsetAsync(&d_rb->unsorted, 0, sizeof(uint32_t), st));
+    if (expect_local) flags_and_count(false);
     IBH_HIP(hipMemcpyAsync(&rb, d_rb, sizeof(rb), hipMemcpyDeviceToHost, st));
     IBH_HIP(hipStreamSynchronize(st));
     order_debug(rb.info, t.n, lo_bits, hi_bits);
     const bool resort = t.n >= 2 && !order_is_final(rb.info);
-    if (resort && radix_after_analysis(rb.info, t.keys, t.keys_alt, t.idx, t.idx_alt, t.n, lo_bits, hi_bits, st)) {
-        std::swap(t.keys, t.keys_alt); std::swap(t.idx, t.idx_alt);
-    }
-    if (resort || !expect_local) {
-        hipLaunchKernelGGL(k_head_flags, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, head);
-        exclusive_scan_u32(head, head, t.n, d_total, st);
+    if (resort) {
+        // Ice-cell rows: the column field is not monotone along the whole sequence (elevation classes),
+        // but inside each ROW it is when the exchange grid is sorted (later cells = later GCM cells =
+        // later class ids).  Then a stable sort by the row field alone is the full order: do that
+        // first and verify; only a failed check pays for the column passes.
+        const bool optimistic = !expect_local && (rb.info.flags & ORD_LO_DEC) && hi_bits > 0;
+        OrderInfo plan = rb.info;
+        if (optimistic) plan.flags &= ~(uint32_t)ORD_LO_DEC;
+        if (radix_after_analysis(plan, t.keys, t.keys_alt, t.idx, t.idx_alt, t.n, lo_bits, hi_bits, st)) {
+            std::swap(t.keys, t.keys_alt); std::swap(t.idx, t.idx_alt);
+        }
+        flags_and_count(optimistic);
+        IBH_HIP(hipMemcpyAsync(&rb.total, d_total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        IBH_HIP(hipStreamSynchronize(st));
+        if (optimistic && rb.unsorted) {
+            if (radix_after_analysis(rb.info, t.keys, t.keys_alt, t.idx, t.idx_alt, t.n, lo_bits, hi_bits, st)) {
+                std::swap(t.keys, t.keys_alt); std::swap(t.idx, t.idx_alt);
+            }
+            flags_and_count(false);
+            IBH_HIP(hipMemcpyAsync(&rb.total, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            IBH_HIP(hipStreamSynchronize(st));
+        }
+    } else if (!expect_local) {
+        flags_and_count(false);
         IBH_HIP(hipMemcpyAsync(&rb.total, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         IBH_HIP(hipStreamSynchronize(st));
     }
