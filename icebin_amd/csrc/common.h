@@ -174,6 +174,7 @@ struct ibh_weighted {
     mutable int last_kernel = 0;
     // apply_transformed: scratch fields + small transform, and M*1 (row sums) for the offset term
     mutable ibh::DevBuf<double> scratch, tbuf, rowsum1;
+    mutable ibh::DevBuf<double> xt;     // shortrow: transposed copy of the (small) input fields
     mutable bool have_rowsum1 = false;
     ~ibh_weighted() {
         for (int k = 0; k < 2; ++k)

@@ -273,6 +273,26 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 
 constexpr int SR_THREADS = 256;
 
+// XT[c*ldt + f] = X[f*ldx + c]; pad columns f in [nf, ldt) are zeroed (read for tail fields, never stored)
+__global__ void transpose_fields_kernel(const double *__restrict__ X, long ldx, int nf, int ncol,
+                                        double *__restrict__ XT, int ldt) {
+    __shared__ double tile[16][65];
+    const int cb = blockIdx.x * 64, fb = blockIdx.y * 16;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 256 threads: 64 columns x 4
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f = fb + ty * 4 + q, c = cb + tx;
+        tile[ty * 4 + q][tx] = (f < nf && c < ncol) ? X[(long)f * ldx + c] : 0.0;
+    }
+    __syncthreads();
+    const int fo = threadIdx.x & 15, co = threadIdx.x >> 4;          // 16 fields x 16 columns per pass
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = cb + co + q * 16;
+        if (c < ncol && fb + fo < ldt) XT[(long)c * ldt + fb + fo] = tile[fo][co + q * 16];
+    }
+}
+
 // REALIGN: the result planes Y[f, :] do not start on 64-byte lines (odd leading dimension: the
 // reference's A_b(nvar, n) is contiguous, so ldy = nrow_d).  A wave's 512-byte store would then
 // straddle nine lines and leave two of them partially written, to be completed by the neighbouring
@@ -281,7 +301,13 @@ constexpr int SR_THREADS = 256;
 // 64-byte boundary at or after its first row (consecutive workgroups advance by 248 rows, so the
 // runs tile the plane exactly); values cross lanes through LDS and every wave stores whole lines.
 constexpr int SR_STEP = SR_THREADS - 8;
-template <bool NT, int G, bool REALIGN>
+// XT: X is read from its transpose XT[c, f] (row stride ldx = fields padded to 16): the G fields of
+// one entry are 8*G contiguous bytes per lane, fetched with 16-byte loads.  With the field-major X a
+// wave gather touches up to 64 lines PER FIELD when the lanes' columns differ (IvE: the elevation
+// class changes from cell to cell); transposed it is 64 lines per ENTRY.  The transpose of the
+// (small: nf x nA_d or nE_d) input is a ~3 us pre-kernel.
+typedef double sr_double2 __attribute__((ext_vector_type(2)));
+template <bool NT, int G, bool REALIGN, bool XT>
 __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
     const double *__restrict__ X, long ldx, double *__restrict__ Y, long ldy, int nrow, int nf, int fper,
@@ -316,6 +342,30 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     // one store phase per thread.
     for (int f0 = fbeg; f0 < fend; f0 += G) {
         double acc[G];
+        if (XT) {
+            // entry by entry, G fields at a time (f0 is a multiple of G, rows of XT are padded to 16 fields)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = 0.0;
+            auto entry = [&](int c, double v, bool first) {
+                const sr_double2 *p = reinterpret_cast<const sr_double2 *>(X + (long)c * ldx + f0);
+#pragma unroll
+                for (int g = 0; g < G; g += 2) {
+                    const sr_double2 x = p[g >> 1];
+                    acc[g] = first ? v * x.x : fma(v, x.x, acc[g]);
+                    acc[g + 1] = first ? v * x.y : fma(v, x.y, acc[g + 1]);
+                }
+            };
+            // predicated, never multiplied by a padded zero: 0*NaN must not leak into a row
+            if (n > 0) entry(c0, v0, true);
+            if (n > 1) entry(c1, v1, false);
+            if (n > 2) entry(c2, v2, false);
+            if (n > 3) entry(c3, v3, false);
+            for (int k = beg + 4; k < end; ++k) entry(colind[k], vals[k], false);
+            if (dead) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = fill;
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int f = f0 + g < fend ? f0 + g : fend - 1;
@@ -328,6 +378,7 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
             if (n > 3) a = fma(v3, xf[c3], a);
             for (int k = beg + 4; k < end; ++k) a = fma(vals[k], xf[colind[k]], a);
             acc[g] = dead ? fill : a;
+        }
         }
         if (!REALIGN) {
 #pragma unroll
@@ -497,19 +548,34 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
         IBH_CHECK(nblk < (1l << 31), "spmm grid too large (%ld blocks)", nblk);
         dim3 grid((unsigned)nblk);
         const int g = get_tuning("shortrow_group", big ? (one_entry ? 8 : 4) : fper >= 8 ? 8 : 4);
+        // transposed input: pays when the lanes of a wave gather different columns (>= 2 entries per row:
+        // 5 km IvE 26.9 -> 18.5 us, 1 km IvE 302 -> 183 us) and at bandwidth-bound sizes (1 km IvA 207 ->
+        // 176 us); a latency-bound one-entry apply (5 km IvA, 14 us) only pays for the extra launch
+        int use_xt = get_tuning("shortrow_xt", -1);
+        if (use_xt < 0) use_xt = (!one_entry || big) ? 1 : 0;
+        if (fper % g != 0 || (g & 1)) use_xt = 0;
+        const double *xin = dA;
+        long xld = (long)lda;
+        if (use_xt) {
+            const int ldt = (nvar + 15) & ~15;
+            w->xt.alloc((size_t)w->ncol * (size_t)ldt);
+            hipLaunchKernelGGL(transpose_fields_kernel, dim3((unsigned)ceil_div(w->ncol, 64), (unsigned)(ldt / 16)), dim3(256), 0, stream,
+                               dA, (long)lda, nvar, w->ncol, w->xt.p, ldt);
+            xin = w->xt.p; xld = ldt;
+        }
+#define IBH_SR4(NT, GG, RA, XTT)                                                                                \
+    hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, RA, XTT>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
+                       w->val.p, xin, xld, dB, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill)
 #define IBH_SR(NT, GG)                                                                                          \
     do {                                                                                                        \
-        if (realign)                                                                                            \
-            hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, true>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
-                               w->val.p, dA, (long)lda, dB, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill);     \
-        else                                                                                                    \
-            hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, false>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
-                               w->val.p, dA, (long)lda, dB, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill);     \
+        if (realign) { if (use_xt) IBH_SR4(NT, GG, true, true); else IBH_SR4(NT, GG, true, false); }            \
+        else { if (use_xt) IBH_SR4(NT, GG, false, true); else IBH_SR4(NT, GG, false, false); }                  \
     } while (0)
         const bool nt = get_tuning("shortrow_nt", 1) != 0;
         if (g >= 16) { if (nt) IBH_SR(true, 16); else IBH_SR(false, 16); }
         else if (g >= 8) { if (nt) IBH_SR(true, 8); else IBH_SR(false, 8); }
         else { if (nt) IBH_SR(true, 4); else IBH_SR(false, 4); }
+#undef IBH_SR4
 #undef IBH_SR
         IBH_HIP(hipGetLastError());
     }

@@ -9,6 +9,10 @@ g = syn.make_grids(cfg); em = syn.dome_elevmask(g)
 rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em)
 L = _capi.lib(); fn = L.ibh_weighted_apply_device
 cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+for kv in os.environ.get("IBH_TUNE", "").split(","):       # e.g. IBH_TUNE=shortrow_xt=1,shortrow_fper=8
+    if kv:
+        from icebin_amd.linear import set_tuning
+        set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 for name in names:
     W = rm.matrix(name)
     nrow, ncol, nnz = W.nrow_d, W.ncol_d, W.nnz

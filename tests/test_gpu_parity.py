@@ -602,7 +602,14 @@ def test_shortrow_realigned_result_planes(name):
     x = torch.from_numpy(syn.fields(nf, ncol)).cuda()
     try:
         set_tuning("shortrow_realign", 0)
+        set_tuning("shortrow_xt", 0)
         ref = W.apply_device(x, out=torch.empty((nf, nrow), dtype=torch.float64, device="cuda")).cpu().numpy()
+        # the transposed-input variant (16-byte loads of XT[c, f0:f0+G]) does the same arithmetic in the same order
+        for xt, ra in ((1, 0), (1, 1)):
+            set_tuning("shortrow_xt", xt); set_tuning("shortrow_realign", ra)
+            got = W.apply_device(x, out=torch.empty((nf, nrow), dtype=torch.float64, device="cuda")).cpu().numpy()
+            assert np.array_equal(got, ref, equal_nan=True), (xt, ra)
+        set_tuning("shortrow_xt", -1)
         set_tuning("shortrow_realign", 1)
         for ld in (nrow, nrow + 1, nrow + 3, nrow + 8):
             for off in (0, 1, 5):
@@ -615,3 +622,4 @@ def test_shortrow_realigned_result_planes(name):
                 assert np.all(planes[:, nrow:] == -7.0) and np.all(got[:off] == -7.0) and np.all(got[off + nf * ld:] == -7.0)
     finally:
         set_tuning("shortrow_realign", -1)
+        set_tuning("shortrow_xt", -1)
