@@ -242,6 +242,35 @@ def test_5km_headline_shape_parity_and_conservation():
     assert rel_linf(IvA.apply(xa), oI.apply(xa)) <= FIELD_RTOL
 
 
+def test_config3_chain_5km_16_fields():
+    """BASELINE config 3: 5 km, nhc = 40: 16 fields through EvI, then AvE, then IvA (ice -> elevation
+    classes -> atmosphere -> ice), plus IvE on the intermediate; matrices bit-exact, every stage of the
+    chain within the field tolerance of the oracle run on the oracle's own intermediates, and the
+    round trip conserves the integral (constant field stays constant where defined)."""
+    g, em, mm, rg = setup("g5")
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    W = {n: rm.matrix(n) for n in ("EvI", "AvE", "IvA", "IvE")}
+    O = {n: rg.matrix_d(n, em, scale=True, correctA=True) for n in W}
+    for n in W:
+        assert_same_weighted(W[n], O[n], n + " g5")
+    xI = syn.fields(16, W["EvI"].ncol_d)
+    yE, oE = W["EvI"].apply(xI), O["EvI"].apply(xI)
+    assert rel_linf(yE, oE) <= FIELD_RTOL
+    # the E and A spaces of independently built matrices are numbered alike here (same emission order)
+    np.testing.assert_array_equal(W["AvE"].dim(1), W["EvI"].dim(0))
+    np.testing.assert_array_equal(W["IvA"].dim(1), W["AvE"].dim(0))
+    yA, oA = W["AvE"].apply(yE), O["AvE"].apply(oE)
+    assert rel_linf(yA, oA) <= 4 * FIELD_RTOL
+    yI, oI = W["IvA"].apply(yA), O["IvA"].apply(oA)
+    assert rel_linf(yI, oI) <= 8 * FIELD_RTOL
+    zI, oz = W["IvE"].apply(yE), O["IvE"].apply(oE)
+    assert rel_linf(zI, oz) <= 4 * FIELD_RTOL
+    ones = np.ones((1, W["EvI"].ncol_d))
+    back = W["IvA"].apply(W["AvE"].apply(W["EvI"].apply(ones)))
+    m = np.isfinite(back)
+    assert m.any() and np.max(np.abs(back[m] - 1.0)) < 1e-12
+
+
 def test_device_resident_apply_torch():
     import torch
     g, em, mm, rg = setup("g20")
