@@ -194,10 +194,6 @@ struct SetArgs {
     int64_t *to_sparse;         // [capacity] dense -> sparse
     const uint32_t *off;        // [nX] new keys of this set emitted before cell x (after the scan)
     int pkshift;                // this set's flag pair inside pk[x]
-    int e_nhc;                  // > 0: elevation-class keys, first[] is laid out class-fastest (fslot)
-    int e_hc_outer;             // iE = ihc*sHC + iA (sA == 1) rather than iA*sA + ihc (sHC == 1)
-    long e_sA, e_sHC;
-    int dbg_mode;
 };
 __device__ __forceinline__ int old_dense(const SetArgs &a, long key) {
     if (a.ident_n >= 0) return key < a.ident_n ? (int)key : -1;
@@ -211,19 +207,9 @@ __device__ __forceinline__ int old_dense(const SetArgs &a, long key) {
 // otherwise issue 7.7e7 of them on ~10^5 addresses.  Keys that are (almost) unique per cell (ice
 // cells, exchange cells) go to memory directly.
 __device__ __forceinline__ bool shared_keys(const SetArgs &a) { return a.key == KEY_A || a.key == KEY_E; }
-// Position of a key's entry in first[].  Elevation-class keys iE = iA*sA + ihc*sHC of ONE atmosphere
-// cell are up to a megabyte apart in the natural layout; they are stored class-fastest instead, so the
-// ~40 keys a run of cells touches share a few cache lines.
-__device__ __forceinline__ long fslot(const SetArgs &a, long key) {
-    if (a.e_nhc <= 0) return key;
-    const long ihc = a.e_hc_outer ? key / a.e_sHC : key % a.e_sA;
-    const long iA = a.e_hc_outer ? key % a.e_sHC : key / a.e_sA;
-    return iA * a.e_nhc + ihc;
-}
-
 __device__ __forceinline__ void first_entry(const SetArgs &a, long key, bool has, uint32_t pos, bool dedupe, int lane) {
     if (!dedupe) {
-        if (has) atomicMin(&a.first[fslot(a, key)], pos);
+        if (has) atomicMin(&a.first[key], pos);
         return;
     }
     unsigned long long todo = __ballot(has);          // every lane takes part in the ballots
@@ -236,7 +222,7 @@ __device__ __forceinline__ void first_entry(const SetArgs &a, long key, bool has
         todo &= ~same;
     }
     // ONE atomic instruction for all elected lanes
-    if (is_leader) atomicMin(&a.first[fslot(a, key)], pos);
+    if (is_leader) atomicMin(&a.first[key], pos);
 }
 __device__ __forceinline__ void first_one(const SetArgs &a, const XCell &c, long x, bool valid) {
     long k0 = -1, k1 = -1;
@@ -267,8 +253,8 @@ __device__ __forceinline__ uint32_t flag_one(const SetArgs &a, const XCell &c, l
     long k0, k1;
     const int n = list_entries(c, x, a.list, a.key, k0, k1);
     uint32_t f = 0;
-    if (n > 0 && old_dense(a, k0) < 0 && a.first[fslot(a, k0)] == (uint32_t)(2 * x)) f |= 1u;
-    if (n > 1 && old_dense(a, k1) < 0 && a.first[fslot(a, k1)] == (uint32_t)(2 * x + 1)) f |= 2u;
+    if (n > 0 && old_dense(a, k0) < 0 && a.first[k0] == (uint32_t)(2 * x)) f |= 1u;
+    if (n > 1 && old_dense(a, k1) < 0 && a.first[k1] == (uint32_t)(2 * x + 1)) f |= 2u;
     return f;
 }
 // dense id of `key` (any cell may ask): old id, else base + rank of the key's first occurrence
@@ -276,7 +262,7 @@ __device__ __forceinline__ int dense_of(const SetArgs &a, long key, const uint32
     if (!a.enabled) return (int)key;                       // identity over the whole sparse extent
     const int t = old_dense(a, key);
     if (t >= 0) return t;
-    const uint32_t p = a.first[fslot(a, key)];
+    const uint32_t p = a.first[key];
     const uint32_t xf = p >> 1;
     uint32_t r = a.off[xf];
     if (p & 1u) r += (pk[xf] >> a.pkshift) & 1u;           // second entry of its cell: after the first if that one was new too
@@ -332,12 +318,6 @@ static Numbering number_set_prepare(const RgView &rg, ibh_sparse_set *set, int64
     SetArgs &a = nb.args;
     a.list = list; a.key = key; a.base = ds.n_old; a.to_sparse = ds.to_sparse; a.pkshift = pkshift;
     a.ident_n = -1; a.tab = nullptr;
-    a.e_nhc = 0; a.e_hc_outer = 0; a.e_sA = rg.sA; a.e_sHC = rg.sHC;
-    a.dbg_mode = 0;
-    if (key == KEY_E) {        // regridder creation admits exactly these two stride patterns
-        if (rg.sA == 1 && rg.sHC == rg.nA) { a.e_nhc = rg.nhc; a.e_hc_outer = 1; }
-        else if (rg.sHC == 1 && rg.sA == rg.nhc) { a.e_nhc = rg.nhc; a.e_hc_outer = 0; }
-    }
     if (ds.n_old) {
         if (set->identity) {
             a.ident_n = ds.n_old;
