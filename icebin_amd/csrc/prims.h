@@ -40,8 +40,8 @@ bool radix_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32
 // to finish in one analysis pass + LDS sorts of the independent pieces the sequence splits into
 // (see prims.hip "adaptive ordering").  Synchronises the stream once.  d_info: device scratch.
 enum { ORD_FULL_DEC = 1, ORD_HI_DEC = 2, ORD_LO_DEC = 4 };
-constexpr int CS_SMALL = 2048, CS_BIG = 8192;       // size classes of the pieces sorted in LDS; longer pieces -> radix sort
-struct OrderInfo { uint32_t flags, nchunks, maxlen, nsmall, nbig, reserved; };
+constexpr int CS_SMALL = 2048, CS_MID = 4096, CS_BIG = 8192;   // size classes of the pieces sorted in LDS; longer pieces -> radix sort
+struct OrderInfo { uint32_t flags, nchunks, maxlen, nsmall, nmid, nbig; };
 void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_info, hipStream_t stream,
                           bool try_pieces = true);
 // Pieces of the synchronous form, for callers that fold the read-back of *d_info into a host

@@ -553,10 +553,10 @@ __global__ void oa_work_list(const uint32_t *__restrict__ cut, const uint32_t *_
     if (k > 0 && cut[k] && !cut[k - 1]) wend[wpos[k] - 1] = (uint32_t)k;
     if (k == n - 1 && !cut[k]) wend[info->nchunks - 1] = (uint32_t)n;
 }
-// longest piece + the two size-class lists the sort kernels walk (order inside a list is irrelevant)
+// longest piece + the three size-class lists the sort kernels walk (order inside a list is irrelevant)
 __global__ void oa_work_classify(const uint32_t *__restrict__ wstart, const uint32_t *__restrict__ wend,
-                                 OrderInfo *__restrict__ info, uint32_t *__restrict__ small, uint32_t *__restrict__ big,
-                                 uint32_t small_cap) {
+                                 OrderInfo *__restrict__ info, uint32_t *__restrict__ small, uint32_t *__restrict__ mid,
+                                 uint32_t *__restrict__ big) {
     const uint32_t nch = info->nchunks;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -566,15 +566,18 @@ __global__ void oa_work_classify(const uint32_t *__restrict__ wstart, const uint
         const uint32_t c = c0 + threadIdx.x;
         const uint32_t len = c < nch ? wend[c] - wstart[c] : 0u;
         m = max(m, len);
-        const bool is_s = len > 1 && len <= small_cap, is_b = len > small_cap;
-        const unsigned long long ms = __ballot(is_s), mb = __ballot(is_b);
-        uint32_t bs = 0, bb = 0;
+        const bool is_s = len > 1 && len <= (uint32_t)CS_SMALL, is_m = len > (uint32_t)CS_SMALL && len <= (uint32_t)CS_MID,
+                   is_b = len > (uint32_t)CS_MID;
+        const unsigned long long ms = __ballot(is_s), mm = __ballot(is_m), mb = __ballot(is_b);
+        uint32_t bs = 0, bm = 0, bb = 0;
         if (lane == 0) {
             if (ms) bs = atomicAdd(&info->nsmall, (uint32_t)__popcll(ms));
+            if (mm) bm = atomicAdd(&info->nmid, (uint32_t)__popcll(mm));
             if (mb) bb = atomicAdd(&info->nbig, (uint32_t)__popcll(mb));
         }
-        bs = __shfl(bs, 0, 64); bb = __shfl(bb, 0, 64);
+        bs = __shfl(bs, 0, 64); bm = __shfl(bm, 0, 64); bb = __shfl(bb, 0, 64);
         if (is_s) small[bs + (uint32_t)__popcll(ms & lt)] = c;
+        if (is_m) mid[bm + (uint32_t)__popcll(mm & lt)] = c;
         if (is_b) big[bb + (uint32_t)__popcll(mb & lt)] = c;
     }
 #pragma unroll
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(THREADS) void oa_chunk_sort(uint64_t *__restrict__ 
     if (info->maxlen > (uint32_t)CS_BIG) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    const uint32_t nlist = LO > 1 ? info->nbig : info->nsmall;
+    const uint32_t nlist = LO >= CS_MID ? info->nbig : LO >= CS_SMALL ? info->nmid : info->nsmall;
     {
       for (uint32_t q = blockIdx.x; q < nlist; q += gridDim.x) {
         const uint32_t c = list[q];
@@ -712,10 +715,11 @@ void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_
         return;
     }
     IBH_CHECK(n < (1ul << 32), "sort too large");
-    constexpr size_t lds_small = chunk_sort_lds<CS_SMALL, 256>(), lds_big = chunk_sort_lds<CS_BIG, 1024>();
+    constexpr size_t lds_small = chunk_sort_lds<CS_SMALL, 256>(), lds_mid = chunk_sort_lds<CS_MID, 512>(),
+                     lds_big = chunk_sort_lds<CS_BIG, 1024>();
     static bool attr_set = false;
     if (!attr_set) {
-        IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&oa_chunk_sort<CS_BIG, CS_SMALL, 1024>),
+        IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&oa_chunk_sort<CS_BIG, CS_MID, 1024>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
         attr_set = true;
     }
@@ -731,14 +735,18 @@ void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_
     hipLaunchKernelGGL(oa_cut_flags, dim3((unsigned)nt), dim3(OA_T), 0, st, keys, n, pm, sm, cut, head);
     exclusive_scan_u32(head, wpos, n, &d_info->nchunks, st);
     hipLaunchKernelGGL(oa_work_list, dim3(ge), dim3(256), 0, st, cut, head, wpos, n, d_info, wstart, wend);
-    uint32_t *lsmall = A.get<uint32_t>(n / 2 + 1), *lbig = A.get<uint32_t>(n / CS_SMALL + 1);
+    uint32_t *lsmall = A.get<uint32_t>(n / 2 + 1), *lmid = A.get<uint32_t>(n / CS_SMALL + 1), *lbig = A.get<uint32_t>(n / CS_MID + 1);
     const unsigned gmax = (unsigned)std::min<size_t>((n + 1023) / 1024, 1024);
-    hipLaunchKernelGGL(oa_work_classify, dim3(gmax), dim3(256), 0, st, wstart, wend, d_info, lsmall, lbig, (uint32_t)CS_SMALL);
+    hipLaunchKernelGGL(oa_work_classify, dim3(gmax), dim3(256), 0, st, wstart, wend, d_info, lsmall, lmid, lbig);
     const unsigned gs = (unsigned)std::min<size_t>((n + 1) / 2, 256 * 12);
     hipLaunchKernelGGL((oa_chunk_sort<CS_SMALL, 1, 256>), dim3(gs), dim3(256), lds_small, st, keys, idx, wstart, wend, lsmall, d_info);
     if (n > (size_t)CS_SMALL) {
-        const unsigned gb = (unsigned)std::min<size_t>(n / CS_SMALL, 512);
-        hipLaunchKernelGGL((oa_chunk_sort<CS_BIG, CS_SMALL, 1024>), dim3(gb), dim3(1024), lds_big, st, keys, idx, wstart, wend, lbig, d_info);
+        const unsigned gm = (unsigned)std::min<size_t>(n / CS_SMALL, 1024);
+        hipLaunchKernelGGL((oa_chunk_sort<CS_MID, CS_SMALL, 512>), dim3(gm), dim3(512), lds_mid, st, keys, idx, wstart, wend, lmid, d_info);
+    }
+    if (n > (size_t)CS_MID) {
+        const unsigned gb = (unsigned)std::min<size_t>(n / CS_MID, 512);
+        hipLaunchKernelGGL((oa_chunk_sort<CS_BIG, CS_MID, 1024>), dim3(gb), dim3(1024), lds_big, st, keys, idx, wstart, wend, lbig, d_info);
     }
     IBH_HIP(hipGetLastError());
 }
@@ -767,7 +775,7 @@ bool adaptive_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uin
 
 void order_debug(const OrderInfo &h, size_t n, int lo_bits, int hi_bits) {
     static const bool dbg = getenv("IBH_DEBUG_SORT") != nullptr;
-    if (dbg) fprintf(stderr, "[ibh sort] n=%zu flags=%u pieces=%u maxlen=%u small=%u big=%u lo_bits=%d hi_bits=%d\n", n, h.flags, h.nchunks, h.maxlen, h.nsmall, h.nbig, lo_bits, hi_bits);
+    if (dbg) fprintf(stderr, "[ibh sort] n=%zu flags=%u pieces=%u maxlen=%u small=%u mid=%u big=%u lo_bits=%d hi_bits=%d\n", n, h.flags, h.nchunks, h.maxlen, h.nsmall, h.nmid, h.nbig, lo_bits, hi_bits);
 }
 
 }  // namespace ibh
