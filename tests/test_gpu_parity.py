@@ -652,3 +652,65 @@ def test_shortrow_realigned_result_planes(name):
     finally:
         set_tuning("shortrow_realign", -1)
         set_tuning("shortrow_xt", -1)
+
+
+@pytest.mark.parametrize("nrow", [1, 7, 247, 248, 249, 255, 256, 257, 495, 496, 497, 1000])
+def test_shortrow_variants_on_edge_sizes(nrow):
+    """Plain / re-aligned / transposed-input shortrow launches on row counts around the 248-row step
+    and the 256-thread workgroup, 0-3 entries per row, a dead (wM == 0) row, against numpy."""
+    import torch
+    from icebin_amd.linear import linear_Weighted, set_tuning
+    rng = np.random.default_rng(nrow)
+    ncol, nf = 5, 6
+    cnt = rng.integers(0, 4, nrow)
+    rowptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    colind = np.concatenate([np.sort(rng.choice(ncol, c, replace=False)) for c in cnt] + [np.zeros(0, np.int64)]).astype(np.int32)
+    val = rng.standard_normal(len(colind))
+    wM = np.ones(nrow); wM[nrow // 2] = 0.0
+    W = linear_Weighted.from_csr((nrow, ncol), rowptr, colind, val, wM, np.ones(ncol))
+    W.set_kernel("shortrow")
+    x = rng.standard_normal((nf, ncol))
+    dense = np.zeros((nrow, ncol))
+    for r in range(nrow):
+        dense[r, colind[rowptr[r]:rowptr[r + 1]]] = val[rowptr[r]:rowptr[r + 1]]
+    ref = x @ dense.T
+    ref[:, nrow // 2] = -3.0
+    xd = torch.from_numpy(x).cuda()
+    try:
+        for xt in (0, 1):
+            for ra in (0, 1):
+                set_tuning("shortrow_xt", xt); set_tuning("shortrow_realign", ra)
+                for off in (0, 3):
+                    buf = torch.full((nf * (nrow + 5) + 8,), 9.0, dtype=torch.float64, device="cuda")
+                    out = buf[off:off + nf * (nrow + 5)].view(nf, nrow + 5)[:, :nrow]
+                    W.apply_device(xd, out=out, fill=-3.0)
+                    got = buf.cpu().numpy()
+                    planes = got[off:off + nf * (nrow + 5)].reshape(nf, nrow + 5)
+                    assert np.max(np.abs(planes[:, :nrow] - ref)) <= 1e-13 * max(1.0, np.max(np.abs(ref))), (xt, ra, off)
+                    assert np.all(planes[:, nrow:] == 9.0) and np.all(got[:off] == 9.0) and np.all(got[off + nf * (nrow + 5):] == 9.0)
+    finally:
+        set_tuning("shortrow_realign", -1)
+        set_tuning("shortrow_xt", -1)
+
+
+def test_column_sums_with_long_columns():
+    """Mw (column sums in ascending row order) when a few ice cells are overlapped by MANY atmosphere
+    cells: the short-column path (assemble.hip k_col_sums) takes its selection branch (3..64 entries)
+    and its one-wave-per-column branch (> 64), still bit-exact against the oracle."""
+    g = syn.make_grids("g20")
+    em = syn.dome_elevmask(g)
+    ok = np.flatnonzero(np.isfinite(em))
+    iA_all = np.unique(g["ex_indices"][:, 0])
+    rng = np.random.default_rng(11)
+    extra = []
+    for iI, k in ((ok[10], 100), (ok[200], 40), (ok[500], 9)):           # 100, 40 and 9 extra atmosphere cells
+        for a in rng.choice(iA_all, min(k, len(iA_all)), replace=False):
+            extra.append((a, iI))
+    extra = np.array(extra, np.int32)
+    g = dict(g)
+    g["ex_indices"] = np.concatenate([g["ex_indices"], extra]).astype(np.int32)
+    g["ex_area"] = np.concatenate([g["ex_area"], 1e6 * (1.0 + rng.random(len(extra)))])
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    for name in ("AvI", "EvI", "AvX"):
+        assert_same_weighted(rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True), name + " long columns")
