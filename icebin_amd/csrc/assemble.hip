@@ -466,14 +466,32 @@ __global__ void k_segment_heads(const uint64_t *__restrict__ keys, size_t n, con
     row[u] = (int32_t)(key >> 32);
     col[u] = (int32_t)(key & 0xffffffffu);
 }
-__global__ void k_rowptr(const int32_t *__restrict__ row, long nnz, int nrow, int32_t *__restrict__ rowptr) {
+// rowptr from the (sorted) row index of every entry.  Rows that own entries get their start from the
+// entry that opens them; rows WITHOUT entries (a caller-supplied identity set spans every ice cell,
+// most of them masked: millions of consecutive empty rows) find theirs by binary search, each on
+// its own thread -- a per-entry loop over the gap in front of it would serialise on exactly those runs.
+__global__ void k_rowptr_heads(const int32_t *__restrict__ row, long nnz, int32_t *__restrict__ rowptr) {
     const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nnz) return;
     const int r = row[u];
-    const int prev = u > 0 ? row[u - 1] : -1;
-    for (int q = prev + 1; q <= r; ++q) rowptr[q] = (int32_t)u;
-    if (u == nnz - 1)
-        for (int q = r + 1; q <= nrow; ++q) rowptr[q] = (int32_t)nnz;
+    if (u == 0 || row[u - 1] != r) rowptr[r] = (int32_t)u;
+}
+__global__ void k_rowptr_fill(const int32_t *__restrict__ row, long nnz, int nrow, int32_t *__restrict__ rowptr) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nrow) return;
+    if (q == nrow) { rowptr[q] = (int32_t)nnz; return; }
+    if (rowptr[q] >= 0) return;
+    long lo = 0, hi = nnz;                       // first entry whose row is >= q
+    while (lo < hi) {
+        const long mid = lo + ((hi - lo) >> 1);
+        if (row[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    rowptr[q] = (int32_t)lo;
+}
+static void rowptr_from_rows(const int32_t *row, long nnz, int nrow, int32_t *rowptr, hipStream_t st) {
+    IBH_HIP(hipMemsetAsync(rowptr, 0xFF, sizeof(int32_t) * ((size_t)nrow + 1), st));
+    if (nnz) hipLaunchKernelGGL(k_rowptr_heads, dim3(ceil_div(nnz, 256)), dim3(256), 0, st, row, nnz, rowptr);
+    hipLaunchKernelGGL(k_rowptr_fill, dim3(ceil_div(nrow + 1, 256)), dim3(256), 0, st, row, nnz, nrow, rowptr);
 }
 // spsparse sum(M,dim,'+'): one sequential chain per segment (a CSR row in ascending column order,
 // or a column in ascending row order through the stable by-column permutation `idx`), exactly
@@ -754,7 +772,7 @@ static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, 
     int32_t *segptr = A.get<int32_t>((size_t)nnz + 1);
     hipLaunchKernelGGL(k_segment_heads, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, head, nnz, segptr, row, w->colind.p);
     seg_sums<false>(segptr, t.idx, t.term, (int)nnz, (long)t.n, w->val.p, st);
-    hipLaunchKernelGGL(k_rowptr, dim3(ceil_div(nnz, T)), dim3(T), 0, st, row, (long)nnz, nrow, w->rowptr.p);
+    rowptr_from_rows(row, (long)nnz, nrow, w->rowptr.p, st);
     IBH_HIP(hipGetLastError());
     *row_out = row;
 }
@@ -1072,7 +1090,7 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
         if (f.nbits > 0 && radix_sort_pairs(ck, ck2, ci, ci2, (size_t)nnz, &f, 1, st)) { std::swap(ck, ck2); std::swap(ci, ci2); }
         int32_t *scol = A.get<int32_t>((size_t)nnz), *colptr = A.get<int32_t>((size_t)ncol + 1);
         hipLaunchKernelGGL(k_keys_to_i32, dim3(ceil_div(nnz, T)), dim3(T), 0, st, ck, nnz, scol);
-        hipLaunchKernelGGL(k_rowptr, dim3(ceil_div(nnz, T)), dim3(T), 0, st, scol, nnz, ncol, colptr);
+        rowptr_from_rows(scol, nnz, ncol, colptr, st);
         seg_sums<true>(colptr, ci, w->val.p, ncol, nnz, cs, st);
     } else if (ncol) {
         IBH_HIP(hipMemsetAsync(cs, 0, sizeof(double) * (size_t)ncol, st));

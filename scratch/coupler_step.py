@@ -1,0 +1,39 @@
+"""Time one coupling step's worth of this path (dev tool), shaped like IceCoupler.cpp:361-468 + :203-252, :445:
+new elevation mask -> regrid_matrices -> EvI (unscaled, dimE1 fresh, dimI identity), AvI (unscaled),
+IvE (scaled, shared dimE1), XvE (unscaled, shared dimE1, dimX identity) -> the two fused applies
+IvE*(V*T+b) and AvI*(V*T+b).  Wall-clock per phase, best of 7 steps after 2 warm-ups."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import icebin_amd
+from icebin_amd import synthetic as syn
+for cfg in sys.argv[1].split(","):
+    g = syn.make_grids(cfg); em = syn.dome_elevmask(g)
+    mm = icebin_amd.from_synthetic(g)
+    nI, nX, nE = g["nI"], len(g["ex_area"]), g["nA"] * 40
+    nvar_in, nvar_out = 8, 6
+    T = np.zeros((nvar_in, nvar_out)); T[np.arange(nvar_out), np.arange(nvar_out)] = 1.0; T[6, 2] = 0.5
+    b = np.linspace(0.0, 1.0, nvar_out)
+    best = None
+    for step in range(9):
+        torch.cuda.synchronize(); t = [time.perf_counter()]
+        rm = mm.regrid_matrices("greenland", em + 0.01 * step, scale=True, correctA=False)
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        dimI, dimE = icebin_amd.SparseSet.identity(nI), icebin_amd.SparseSet(nE)
+        EvI = rm.matrix_d("EvI", (dimE, dimI), scale=False, correctA=False); t.append(time.perf_counter())
+        AvI = rm.matrix_d("AvI", (None, dimI), scale=False, correctA=False); t.append(time.perf_counter())
+        IvE = rm.matrix_d("IvE", (dimI, dimE), scale=True, correctA=False); t.append(time.perf_counter())
+        dimX = icebin_amd.SparseSet.identity(nX)
+        XvE = rm.matrix_d("XvE", (dimX, dimE), scale=False, correctA=False); t.append(time.perf_counter())
+        vE = torch.randn((nvar_in, IvE.ncol_d), dtype=torch.float64, device="cuda")
+        vI = torch.randn((nvar_in, AvI.ncol_d), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        yI = IvE.apply_transformed_device(vE, T, b)
+        yA = AvI.apply_transformed_device(vI, T, b)
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        d = np.diff(t) * 1e3
+        if step >= 2 and (best is None or d.sum() < best.sum()):
+            best = d
+    names = ["regrid_matrices(elevmask upload)", "EvI", "AvI", "IvE", "XvE", "(field setup)", "2 fused applies"]
+    print("%-5s nX=%d" % (cfg, nX), "  ".join("%s %.3f ms" % (n, v) for n, v in zip(names, best) if not n.startswith("(")),
+          " | matrices %.3f ms" % best[1:5].sum(), flush=True)
