@@ -158,7 +158,10 @@ int ibh_weighted_get_csr(const ibh_weighted *w, int32_t *rowptr, int32_t *colind
  * dense index spaces; rows with wM == 0 receive `fill`; when the matrix is
  * not conservative and force_conservation != 0 each variable is rescaled by
  * (Mw . A) / (wM . B).  _host takes host pointers (copies over PCIe);
- * _device takes device pointers and only enqueues work on `stream`. */
+ * _device takes device pointers and only enqueues work on `stream`.  lda/ldb:
+ * distance in doubles between consecutive variables (>= dense extents); any value
+ * works, ldb a multiple of 64 (512-byte planes) is fastest for the I-row matrices.
+ * The handle keeps small per-apply scratch buffers: use one stream at a time per handle. */
 int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nvar, int64_t lda,
                             double *B_b, int64_t ldb, double fill, int force_conservation);
 int ibh_weighted_apply_device(const ibh_weighted *w, const double *dA_b, int32_t nvar, int64_t lda,
