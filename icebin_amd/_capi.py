@@ -52,6 +52,8 @@ _SIGS = {
     "ibh_regridder_wA": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "ibh_regrid_matrices_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                             C.POINTER(C.c_void_p)]),
+    "ibh_regrid_matrices_create_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                                   C.c_void_p, C.POINTER(C.c_void_p)]),
     "ibh_regrid_matrices_destroy": (C.c_int, [C.c_void_p]),
     "ibh_regrid_matrices_matrix_d": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                               C.c_void_p, C.POINTER(C.c_void_p)]),

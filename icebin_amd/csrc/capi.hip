@@ -277,6 +277,25 @@ int ibh_regrid_matrices_create(const ibh_regridder *rg, const double *elevmaskI,
         *out = rm.release();
     });
 }
+int ibh_regrid_matrices_create_device(const ibh_regridder *rg, const double *d_elevmaskI, int64_t n, int scale,
+                                      int correctA, const double sigma[3], void *stream, ibh_regrid_matrices **out) {
+    return guarded([&] {
+        IBH_CHECK(rg && d_elevmaskI && out, "null argument");
+        IBH_CHECK(n == rg->nI, "elevmaskI has %ld elements, the ice grid has nI=%ld", (long)n, (long)rg->nI);
+        int dev = -1;
+        IBH_HIP(hipGetDevice(&dev));
+        IBH_CHECK(dev == rg->device, "regridder belongs to device %d, current device is %d", rg->device, dev);
+        std::unique_ptr<ibh_regrid_matrices> rm(new ibh_regrid_matrices);
+        rm->rg = rg;
+        rm->scale = scale; rm->correctA = correctA;
+        if (sigma) for (int k = 0; k < 3; ++k) rm->sigma[k] = sigma[k];
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        rm->elevmaskI.alloc((size_t)n);
+        IBH_HIP(hipMemcpyAsync(rm->elevmaskI.p, d_elevmaskI, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        IBH_HIP(hipStreamSynchronize(st));
+        *out = rm.release();
+    });
+}
 int ibh_regrid_matrices_destroy(ibh_regrid_matrices *rm) { delete rm; return IBH_OK; }
 
 int ibh_regrid_matrices_matrix_d(const ibh_regrid_matrices *rm, const char *spec, ibh_sparse_set *dim0,

@@ -136,9 +136,18 @@ class GCMRegridder:
         """_icebin.pyx:164-175.  `conserve` is accepted and, as in the reference's C++ shim
         (icebin_cython.cpp:215-236), not used."""
         sheet = self._sheets[sheet_name]       # KeyError like ice_regridders().index.at()
-        em = np.ascontiguousarray(np.asarray(elevmaskI, np.float64).reshape(-1))
         sig = np.asarray(sigma, np.float64)
         h = C.c_void_p()
+        if hasattr(elevmaskI, "is_cuda") and elevmaskI.is_cuda:
+            # elevation mask already in HBM (torch.float64 CUDA tensor): no trip over PCIe
+            import torch
+            em = elevmaskI.reshape(-1).contiguous()
+            assert em.dtype == torch.float64
+            st = torch.cuda.current_stream(em.device).cuda_stream
+            check(lib().ibh_regrid_matrices_create_device(sheet.h, C.c_void_p(em.data_ptr()), em.numel(), int(scale),
+                                                         int(correctA), ptr(sig), C.c_void_p(st), C.byref(h)))
+            return RegridMatrices(h, keep=(self,))
+        em = np.ascontiguousarray(np.asarray(elevmaskI, np.float64).reshape(-1))
         check(lib().ibh_regrid_matrices_create(sheet.h, ptr(em), len(em), int(scale), int(correctA), ptr(sig), C.byref(h)))
         return RegridMatrices(h, keep=(self,))
 

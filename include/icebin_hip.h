@@ -114,6 +114,12 @@ typedef struct ibh_regrid_matrices ibh_regrid_matrices;
 int ibh_regrid_matrices_create(const ibh_regridder *rg, const double *elevmaskI, int64_t n,
                                int scale, int correctA, const double sigma[3],
                                ibh_regrid_matrices **out);
+/* Same with the elevation mask already in HBM (an ice model that runs on the GPU: the host form
+ * moves 8*nI bytes over PCIe per coupling step, 4 ms at 1 km).  Copied device-to-device on `stream`,
+ * which is synchronised before returning. */
+int ibh_regrid_matrices_create_device(const ibh_regridder *rg, const double *d_elevmaskI, int64_t n,
+                                      int scale, int correctA, const double sigma[3], void *stream,
+                                      ibh_regrid_matrices **out);
 int ibh_regrid_matrices_destroy(ibh_regrid_matrices *rm);
 
 /* RegridMatrices_Dynamic::matrix_d(spec, dims, params) (:412-423).

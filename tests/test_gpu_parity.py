@@ -714,3 +714,15 @@ def test_column_sums_with_long_columns():
     rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
     for name in ("AvI", "EvI", "AvX"):
         assert_same_weighted(rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True), name + " long columns")
+
+
+def test_device_resident_elevation_mask():
+    """regrid_matrices() from an elevation mask that is already in HBM builds the same matrices."""
+    import torch
+    g, em, mm, rg = setup("g20")
+    emd = torch.from_numpy(em).cuda()
+    rm = mm.regrid_matrices("greenland", emd, scale=True, correctA=True)
+    for name in ("AvI", "EvI", "IvE"):
+        assert_same_weighted(rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True), name + " device mask")
+    with pytest.raises(icebin_amd.IcebinHipError, match="elements"):
+        mm.regrid_matrices("greenland", emd[:-1])
