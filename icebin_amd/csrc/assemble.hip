@@ -167,10 +167,6 @@ __global__ void k_fill_i32(int32_t *p, size_t n, int32_t v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-__global__ void k_iota_i32(int32_t *p, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = (int32_t)i;
-}
 __global__ void k_iota_i64(int64_t *p, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = (int64_t)i;

@@ -596,7 +596,6 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
 // out[k, j] = sum_l T[l,k] * in[l, j] + b[k] * (scale ? scale[j] : 1): the variable transform, applied
 // on whichever side of M is small.  T entries that are exactly 0 are structural (skipped: a NaN in an
 // unused input variable must not reach the outputs).  One thread per column j, all k in registers.
-constexpr int TR_MAX = 64;      // max nvar_in / nvar_out handled in one launch
 __global__ void transform_kernel(const double *__restrict__ in, long ldin, int nin, const double *__restrict__ Tm,
                                  const double *__restrict__ b, const double *__restrict__ scale,
                                  const double *__restrict__ wM, double fill, double *__restrict__ out, long ldout,
