@@ -729,8 +729,7 @@ static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, 
     order_and_chunk_sort(t.keys, t.idx, t.n, &d_rb->info, st, expect_local);
     IBH_HIP(hipMemsetAsync(&d_rb->unsorted, 0, sizeof(uint32_t), st));
     if (expect_local) flags_and_count(false);
-    IBH_HIP(hipMemcpyAsync(&rb, d_rb, sizeof(rb), hipMemcpyDeviceToHost, st));
-    IBH_HIP(hipStreamSynchronize(st));
+    readback_sync(&rb, d_rb, sizeof(rb), st);
     order_debug(rb.info, t.n, lo_bits, hi_bits);
     const bool resort = t.n >= 2 && !order_is_final(rb.info);
     if (resort) {
@@ -745,20 +744,17 @@ static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, 
             std::swap(t.keys, t.keys_alt); std::swap(t.idx, t.idx_alt);
         }
         flags_and_count(optimistic);
-        IBH_HIP(hipMemcpyAsync(&rb.total, d_total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        IBH_HIP(hipStreamSynchronize(st));
+        readback_sync(&rb.total, d_total, 2 * sizeof(uint32_t), st);
         if (optimistic && rb.unsorted) {
             if (radix_after_analysis(rb.info, t.keys, t.keys_alt, t.idx, t.idx_alt, t.n, lo_bits, hi_bits, st)) {
                 std::swap(t.keys, t.keys_alt); std::swap(t.idx, t.idx_alt);
             }
             flags_and_count(false);
-            IBH_HIP(hipMemcpyAsync(&rb.total, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            IBH_HIP(hipStreamSynchronize(st));
+            readback_sync(&rb.total, d_total, sizeof(uint32_t), st);
         }
     } else if (!expect_local) {
         flags_and_count(false);
-        IBH_HIP(hipMemcpyAsync(&rb.total, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        IBH_HIP(hipStreamSynchronize(st));
+        readback_sync(&rb.total, d_total, sizeof(uint32_t), st);
     }
     const uint32_t nnz = rb.total;
     IBH_CHECK(nnz < (1u << 31), "nnz overflows int32");
@@ -1025,8 +1021,7 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     }
     exclusive_scan3(pk, (size_t)g->nX, roff, coff, poff, d_cnt + 1, st);
     uint32_t h_cnt[4];
-    IBH_HIP(hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
-    IBH_HIP(hipStreamSynchronize(st));
+    readback_sync(h_cnt, d_cnt, sizeof(h_cnt), st);
     const uint32_t err_x = h_cnt[0];
     if (err_x != big) {
         // message of linterp_1d_b, IceRegridder_L0.cpp:84-85

@@ -9,6 +9,7 @@
 #include "prims.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace ibh {
 
@@ -28,6 +29,19 @@ void release_workspace() {
     Arena &a = arena();
     for (auto &b : a.blocks) (void)hipFree(b.p);
     a.blocks.clear();
+}
+
+void readback_sync(void *dst, const void *dsrc, size_t bytes, hipStream_t stream) {
+    struct Pinned {
+        void *p = nullptr;
+        ~Pinned() { if (p) (void)hipHostFree(p); }
+    };
+    static thread_local Pinned pin;
+    IBH_CHECK(bytes <= 256, "internal: read-back of %zu bytes", bytes);
+    if (!pin.p) IBH_HIP(hipHostMalloc(&pin.p, 256, hipHostMallocDefault));
+    IBH_HIP(hipMemcpyAsync(pin.p, dsrc, bytes, hipMemcpyDeviceToHost, stream));
+    IBH_HIP(hipStreamSynchronize(stream));
+    memcpy(dst, pin.p, bytes);
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
@@ -766,8 +780,7 @@ bool adaptive_sort_pairs(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uin
     if (n < 2) return false;
     order_and_chunk_sort(keys, vals, n, d_info, st);
     OrderInfo h;
-    IBH_HIP(hipMemcpyAsync(&h, d_info, sizeof(h), hipMemcpyDeviceToHost, st));
-    IBH_HIP(hipStreamSynchronize(st));
+    readback_sync(&h, d_info, sizeof(h), st);
     order_debug(h, n, lo_bits, hi_bits);
     if (order_is_final(h)) return false;                                              // in order / pieces sorted in place
     return radix_after_analysis(h, keys, keys_alt, vals, vals_alt, n, lo_bits, hi_bits, st);
