@@ -313,6 +313,17 @@ public:
                                          params.sigma.data(), &rm));
         return std::unique_ptr<RegridMatrices_Dynamic>(new RegridMatrices_Dynamic(regridder, rm, params));
     }
+    /** Same with the elevation mask already in device memory (no counterpart in the reference, whose
+        ice models live on the host): copied device-to-device on `stream`. */
+    std::unique_ptr<RegridMatrices_Dynamic> regrid_matrices_device(int sheet_index, const double *d_elevmaskI, long n,
+                                                                   RegridParams const &params = RegridParams(),
+                                                                   void *stream = nullptr) const {
+        IceRegridder const *regridder = sheets_.at((size_t)sheet_index).get();
+        ibh_regrid_matrices *rm = nullptr;
+        check(ibh_regrid_matrices_create_device(regridder->h_, d_elevmaskI, n, params.scale, params.correctA,
+                                                params.sigma.data(), stream, &rm));
+        return std::unique_ptr<RegridMatrices_Dynamic>(new RegridMatrices_Dynamic(regridder, rm, params));
+    }
     /** GCMRegridder::wA (GCMRegridder.hpp:305-315, icebin_cython.cpp:103-117) */
     std::vector<double> wA(std::string const &ice_sheet_name, bool native, double fill = 0.) const {
         std::vector<double> out((size_t)nA());
