@@ -769,6 +769,91 @@ static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, 
     *row_out = row;
 }
 
+// ---- bands for the rowdual apply kernel (spmm.hip) -----------------------------------------------
+// An ice cell between two elevation classes is a column of TWO rows of an E-row matrix: (cell a,
+// class k) with weight 1-r and (a, k+1) with weight r.  Row by row its field value is fetched twice.
+// The band structure lists every (GCM cell, ice cell) pair ONCE, in the lower row, with both weights:
+// band r = the entries of row r that are not the upper partner of an entry of the row below, in CSR
+// order (columns ascending); an upper partner is attached to its lower entry.  Pairing is decided per
+// column from its few entries (per-column slots of the short-column path): within one GCM cell,
+// classes pair up from the lowest (k, k+1), so the partner row of a band is always the same row.
+// A filtered copy of the CSR: no sorting, exact copies of M's values.
+__device__ __forceinline__ void e_decode(const RgView &rg, int64_t e, long &a, long &hc) {
+    if (rg.sHC >= rg.sA) { hc = e / rg.sHC; a = (e % rg.sHC) / rg.sA; }
+    else { a = e / rg.sA; hc = e % rg.sA; }
+}
+__global__ void k_band_roles(RgView rg, const int64_t *__restrict__ row_s, const uint32_t *__restrict__ colptr, int ncol,
+                             const int32_t *__restrict__ lrow, const uint32_t *__restrict__ lidx,
+                             uint32_t *__restrict__ lower, int32_t *__restrict__ partner) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    const uint32_t b = colptr[c], e = colptr[c + 1];
+    for (uint32_t i = b; i < e; ++i) {
+        long ai, hi;
+        e_decode(rg, row_s[lrow[i]], ai, hi);
+        // number of consecutive classes directly below this entry in the same GCM cell: odd -> upper partner
+        int below = 0;
+        int32_t up = -1;                       // the entry one class above (its partner if this one is a lower entry)
+        for (long t = hi - 1;; --t) {
+            bool found = false;
+            for (uint32_t j = b; j < e && !found; ++j) {
+                long aj, hj;
+                e_decode(rg, row_s[lrow[j]], aj, hj);
+                found = aj == ai && hj == t;
+            }
+            if (!found) break;
+            ++below;
+        }
+        for (uint32_t j = b; j < e; ++j) {
+            long aj, hj;
+            e_decode(rg, row_s[lrow[j]], aj, hj);
+            if (aj == ai && hj == hi + 1) up = (int32_t)lidx[j];
+        }
+        const bool is_lower = (below & 1) == 0;
+        lower[lidx[i]] = is_lower ? 1u : 0u;
+        partner[lidx[i]] = is_lower ? up : -1;
+    }
+}
+__global__ void k_band_emit(const int32_t *__restrict__ row, const int32_t *__restrict__ col, const double *__restrict__ val,
+                            long nnz, const uint32_t *__restrict__ lower, const uint32_t *__restrict__ dpos,
+                            const int32_t *__restrict__ partner, int32_t *__restrict__ bcol, double *__restrict__ bv0,
+                            double *__restrict__ bv1, int32_t *__restrict__ rb1) {
+    const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nnz || !lower[u]) return;
+    const uint32_t d = dpos[u];
+    const int32_t p = partner[u];
+    bcol[d] = (int32_t)((uint32_t)col[u] | 0x40000000u | (p >= 0 ? 0x80000000u : 0u));
+    bv0[d] = val[u];
+    bv1[d] = p >= 0 ? val[p] : 0.0;
+    if (p >= 0) rb1[row[p]] = row[u];          // every lower entry of this row names the same partner row
+}
+__global__ void k_band_ptr(const int32_t *__restrict__ rowptr, int nrow, long nnz, const uint32_t *__restrict__ dpos,
+                           const uint32_t *__restrict__ d_total, int32_t *__restrict__ bptr) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > nrow) return;
+    const int k = rowptr[r];
+    bptr[r] = k < nnz ? (int32_t)dpos[k] : (int32_t)*d_total;
+}
+// colptr/lrow/lidx: the per-column slots built for the column sums.  *d_total receives the number of band entries.
+static void build_bands(ibh_weighted *w, const RgView &rg, const int64_t *row_s, const int32_t *row, const uint32_t *colptr,
+                        const int32_t *lrow, const uint32_t *lidx, uint32_t *d_total, hipStream_t st) {
+    Arena &A = arena();
+    const int T = 256;
+    const int nrow = w->nrow, ncol = w->ncol;
+    const long nnz = w->nnz;
+    uint32_t *lower = A.get<uint32_t>((size_t)nnz), *dpos = A.get<uint32_t>((size_t)nnz);
+    int32_t *partner = A.get<int32_t>((size_t)nnz);
+    hipLaunchKernelGGL(k_band_roles, dim3(ceil_div(ncol, T)), dim3(T), 0, st, rg, row_s, colptr, ncol, lrow, lidx, lower, partner);
+    exclusive_scan_u32(lower, dpos, (size_t)nnz, d_total, st);
+    w->band_ptr.alloc((size_t)nrow + 1); w->band_rb1.alloc((size_t)nrow);
+    w->band_col.alloc((size_t)nnz); w->band_v0.alloc((size_t)nnz); w->band_v1.alloc((size_t)nnz);       // upper bound; >= nnz/2 are used
+    IBH_HIP(hipMemsetAsync(w->band_rb1.p, 0xFF, sizeof(int32_t) * (size_t)nrow, st));
+    hipLaunchKernelGGL(k_band_emit, dim3(ceil_div(nnz, T)), dim3(T), 0, st, row, w->colind.p, w->val.p, nnz, lower, dpos, partner,
+                       w->band_col.p, w->band_v0.p, w->band_v1.p, w->band_rb1.p);
+    hipLaunchKernelGGL(k_band_ptr, dim3(ceil_div(nrow + 1, T)), dim3(T), 0, st, w->rowptr.p, nrow, nnz, dpos, d_total, w->band_ptr.p);
+    IBH_HIP(hipGetLastError());
+}
+
 // ---- smoothing (sigma != 0): M <- smoothI * M  (smoother.cpp:8-99, RegridMatrices_Dynamic.cpp:237-248) ------
 // smoothI[i,j] = exp(-.5 d2(i,j)) * area_j / sum_j(...) over the unmasked ice cells j of dimI with
 // d2 = sum_k ((c_j[k]-c_i[k])/sigma[k])^2 < 4, c = (x, y, elevation), area = wM.  The reference finds
@@ -1061,12 +1146,15 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     double *rowmul = A.get<double>((size_t)nrow), *colmul = A.get<double>((size_t)ncol);
     w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
     seg_sums<true>(w->rowptr.p, nullptr, w->val.p, nrow, nnz, rs, st);
+    uint32_t *colptr = nullptr, *lidx = nullptr;       // per-column slots (short-column path), reused by build_bands
+    int32_t *lrow = nullptr;
     if (nnz && nnz <= 4l * ncol) {
         // short columns: per-column slots + one thread per column (see k_col_sums)
-        uint32_t *colptr = A.get<uint32_t>((size_t)ncol + 1);
+        colptr = A.get<uint32_t>((size_t)ncol + 1);
         uint32_t *cntc = A.get<uint32_t>(2 * (size_t)ncol + 1), *fillc = cntc + ncol, *nlong = fillc + ncol;    // zeroed together
-        int32_t *lrow = A.get<int32_t>((size_t)nnz), *longcols = A.get<int32_t>((size_t)ncol);
-        uint32_t *lidx = A.get<uint32_t>((size_t)nnz);
+        lrow = A.get<int32_t>((size_t)nnz);
+        int32_t *longcols = A.get<int32_t>((size_t)ncol);
+        lidx = A.get<uint32_t>((size_t)nnz);
         IBH_HIP(hipMemsetAsync(cntc, 0, sizeof(uint32_t) * (2 * (size_t)ncol + 1), st));
         hipLaunchKernelGGL(k_col_count, dim3(ceil_div(nnz, T)), dim3(T), 0, st, w->colind.p, nnz, cntc);
         exclusive_scan_u32(cntc, colptr, (size_t)ncol, colptr + ncol, st);
@@ -1097,7 +1185,21 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
                            apply_row, apply_col);
     IBH_HIP(hipGetLastError());
     if (smooth) smooth_matrix(w.get(), rm, rset.to_sparse, sigma, st);
-    IBH_HIP(hipStreamSynchronize(st));
+    // E-row matrices over ice / exchange columns: band structure for the apply (after the scaling: exact
+    // copies of M).  Opt-in (ibh_set_tuning("assemble_bands", 1)): it costs +25-35 % of the build and
+    // buys -16 % on a 1 km apply, nothing at 5 km -- right for a matrix that is applied to many field
+    // batches, wrong for the coupler's one build : one apply per step.
+    const bool want_bands = sp->row_key == KEY_E && (sp->col_key == KEY_I || sp->col_key == KEY_X) && colptr != nullptr &&
+                            ncol < (1 << 28) && get_tuning("assemble_bands", 0);
+    uint32_t nband_entries = 0;
+    if (want_bands) {
+        uint32_t *d_nb = A.get<uint32_t>(1);
+        build_bands(w.get(), rg, rset.to_sparse, row, colptr, lrow, lidx, d_nb, st);
+        readback_sync(&nband_entries, d_nb, sizeof(uint32_t), st);
+        w->band_n = nband_entries;
+    } else {
+        IBH_HIP(hipStreamSynchronize(st));
+    }
     *out = w.release();
 }
 

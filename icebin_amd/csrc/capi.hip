@@ -490,13 +490,14 @@ int ibh_weighted_set_kernel(ibh_weighted *w, const char *name) {
         if (!strcmp(name, "auto")) w->kernel_override = 0;
         else if (!strcmp(name, "rowblock")) w->kernel_override = 1;
         else if (!strcmp(name, "shortrow")) w->kernel_override = 2;
+        else if (!strcmp(name, "rowdual")) w->kernel_override = 3;        // falls back to rowblock when the matrix has no bands
         else fail(IBH_EINVAL, "unknown kernel '%s'", name);
     });
 }
 int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen) {
     return guarded([&] {
         IBH_CHECK(w && buf && buflen > 0, "bad argument");
-        snprintf(buf, (size_t)buflen, "%s", w->last_kernel == 1 ? "rowblock" : w->last_kernel == 2 ? "shortrow" : "none");
+        snprintf(buf, (size_t)buflen, "%s", w->last_kernel == 1 ? "rowblock" : w->last_kernel == 2 ? "shortrow" : w->last_kernel == 3 ? "rowdual" : "none");
     });
 }
 int ibh_selftest_sort(const uint64_t *keys, int64_t n, int lo_bits, int hi_bits, uint32_t *perm_out, int *path_out) {

@@ -170,11 +170,17 @@ struct ibh_weighted {
     bool owns[2] = {false, false};
     int conservative = 1, scaled = 1;
     // SpMM dispatch
-    int kernel_override = 0;            // 0 auto, 1 rowblock, 2 shortrow
+    int kernel_override = 0;            // 0 auto, 1 rowblock, 2 shortrow, 3 rowdual
     mutable int last_kernel = 0;
     // apply_transformed: scratch fields + small transform, and M*1 (row sums) for the offset term
     mutable ibh::DevBuf<double> scratch, tbuf, rowsum1;
     mutable ibh::DevBuf<double> xt;     // shortrow: transposed copy of the (small) input fields
+    // rowdual (EvI, EvX): the CSR filtered to one entry per (GCM cell, ice cell) carrying the weights of
+    // BOTH elevation classes the cell lies between (assemble.hip build_bands); band r = row r
+    int64_t band_n = 0;                 // number of band entries, 0: not built
+    ibh::DevBuf<int32_t> band_ptr, band_col, band_rb1;   // [nrow+1]; [band_n] column | bit30 lower exists | bit31 upper exists; [nrow]
+    ibh::DevBuf<double> band_v0, band_v1;                // [band_n] lower-class / upper-class weight
+    mutable ibh::DevBuf<double> band_part;               // per-apply partial sums [2][nvar][nrow padded]
     mutable bool have_rowsum1 = false;
     ~ibh_weighted() {
         for (int k = 0; k < 2; ++k)

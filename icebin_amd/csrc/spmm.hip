@@ -121,12 +121,22 @@ __device__ __forceinline__ double xload(__amdgpu_buffer_rsrc_t rs, int byte_off)
     do {                                                                                        \
         if (DIAG && threadIdx.x == 0) diag[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
-template <int FPW, int WK, int UNROLL, int NW, bool DIAG = false>
+// DUAL (EvI, EvX; WK == 1): the "row" is a BAND -- the ice cells of one GCM cell whose elevation lies
+// between two neighbouring classes.  Such a cell is a column of two rows of M (weights 1-r and r on
+// the lower and the upper class); as a band entry it carries both values (vals, vals2; bits 30/31 of
+// the column say which exist) and is read ONCE, feeding two accumulators.  Row by row every X element
+// of these matrices is fetched twice (measured: 2.0 GB for 1.03 GB algorithmic at 1 km).  The kernel
+// then stores the two partial sums of the band (Y = lower-class sums, Y2 = upper-class sums, no
+// fill); dual_combine_kernel adds, for every row, its own lower sum and the upper sum of the band
+// below it.  The band arrays are a filtered copy of the CSR (assemble.hip build_bands).
+template <int FPW, int WK, int UNROLL, int NW, bool DIAG = false, bool DUAL = false>
 __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
     const double *__restrict__ X, long ldx, int ncol, double *__restrict__ Y, long ldy, int nrow, int nf, int nfc,
-    int xcd_mode, const double *__restrict__ wM, double fill, unsigned long long *__restrict__ diag = nullptr)
+    int xcd_mode, const double *__restrict__ wM, double fill, unsigned long long *__restrict__ diag = nullptr,
+    const double *__restrict__ vals2 = nullptr, double *__restrict__ Y2 = nullptr)
 {
+    static_assert(!DUAL || WK == 1, "bands are not split across waves");
     IBH_STAMP(0);
     constexpr int RB_THREADS = NW * 64;
     constexpr int RB_STAGE = RB_SEG / RB_THREADS;
@@ -136,6 +146,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     constexpr int BATCH = UNROLL * STEP;
     __shared__ int s_col[RB_SEG];
     __shared__ double s_val[RB_SEG];
+    __shared__ double s_val2[DUAL ? RB_SEG : 1];
     __shared__ double s_part[WK][FB];
 
     int r, fc;
@@ -151,9 +162,9 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
         const int f = f0 + j < nf ? f0 + j : nf - 1;    // clamp: tail fields read valid memory, never stored
         rs[j] = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)f * ldx), 0, ncol * 8, 0x00020000);
     }
-    double acc[FPW];
+    double acc[FPW], acc2[DUAL ? FPW : 1];
 #pragma unroll
-    for (int j = 0; j < FPW; ++j) acc[j] = 0.0;
+    for (int j = 0; j < FPW; ++j) { acc[j] = 0.0; if (DUAL) acc2[j] = 0.0; }
 
     const int beg = rowptr[r], end = rowptr[r + 1];
     if (DIAG && threadIdx.x == 0) { diag[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(end - beg); }
@@ -161,20 +172,21 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     // The row is walked in segments of RB_SEG entries staged in LDS.  The loads of segment s+1 are
     // issued before segment s is processed (they fly while X streams) and written to LDS after it.
     int cc[RB_STAGE];
-    double vv[RB_STAGE];
+    double vv[RB_STAGE], vv2[DUAL ? RB_STAGE : 1];
     auto stage_load = [&](int seg, int n) {       // all loads first (clamped, unconditional)
 #pragma unroll
         for (int i = 0; i < RB_STAGE; ++i) {
             const int k = min((int)threadIdx.x + i * RB_THREADS, n - 1);
             cc[i] = colind[seg + k];
             vv[i] = vals[seg + k];
+            if (DUAL) vv2[i] = vals2[seg + k];
         }
     };
     auto stage_store = [&](int n) {
 #pragma unroll
         for (int i = 0; i < RB_STAGE; ++i) {
             const int k = threadIdx.x + i * RB_THREADS;
-            if (k < n) { s_col[k] = cc[i]; s_val[k] = vv[i]; }
+            if (k < n) { s_col[k] = cc[i]; s_val[k] = vv[i]; if (DUAL) s_val2[k] = vv2[i]; }
         }
     };
     if (beg < end) {
@@ -193,12 +205,15 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
         int kb = 0;
         for (; kb < nfull; kb += BATCH) {
             int off[UNROLL];
-            double v[UNROLL];
+            double v[UNROLL], v2[DUAL ? UNROLL : 1];
+            bool h0[DUAL ? UNROLL : 1], h1[DUAL ? UNROLL : 1];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int k = kb + wk * 64 + lane + u * STEP;
-                off[u] = s_col[k] << 3;
+                const int c = s_col[k];
+                off[u] = DUAL ? (c & 0x3fffffff) << 3 : c << 3;
                 v[u] = s_val[k];
+                if (DUAL) { v2[u] = s_val2[k]; h0[u] = (c >> 30) & 1; h1[u] = c < 0; }
             }
             double x[FPW][UNROLL];
 #pragma unroll
@@ -208,22 +223,29 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 #pragma unroll
             for (int j = 0; j < FPW; ++j)
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) acc[j] = fma(v[u], x[j][u], acc[j]);
+                for (int u = 0; u < UNROLL; ++u) {
+                    if (DUAL) {                          // a missing partner is never multiplied (0*NaN)
+                        acc[j] = h0[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
+                        acc2[j] = h1[u] ? fma(v2[u], x[j][u], acc2[j]) : acc2[j];
+                    } else acc[j] = fma(v[u], x[j][u], acc[j]);
+                }
         }
         IBH_STAMP(3);
         // Tail batch: lanes past the end re-read the last entry and are masked at the FMA (never
         // multiplied by 0: 0*NaN must not leak into a row).
         if (kb + wk * 64 < n) {
             int off[UNROLL];
-            double v[UNROLL];
-            bool ok[UNROLL];
+            double v[UNROLL], v2[DUAL ? UNROLL : 1];
+            bool ok[UNROLL], ok2[DUAL ? UNROLL : 1];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int k = kb + wk * 64 + lane + u * STEP;
                 ok[u] = k < n;
                 const int kk = ok[u] ? k : n - 1;
-                off[u] = s_col[kk] << 3;
+                const int c = s_col[kk];
+                off[u] = DUAL ? (c & 0x3fffffff) << 3 : c << 3;
                 v[u] = s_val[kk];
+                if (DUAL) { v2[u] = s_val2[kk]; ok2[u] = ok[u] && c < 0; ok[u] = ok[u] && ((c >> 30) & 1); }
             }
             double x[FPW][UNROLL];
 #pragma unroll
@@ -233,7 +255,10 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 #pragma unroll
             for (int j = 0; j < FPW; ++j)
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) acc[j] = ok[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
+                for (int u = 0; u < UNROLL; ++u) {
+                    acc[j] = ok[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
+                    if (DUAL) acc2[j] = ok2[u] ? fma(v2[u], x[j][u], acc2[j]) : acc2[j];
+                }
         }
         if (more) {
             __syncthreads();                      // every wave is done reading this segment
@@ -246,6 +271,16 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 #pragma unroll
     for (int j = 0; j < FPW; ++j) acc[j] = wave_sum(acc[j]);
     IBH_STAMP(5);
+    if (DUAL) {                          // partial sums of the band; fill and the pairing happen in dual_combine_kernel
+#pragma unroll
+        for (int j = 0; j < FPW; ++j) acc2[j] = wave_sum(acc2[j]);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < FPW; ++j)
+                if (f0 + j < nf) { Y[(long)(f0 + j) * ldy + r] = acc[j]; Y2[(long)(f0 + j) * ldy + r] = acc2[j]; }
+        }
+        return;
+    }
 
     const bool dead = wM[r] == 0.0;     // mask_result, IceCoupler.cpp:186-201
     if (WK == 1) {
@@ -492,6 +527,49 @@ static void launch_rowblock(const ibh_weighted *w, const double *dA, int nvar, l
     IBH_HIP(hipGetLastError());
 }
 
+// B[f, r] = lower-class sum of band r + upper-class sum of the band below it (rb1[r], -1: none)
+__global__ void dual_combine_kernel(const double *__restrict__ P0, const double *__restrict__ P1, long ldp,
+                                    const int *__restrict__ rb1, const double *__restrict__ wM, double fill,
+                                    double *__restrict__ Y, long ldy, int nrow, int nf) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (r >= nrow) return;
+    const int b = rb1[r];
+    double t = P0[(long)f * ldp + r];
+    if (b >= 0) t = t + P1[(long)f * ldp + b];
+    Y[(long)f * ldy + r] = wM[r] == 0.0 ? fill : t;
+}
+
+template <int FPW>
+static void launch_rowdual(const ibh_weighted *w, const double *dA, int nvar, long lda, double *dB, long ldb,
+                           double fill, hipStream_t stream)
+{
+    constexpr int NW = 4, FB = FPW * NW;
+    const int nfc = ceil_div(nvar, FB);
+    const int xcd_mode = (nfc % 8 == 0 || nfc == 1 || nfc == 2 || nfc == 4) ? 1 : 0;
+    long nb = (long)w->nrow * nfc;
+    if (xcd_mode == 1 && nfc < 8) {
+        const int m = 8 / nfc;
+        nb = 8l * ((w->nrow + m - 1) / m + 1);
+    }
+    IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
+    IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
+    const long ldp = ((long)w->nrow + 63) & ~63l;
+    w->band_part.alloc(2 * (size_t)nvar * (size_t)ldp);
+    double *P0 = w->band_part.p, *P1 = P0 + (size_t)nvar * (size_t)ldp;
+    const double mean = w->nrow ? (double)w->band_n / (double)w->nrow / 64.0 : 1.0;
+    const int unroll = mean > 4.0 ? 8 : mean > 2.0 ? 4 : mean > 1.0 ? 2 : 1;
+#define IBH_RD(U)                                                                                                  \
+    hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, 1, U, NW, false, true>), dim3((unsigned)nb), dim3(NW * 64), 0, stream, \
+                       w->band_ptr.p, w->band_col.p, w->band_v0.p, dA, lda, w->ncol, P0, ldp, w->nrow, nvar, nfc, xcd_mode, \
+                       w->wM.p, fill, (unsigned long long *)nullptr, w->band_v1.p, P1)
+    if (unroll == 1) IBH_RD(1); else if (unroll == 2) IBH_RD(2); else if (unroll == 8) IBH_RD(8); else IBH_RD(4);
+#undef IBH_RD
+    hipLaunchKernelGGL(dual_combine_kernel, dim3((unsigned)ceil_div(w->nrow, 256), (unsigned)nvar), dim3(256), 0, stream,
+                       P0, P1, ldp, w->band_rb1.p, w->wM.p, fill, dB, ldb, w->nrow, nvar);
+    IBH_HIP(hipGetLastError());
+}
+
 void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda, double *dB, int64_t ldb,
                  double fill, int force_conservation, hipStream_t stream)
 {
@@ -503,8 +581,16 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
         const double mean = w->nrow ? (double)w->nnz / (double)w->nrow : 0.0;
         kernel = mean >= (double)get_tuning("rowblock_min_mean_nnz", 6) ? 1 : 2;
     }
+    if (kernel == 1 && w->kernel_override == 0 && w->band_n > 0 && nvar >= 4 && get_tuning("rowdual_auto", 1)) kernel = 3;
+    if (kernel == 3 && w->band_n == 0) kernel = 1;            // no bands were built for this matrix
     w->last_kernel = kernel;
-    if (kernel == 1) {
+    if (kernel == 3) {
+        const long pairs = (long)w->nrow * nvar;
+        const int fpw = get_tuning("rowdual_fpw", pairs >= 4 * 8192 ? 4 : pairs >= 2 * 8192 ? 2 : 1);
+        if (fpw >= 4) launch_rowdual<4>(w, dA, nvar, (long)lda, dB, (long)ldb, fill, stream);
+        else if (fpw == 2) launch_rowdual<2>(w, dA, nvar, (long)lda, dB, (long)ldb, fill, stream);
+        else launch_rowdual<1>(w, dA, nvar, (long)lda, dB, (long)ldb, fill, stream);
+    } else if (kernel == 1) {
         int fpw = get_tuning("rowblock_fpw", 0), wk = get_tuning("rowblock_wk", 0);
         if (fpw == 0 || wk == 0) {
             // enough workgroups to give every CU ~8: small problems are latency-bound and want many

@@ -197,7 +197,7 @@ typedef struct ibh_weighted_device_view {
 int ibh_weighted_device_view_get(const ibh_weighted *w, ibh_weighted_device_view *out);
 
 /* Tuning / introspection (not part of the reference interface). */
-int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow" */
+int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow", "rowdual" */
 int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
 int ibh_set_tuning(const char *key, int value);
 /* Diagnostic: run the assembly's ordering primitive (order analysis + independent-piece LDS sort,

@@ -132,16 +132,23 @@ def test_errors_mirror_reference():
 @pytest.mark.parametrize("nvar", [1, 2, 3, 5, 8, 16, 17, 64])
 @pytest.mark.parametrize("name", ["AvI", "IvA", "EvI", "IvE", "EvA", "AvE"])
 def test_apply_parity(name, nvar):
+    from icebin_amd.linear import set_tuning
     g, em, mm, rg = setup("g20")
-    w = mm.regrid_matrices("greenland", em, scale=True, correctA=True).matrix(name)
+    set_tuning("assemble_bands", 1)          # opt-in structure behind the "rowdual" kernel (EvI/EvX only)
+    try:
+        w = mm.regrid_matrices("greenland", em, scale=True, correctA=True).matrix(name)
+    finally:
+        set_tuning("assemble_bands", 0)
     o = rg.matrix_d(name, em, scale=True, correctA=True)
     x = syn.fields(nvar, w.ncol_d)
-    for kernel in ("auto", "rowblock", "shortrow"):
+    for kernel in ("auto", "rowblock", "shortrow", "rowdual"):
         w.set_kernel(kernel)
         y = w.apply(x, fill=np.nan, force_conservation=False)
         ref = o.apply(x, fill=np.nan, force_conservation=False)
         assert rel_linf(y, ref) <= FIELD_RTOL, (name, nvar, kernel)
-        assert w.last_kernel() in ("rowblock", "shortrow")
+        assert w.last_kernel() in ("rowblock", "shortrow", "rowdual")
+        if kernel == "rowdual":          # only E-row matrices over ice/exchange columns carry bands
+            assert w.last_kernel() == ("rowdual" if name == "EvI" else "rowblock")
     y1 = w.apply(x[0])
     assert y1.shape == (w.nrow_d,) and rel_linf(y1, o.apply(x[0])) <= FIELD_RTOL
 
@@ -726,3 +733,31 @@ def test_device_resident_elevation_mask():
         assert_same_weighted(rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True), name + " device mask")
     with pytest.raises(icebin_amd.IcebinHipError, match="elements"):
         mm.regrid_matrices("greenland", emd[:-1])
+
+
+@pytest.mark.parametrize("variant", ["sorted", "shuffled", "elev_class"])
+def test_rowdual_bands_on_grid_variants(variant):
+    """The band structure (one entry per (GCM cell, ice cell) with both class weights) applied by the
+    rowdual kernel, on the grid variants that change the pairing: shuffled exchange cells, straddling
+    cells, one class per cell (ELEV_CLASS_INTERP: no partners at all)."""
+    from icebin_amd.linear import set_tuning
+    kw = dict(sorted={}, shuffled=dict(order="shuffled"), elev_class={})[variant]
+    g = syn.make_grids("g50", **kw)
+    if variant == "elev_class":
+        g["interp_style"] = 1
+    em = syn.dome_elevmask(g)
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    set_tuning("assemble_bands", 1)
+    try:
+        rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+        for name in ("EvI", "EvX"):
+            w, o = rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True)
+            assert_same_weighted(w, o, name)
+            x = syn.fields(9, w.ncol_d)
+            x[3, ::7] = np.nan                      # NaN in a field must stay in the rows that use those cells
+            w.set_kernel("rowdual")
+            y = w.apply(x, fill=-1.0, force_conservation=False)
+            assert w.last_kernel() == "rowdual"
+            assert rel_linf(y, o.apply(x, fill=-1.0, force_conservation=False)) <= FIELD_RTOL
+    finally:
+        set_tuning("assemble_bands", 0)
