@@ -761,3 +761,46 @@ def test_rowdual_bands_on_grid_variants(variant):
             assert rel_linf(y, o.apply(x, fill=-1.0, force_conservation=False)) <= FIELD_RTOL
     finally:
         set_tuning("assemble_bands", 0)
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_exchange_grids_bit_exact(seed):
+    """Randomised differential test of the whole assembly against the oracle: arbitrary (iA, iI) pairs
+    (duplicates, any order, ice cells under many atmosphere cells), random masks, zero / negative
+    overlaps, both interpolation styles, both indexingHC layouts -- every ordering path (in order,
+    pieces, radix, optimistic row-only sort and its failed check), both column-sum paths."""
+    rng = np.random.default_rng(1000 + seed)
+    nA_real, nI, nhc = int(rng.integers(3, 40)), int(rng.integers(20, 600)), int(rng.integers(2, 12))
+    im, jm = 12, 8
+    nA = im * jm
+    A_to_sparse = np.sort(rng.choice(nA, nA_real, replace=False)).astype(np.int64)
+    nX = int(rng.integers(50, 3000))
+    iA = rng.choice(A_to_sparse, nX)
+    iI = rng.integers(0, nI, nX)
+    if seed % 3 == 0:                    # a sorted grid (the reference's normal case), else arbitrary order
+        o = np.lexsort((iI, iA)); iA, iI = iA[o], iI[o]
+    area = 1e6 * (0.5 + rng.random(nX))
+    area[rng.random(nX) < 0.03] = 0.0
+    if seed % 4 == 1:
+        area[rng.random(nX) < 0.05] *= -1.0
+    hcdefs = np.sort(rng.random(nhc)) * 3000.0
+    hcdefs[0] = -50.0
+    em = rng.random(nI) * (hcdefs[-1] - 1.0)
+    em[rng.random(nI) < 0.3] = np.nan
+    em[rng.random(nI) < 0.05] = hcdefs[int(rng.integers(0, nhc))]     # exactly on a class boundary (weight 0 dropped)
+    proj = 1e9 * (1.0 + rng.random(nA_real))
+    g = dict(config="random", nx=nI, ny=1, dx=1.0, x_fastest=False, nI=nI, nA=nA, im=im, jm=jm,
+             ex_indices=np.stack([iA, iI], axis=1).astype(np.int32), ex_area=area, A_to_sparse=A_to_sparse,
+             A_native_area=proj * (1.0 + 0.05 * rng.random(nA_real)), A_proj_area=proj, hcdefs=hcdefs,
+             hc_stride_A=1 if seed % 2 == 0 else nhc, hc_stride_HC=nA if seed % 2 == 0 else 1,
+             interp_style=1 if seed % 5 == 4 else 0, I_centroid_xy=np.zeros((nI, 2)))
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    rm = mm.regrid_matrices("greenland", em)
+    for name in ALL:
+        for scale, correctA in ((True, True), (False, False)):
+            w = rm.matrix_d(name, scale=scale, correctA=correctA)
+            o = rg.matrix_d(name, em, scale=scale, correctA=correctA)
+            assert_same_weighted(w, o, "%s scale=%d correctA=%d seed=%d" % (name, scale, correctA, seed))
+            if w.nnz and name in ("AvI", "IvE", "EvI"):
+                x = syn.fields(3, w.ncol_d, seed=seed)
+                assert rel_linf(w.apply(x, fill=-9.0), o.apply(x, fill=-9.0)) <= FIELD_RTOL
