@@ -804,3 +804,29 @@ def test_random_exchange_grids_bit_exact(seed):
             if w.nnz and name in ("AvI", "IvE", "EvI"):
                 x = syn.fields(3, w.ncol_d, seed=seed)
                 assert rel_linf(w.apply(x, fill=-9.0), o.apply(x, fill=-9.0)) <= FIELD_RTOL
+
+
+@pytest.mark.parametrize("nA_real,nX", [(12, 150000), (60, 200000)])
+def test_random_exchange_grids_large_pieces(nA_real, nX):
+    """Same, at sizes where a GCM cell's contributions exceed the LDS piece classes (2048 / 4096 /
+    8192: the first case falls back to the radix sort for AvI, the second lands in the upper classes)."""
+    rng = np.random.default_rng(77 + nA_real)
+    nI, nhc, im, jm = 60000, 8, 12, 8
+    nA = im * jm
+    A_to_sparse = np.sort(rng.choice(nA, nA_real, replace=False)).astype(np.int64)
+    iA = rng.choice(A_to_sparse, nX)
+    iI = rng.integers(0, nI, nX)
+    o = np.lexsort((iI, iA)); iA, iI = iA[o], iI[o]
+    hcdefs = np.linspace(-50.0, 3000.0, nhc)
+    em = rng.random(nI) * 2900.0
+    em[rng.random(nI) < 0.3] = np.nan
+    proj = 1e9 * (1.0 + rng.random(nA_real))
+    g = dict(config="random", nx=nI, ny=1, dx=1.0, x_fastest=False, nI=nI, nA=nA, im=im, jm=jm,
+             ex_indices=np.stack([iA, iI], axis=1).astype(np.int32), ex_area=1e6 * (0.5 + rng.random(nX)),
+             A_to_sparse=A_to_sparse, A_native_area=proj * 1.01, A_proj_area=proj, hcdefs=hcdefs,
+             hc_stride_A=1, hc_stride_HC=nA, interp_style=0, I_centroid_xy=np.zeros((nI, 2)))
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    rm = mm.regrid_matrices("greenland", em)
+    for name in ("AvI", "EvI", "IvE", "EvA", "XvE"):
+        assert_same_weighted(rm.matrix_d(name, scale=True, correctA=True), rg.matrix_d(name, em, scale=True, correctA=True),
+                             "%s nA=%d" % (name, nA_real))
