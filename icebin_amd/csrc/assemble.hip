@@ -701,6 +701,106 @@ __global__ void k_scale(const int32_t *__restrict__ row, const int32_t *__restri
 // ---- shared: sorted (row,col,idx) contributions -> Weighted CSR ---------------------------------
 struct Triplets { uint64_t *keys, *keys_alt; uint32_t *idx, *idx_alt; double *term; size_t n; };
 
+// ---- contributions -> CSR for matrices with short rows (IvA, IvE, XvA, XvE: 1-8 contributions per row) ----
+// No ordering of the whole list: contributions are dropped into per-row slots (integer atomics: the
+// slot inside a row is arbitrary, the SET is not) and one thread per row lists its entries in
+// ascending (column, emission index) order by repeated selection, summing equal columns in emission
+// order with the first term assigned -- exactly what the sort-based path produces.  Rows of more than
+// SR_MAX contributions set a flag and the caller falls back to that path.
+constexpr int SRB_MAX = 32;
+__global__ void k_srb_count(const uint64_t *__restrict__ keys, size_t n, uint32_t *__restrict__ cnt) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) atomicAdd(&cnt[keys[k] >> 32], 1u);
+}
+__global__ void k_srb_scatter(const uint64_t *__restrict__ keys, size_t n, const uint32_t *__restrict__ slotptr,
+                              uint32_t *__restrict__ fillr, uint32_t *__restrict__ scol, uint32_t *__restrict__ sidx) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t key = keys[k];
+    const uint32_t r = (uint32_t)(key >> 32);
+    const uint32_t p = slotptr[r] + atomicAdd(&fillr[r], 1u);
+    scol[p] = (uint32_t)key;
+    sidx[p] = (uint32_t)k;                   // emission index (contributions are still in emission order)
+}
+// next (col, idx) pair after (pc, pi) in the row's slots; returns false when there is none
+__device__ __forceinline__ bool srb_next(const uint32_t *__restrict__ scol, const uint32_t *__restrict__ sidx, uint32_t b,
+                                         uint32_t e, bool first, uint32_t pc, uint32_t pi, uint32_t &bc, uint32_t &bi) {
+    bool any = false;
+    for (uint32_t j = b; j < e; ++j) {
+        const uint32_t c = scol[j], i = sidx[j];
+        const bool after = first || c > pc || (c == pc && i > pi);
+        if (after && (!any || c < bc || (c == bc && i < bi))) { bc = c; bi = i; any = true; }
+    }
+    return any;
+}
+__global__ void k_srb_unique(const uint32_t *__restrict__ slotptr, int nrow, const uint32_t *__restrict__ scol,
+                             uint32_t *__restrict__ ucnt, uint32_t *__restrict__ too_long) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    const uint32_t b = slotptr[r], e = slotptr[r + 1];
+    if (e - b > (uint32_t)SRB_MAX) { *too_long = 1u; ucnt[r] = 0; return; }
+    uint32_t u = 0;
+    for (uint32_t j = b; j < e; ++j) {        // distinct columns: count the first occurrence of each
+        bool seen = false;
+        for (uint32_t q = b; q < j; ++q) seen = seen || scol[q] == scol[j];
+        u += seen ? 0u : 1u;
+    }
+    ucnt[r] = u;
+}
+__global__ void k_srb_emit(const uint32_t *__restrict__ slotptr, int nrow, const uint32_t *__restrict__ scol,
+                           const uint32_t *__restrict__ sidx, const double *__restrict__ term,
+                           const int32_t *__restrict__ rowptr, int32_t *__restrict__ row, int32_t *__restrict__ col,
+                           double *__restrict__ val) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    const uint32_t b = slotptr[r], e = slotptr[r + 1];
+    int out = rowptr[r] - 1;
+    uint32_t pc = 0, pi = 0, bc = 0, bi = 0;
+    bool first = true;
+    double s = 0.0;
+    while (srb_next(scol, sidx, b, e, first, pc, pi, bc, bi)) {
+        if (first || bc != pc) {               // a new (row, col): the first term is assigned
+            if (!first) val[out] = s;
+            ++out;
+            row[out] = r; col[out] = (int32_t)bc;
+            s = term[bi];
+        } else {
+            s = s + term[bi];                  // duplicates in emission order
+        }
+        pc = bc; pi = bi; first = false;
+    }
+    if (!first) val[out] = s;
+}
+// returns false (nothing built) when a row is too long for the per-thread selection
+static bool build_csr_short_rows(ibh_weighted *w, const Triplets &t, int nrow, int ncol, int32_t **row_out, hipStream_t st) {
+    Arena &A = arena();
+    const int T = 256;
+    uint32_t *cnt = A.get<uint32_t>(2 * (size_t)nrow + 2), *fillr = cnt + nrow, *too_long = fillr + nrow, *d_nnz = too_long + 1;
+    uint32_t *slotptr = A.get<uint32_t>((size_t)nrow + 1), *ucnt = A.get<uint32_t>((size_t)nrow);
+    uint32_t *scol = A.get<uint32_t>(t.n), *sidx = A.get<uint32_t>(t.n);
+    IBH_HIP(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (2 * (size_t)nrow + 2), st));
+    hipLaunchKernelGGL(k_srb_count, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, cnt);
+    exclusive_scan_u32(cnt, slotptr, (size_t)nrow, slotptr + nrow, st);
+    hipLaunchKernelGGL(k_srb_scatter, dim3(ceil_div(t.n, T)), dim3(T), 0, st, t.keys, t.n, slotptr, fillr, scol, sidx);
+    hipLaunchKernelGGL(k_srb_unique, dim3(ceil_div(nrow, T)), dim3(T), 0, st, slotptr, nrow, scol, ucnt, too_long);
+    w->rowptr.alloc((size_t)nrow + 1);
+    exclusive_scan_u32(ucnt, reinterpret_cast<uint32_t *>(w->rowptr.p), (size_t)nrow, d_nnz, st);
+    uint32_t h[2];
+    readback_sync(h, too_long, sizeof(h), st);
+    if (h[0]) return false;
+    const uint32_t nnz = h[1];
+    IBH_CHECK(nnz < (1u << 31), "nnz overflows int32");
+    w->nrow = nrow; w->ncol = ncol; w->nnz = nnz;
+    IBH_HIP(hipMemcpyAsync(w->rowptr.p + nrow, d_nnz, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    w->colind.alloc(nnz); w->val.alloc(nnz);
+    int32_t *row = A.get<int32_t>(nnz);
+    hipLaunchKernelGGL(k_srb_emit, dim3(ceil_div(nrow, T)), dim3(T), 0, st, slotptr, nrow, scol, sidx, t.term, w->rowptr.p, row,
+                       w->colind.p, w->val.p);
+    IBH_HIP(hipGetLastError());
+    *row_out = row;
+    return true;
+}
+
 static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, int ncol, int32_t **row_out,
                                          hipStream_t st, bool expect_local = true) {
     Arena &A = arena();
@@ -714,6 +814,12 @@ static void build_csr_from_contributions(ibh_weighted *w, Triplets t, int nrow, 
         *row_out = nullptr;
         return;
     }
+    // ice / exchange rows with a handful of contributions each: per-row slots, no ordering of the list
+    // (measured: always for ~1 contribution per row; with 2+ per row -- IvE -- only while the build is
+    // launch-bound, at 35 M contributions the radix passes are cheaper than the per-row selection)
+    if (!expect_local && nrow > 0 && t.n <= 8 * (size_t)nrow && (2 * t.n <= 3 * (size_t)nrow || t.n < (4u << 20)) &&
+        get_tuning("assemble_short_rows", 1) && build_csr_short_rows(w, t, nrow, ncol, row_out, st))
+        return;
     // Order analysis + piece sort, then (speculatively, on the data as it stands) the duplicate
     // flags and their scan: ONE host synchronisation returns both the analysis and nnz.  Only when a
     // piece was too long for LDS (nothing was touched) does the radix sort run and the tail repeat.
