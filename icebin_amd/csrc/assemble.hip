@@ -484,7 +484,21 @@ __global__ void k_rowptr_fill(const int32_t *__restrict__ row, long nnz, int nro
     }
     rowptr[q] = (int32_t)lo;
 }
+__global__ void k_rowptr_search(const int32_t *__restrict__ row, long nnz, int nrow, int32_t *__restrict__ rowptr) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nrow) return;
+    long lo = 0, hi = nnz;                       // first entry whose row is >= q
+    while (lo < hi) {
+        const long mid = lo + ((hi - lo) >> 1);
+        if (row[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    rowptr[q] = (int32_t)lo;
+}
 static void rowptr_from_rows(const int32_t *row, long nnz, int nrow, int32_t *rowptr, hipStream_t st) {
+    if (nrow < (1 << 16)) {                      // few rows: one launch, every row searches (the small builds are launch-bound)
+        hipLaunchKernelGGL(k_rowptr_search, dim3(ceil_div(nrow + 1, 256)), dim3(256), 0, st, row, nnz, nrow, rowptr);
+        return;
+    }
     IBH_HIP(hipMemsetAsync(rowptr, 0xFF, sizeof(int32_t) * ((size_t)nrow + 1), st));
     if (nnz) hipLaunchKernelGGL(k_rowptr_heads, dim3(ceil_div(nnz, 256)), dim3(256), 0, st, row, nnz, rowptr);
     hipLaunchKernelGGL(k_rowptr_fill, dim3(ceil_div(nrow + 1, 256)), dim3(256), 0, st, row, nnz, nrow, rowptr);
