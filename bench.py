@@ -9,8 +9,9 @@ from HBM ("cold" numbers).
 
 N GPUs (torchrun, one rank per GPU): the fields of a 64*N-field regrid are sharded by field
 across ranks (each rank applies the replicated CSR to its own 64 fields; zero communication
-in the SpMM), then one RCCL all-gather reassembles the [64*N, nrow] result on every rank.  The
-gather of step i overlaps the SpMM of step i+1 on a second stream.  Scaling is weak.
+in the SpMM), then RCCL all-gathers reassemble the [64*N, nrow] results on every rank: one collective
+per --steps-per-gather applies (default 64: a 64 x 122 result is 62 KB, far below the size at which a
+collective is bandwidth-bound), issued on a second stream so it overlaps the following SpMMs.  Scaling is weak.
 
 Prints ONE JSON line on rank 0.
 """
