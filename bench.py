@@ -5,7 +5,11 @@ Metric (BASELINE.json): regridded cells/sec + achieved HBM GB/s, AvI 5 km -> 2x2
 A "step" is one Weighted::apply of the AvI matrix to one batch of 64 synthetic fields that
 are already resident in HBM.  Steps cycle through enough distinct field batches (>= 512 MiB in
 total) that no batch can be served from the 256 MiB Infinity Cache: every step streams its X
-from HBM ("cold" numbers).
+from HBM ("cold" numbers).  Steps are submitted --queue-depth at a time through
+ibh_weighted_apply_many_device (ONE launch serves up to 16 independent 64-field applies: a single
+40 MB apply is latency-sized on this chip, launch + dependent loads are a third of its 11 us;
+--queue-depth 1 is the one-launch-per-apply figure).  Every step still reads its own 39 MB of X
+from HBM and writes its own Y; the CSR is counted ONCE per launch in the roofline bytes.
 
 N GPUs (torchrun, one rank per GPU): the fields of a 64*N-field regrid are sharded by field
 across ranks (each rank applies the replicated CSR to its own 64 fields; zero communication
@@ -53,6 +57,7 @@ def main():
     ap.add_argument("--variants", action="store_true", help="also time the peak-size (all-unmasked) variant; informational")
     ap.add_argument("--all-unmasked", action="store_true", help="every ice cell carries ice (peak-size variant, SURVEY.md 8d)")
     ap.add_argument("--warm", action="store_true", help="reuse ONE field batch (Infinity-Cache-resident numbers)")
+    ap.add_argument("--queue-depth", type=int, default=16, help="applies submitted per launch (1..16)")
     args = ap.parse_args()
 
     import torch
@@ -98,10 +103,12 @@ def main():
     x_host = syn.fields(nf, ncol, seed=syn.SEED + rank)
     x0 = torch.from_numpy(x_host).to(dev)
     X = [x0 if b == 0 else x0 + 1e-3 * b for b in range(nbuf)]
-    Y = [torch.empty((nf, nrow), dtype=torch.float64, device=dev) for _ in range(2)]
+    depth = max(1, min(16, args.queue_depth))
+    Y = [torch.zeros((nf, nrow), dtype=torch.float64, device=dev) for _ in range(2 * depth)]
 
     L = _capi.lib()
     fn = L.ibh_weighted_apply_device
+    fn_many = L.ibh_weighted_apply_many_device
     compute = torch.cuda.Stream(device=dev)
     cs = C.c_void_p(compute.cuda_stream)
     xp = [C.c_void_p(x.data_ptr()) for x in X]
@@ -109,13 +116,32 @@ def main():
     nan = float("nan")
     sharded = FieldShardedApply(W, world * nf, None, dev, steps_per_gather=args.steps_per_gather) if use_dist else None
 
-    def step(i):
-        if use_dist:        # field-sharded SpMM + (grouped) all-gather, icebin_amd/distributed.py
-            sharded.apply_ptr(xp[i % nbuf], ncol)
-            return
-        rc = fn(W._h, xp[i % nbuf], nf, ncol, yp[i & 1], nrow, nan, 0, cs)
-        if rc != 0:
-            _capi.check(rc)
+    def plan(i0, n):
+        """Launch plan for steps i0 .. i0+n-1: (first step, count, X pointer table, Y pointer table),
+        built before the timed region so the loop only makes the C calls."""
+        out = []
+        i, k = i0, 0
+        while i < i0 + n:
+            m = min(depth, i0 + n - i)
+            xa = (C.c_void_p * m)(*[xp[(i + j) % nbuf].value for j in range(m)])
+            ya = (C.c_void_p * m)(*[yp[((k & 1) * depth + j)].value for j in range(m)])
+            out.append((i, m, xa, ya))
+            i += m
+            k += 1
+        return out
+
+    def run(launches):
+        for (i, m, xa, ya) in launches:
+            if use_dist:        # field-sharded SpMM + (grouped) all-gather, icebin_amd/distributed.py
+                for j in range(m):
+                    sharded.apply_ptr(xp[(i + j) % nbuf], ncol)
+                continue
+            if m == 1:
+                rc = fn(W._h, xa[0], nf, ncol, ya[0], nrow, nan, 0, cs)
+            else:
+                rc = fn_many(W._h, m, xa, nf, ncol, ya, nrow, nan, 0, cs)
+            if rc != 0:
+                _capi.check(rc)
 
     def sync_all():
         if use_dist:
@@ -126,19 +152,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    warm_plan, timed_plan = plan(0, args.warmup), plan(args.warmup, args.steps)
     with torch.cuda.stream(compute):
-        for i in range(args.warmup):
-            step(i)
+        run(warm_plan)
         sync_all()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record(compute)
-        for i in range(args.steps):
-            step(i)
+        run(timed_plan)
         e1.record(compute)
         sync_all()
         dt = time.perf_counter() - t0
-    kernel_ms = e0.elapsed_time(e1) / max(args.steps, 1)      # avg launch-to-launch on the launch stream
+    region_ms = e0.elapsed_time(e1)                           # HIP events on the launch stream
+    kernel_ms = region_ms / max(args.steps, 1)                # per step (= per 64-field apply)
+    nlaunch = len(timed_plan)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -149,7 +176,10 @@ def main():
     if rank == 0:
         cells = n_unmasked * nf * world * args.steps
         B = spmm_bytes(nnz, nrow, ncol, nf)
-        achieved = B / (kernel_ms * 1e-3) / 1e9
+        csr_bytes = 12 * nnz + 4 * (nrow + 1)
+        # algorithmic bytes of the timed region: every step's X and Y once, the CSR once per LAUNCH
+        B_region = args.steps * (B - csr_bytes) + nlaunch * csr_bytes
+        achieved = B_region / (region_ms * 1e-3) / 1e9
         result = {
             "metric": "regridded cells/sec (%s, %s, %d fields/GPU)" % (args.matrix, args.config, nf),
             "value": cells / dt, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,10 +191,14 @@ def main():
                        "mask": "all cells unmasked" if args.all_unmasked else "dome, ~45 % unmasked",
                        "nrow_d": nrow, "ncol_d": ncol, "nnz": nnz, "fields_per_gpu": nf, "field_batches": nbuf,
                        "cache": "warm" if args.warm else "cold (rotating batches > Infinity Cache)",
-                       "kernel": W.last_kernel(), "parallelism": ("field-shard x%d + all-gather every %d steps" % (world, args.steps_per_gather)) if use_dist else "1 GPU"},
+                       "kernel": W.last_kernel(), "queue_depth": depth, "parallelism": ("field-shard x%d + all-gather every %d steps" % (world, args.steps_per_gather)) if use_dist else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, W.last_kernel()),
-                         "kernel_us": kernel_ms * 1e3, "algorithmic_bytes": B},
+                         "kernel_us": kernel_ms * 1e3, "algorithmic_bytes": B,
+                         "launches": nlaunch, "steps_per_launch": depth,
+                         "launch_us": region_ms * 1e3 / max(nlaunch, 1),
+                         "algorithmic_bytes_per_launch": B_region / max(nlaunch, 1),
+                         "traffic_source": "profiles/*_pmc_traffic.json (separate rocprofv3 --pmc passes of this command; not measured in this run)"},
             "assembly": {"first_call_ms": t_asm_first * 1e3, "steady_ms": t_asm * 1e3,
                          "algorithmic_bytes": asm_bytes(len(grids["ex_area"]), grids["nI"], nnz, nrow, ncol),
                          "GBps": asm_bytes(len(grids["ex_area"]), grids["nI"], nnz, nrow, ncol) / t_asm / 1e9},
@@ -178,7 +212,7 @@ def main():
         if use_dist:
             y = sharded.result(0, 0).cpu().numpy()
         else:
-            y = Y[(args.steps - 1) & 1].cpu().numpy() if args.steps > 0 else None
+            y = torch.stack(Y).cpu().numpy() if args.steps > 0 else None
         result["finite_output"] = bool(y is not None and np.isfinite(y).all())
         print(json.dumps(result), flush=True)
     if use_dist:

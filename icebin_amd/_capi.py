@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libicebin_hip.so")
+LIB_PATH = os.environ.get("ICEBIN_HIP_LIB") or os.path.join(_HERE, "lib", "libicebin_hip.so")   # override: experiment builds only
 
 IBH_OK, IBH_EINVAL, IBH_ENODEVICE, IBH_EHIP, IBH_ERANGE, IBH_ENOTIMPL, IBH_ENOKEY = 0, -1, -2, -3, -4, -5, -6
 
@@ -75,6 +75,9 @@ _SIGS = {
                                          C.c_double, C.c_int]),
     "ibh_weighted_apply_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
                                            C.c_double, C.c_int, C.c_void_p]),
+    "ibh_weighted_apply_many_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
+                                                C.c_int64, C.c_double, C.c_int, C.c_void_p]),
+    "ibh_weighted_reserve": (C.c_int, [C.c_void_p, C.c_int32]),
     "ibh_weighted_apply_transformed_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
                                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_double,
                                                        C.c_void_p]),

@@ -29,16 +29,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, variant=None, extra_flags=()):
+    """variant/extra_flags: experiment builds (scratch/), e.g. variant="nt", extra_flags=["-DIBH_X_AUX=2"]
+    -> lib/libicebin_hip_nt.so, loaded with ICEBIN_HIP_LIB=<path>.  The product build takes neither."""
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
+    tag = "" if not variant else "_" + variant
+    lib = LIB if not variant else os.path.join(LIBDIR, "libicebin_hip%s.so" % tag)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        obj = os.path.join(LIBDIR, s.replace(".hip", tag + ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([_hipcc()] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([_hipcc()] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -51,10 +55,12 @@ def build_library(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs)
-    return LIB
+    if jobs or force or _stale(lib, objs):
+        run([_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    variant = args[0] if args else None
+    print(build_library(force="--force" in sys.argv, verbose=True, variant=variant, extra_flags=args[1:]))

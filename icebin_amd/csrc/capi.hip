@@ -434,6 +434,22 @@ int ibh_weighted_apply_device(const ibh_weighted *w, const double *dA, int32_t n
         spmm_launch(w, dA, nvar, lda, dB, ldb, fill, force_conservation, static_cast<hipStream_t>(stream));
     });
 }
+int ibh_weighted_apply_many_device(const ibh_weighted *w, int32_t nbatch, const double *const *dA, int32_t nvar,
+                                   int64_t lda, double *const *dB, int64_t ldb, double fill, int force_conservation,
+                                   void *stream) {
+    return guarded([&] {
+        check_weighted_device(w);
+        IBH_CHECK(nbatch >= 0 && nvar >= 0 && (nbatch == 0 || nvar == 0 || (dA && dB)), "bad arguments");
+        spmm_launch_many(w, nbatch, dA, nvar, lda, dB, ldb, fill, force_conservation, static_cast<hipStream_t>(stream));
+    });
+}
+int ibh_weighted_reserve(const ibh_weighted *w, int32_t nvar) {
+    return guarded([&] {
+        check_weighted_device(w);
+        IBH_CHECK(nvar >= 0, "bad arguments");
+        weighted_reserve(w, nvar);
+    });
+}
 int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nvar, int64_t lda, double *B_b,
                             int64_t ldb, double fill, int force_conservation) {
     return guarded([&] {

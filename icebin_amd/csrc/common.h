@@ -174,6 +174,7 @@ struct ibh_weighted {
     mutable int last_kernel = 0;
     // apply_transformed: scratch fields + small transform, and M*1 (row sums) for the offset term
     mutable ibh::DevBuf<double> scratch, tbuf, rowsum1;
+    mutable ibh::DevBuf<double> consv;  // force_conservation: the two dot products per variable [2*nvar]
     mutable ibh::DevBuf<double> xt;     // shortrow: transposed copy of the (small) input fields
     // rowdual (EvI, EvX): the CSR filtered to one entry per (GCM cell, ice cell) carrying the weights of
     // BOTH elevation classes the cell lies between (assemble.hip build_bands); band r = row r
@@ -192,6 +193,9 @@ namespace ibh {
 // spmm.hip
 void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda, double *dB, int64_t ldb,
                  double fill, int force_conservation, hipStream_t stream);
+void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA, int nvar, int64_t lda,
+                      double *const *dB, int64_t ldb, double fill, int force_conservation, hipStream_t stream);
+void weighted_reserve(const ibh_weighted *w, int nvar);
 void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_in, int64_t lda, const double *T,
                               const double *b, int nvar_out, double *dB, int64_t ldb, double fill, hipStream_t stream);
 void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int64_t lda, double *dout,

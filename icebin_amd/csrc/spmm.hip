@@ -25,19 +25,32 @@
 //    Y stores -- is fully coalesced (512 B per wave-store, non-temporal); the
 //    small X (nf x nA_d) is served from L2.
 #include "common.h"
+#include <mutex>
 
 namespace ibh {
 
 // ---- tuning knobs (ibh_set_tuning) ---------------------------------------------------------
-static std::unordered_map<std::string, int> &tuning() {
-    static std::unordered_map<std::string, int> t;
-    return t;
-}
+// Process-wide and read on every apply while another host thread may be calling ibh_set_tuning:
+// guarded by a mutex (an uncontended lock is ~20 ns against a >= 3 us launch).
+namespace {
+struct Tuning {
+    std::mutex mu;
+    std::unordered_map<std::string, int> map;
+};
+Tuning &tuning() { static Tuning *t = new Tuning; return *t; }
+}  // namespace
 int get_tuning(const char *key, int dflt) {
-    auto it = tuning().find(key);
-    return it == tuning().end() ? dflt : it->second;
+    Tuning &t = tuning();
+    std::lock_guard<std::mutex> lk(t.mu);
+    if (t.map.empty()) return dflt;
+    auto it = t.map.find(key);
+    return it == t.map.end() ? dflt : it->second;
 }
-void set_tuning(const char *key, int value) { tuning()[key] = value; }
+void set_tuning(const char *key, int value) {
+    Tuning &t = tuning();
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.map[key] = value;
+}
 
 // ---- helpers -------------------------------------------------------------------------------
 // Sum over the 64 lanes of a wave, result valid in every lane.  DPP moves instead of ds_bpermute:
@@ -94,7 +107,8 @@ __device__ __forceinline__ bool block_to_task(int b, int nrow, int nfc, int mode
         }
         return r < nrow;
     }
-    const int logical = xcd_contiguous(b, nrow * nfc);
+    const int logical = xcd_contiguous(b, (int)gridDim.x);     // gridDim.x = nrow*nfc rounded up to a multiple of 8
+    if (logical >= nrow * nfc) return false;
     r = logical / nfc;
     fc = logical - r * nfc;
     return true;
@@ -109,18 +123,30 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // buffer_load + one FMA instead of a 64-bit address computation per load; at the 40 MB headline
 // size the kernel is as much instruction-issue- as bandwidth-limited.
 __device__ __forceinline__ double xload(__amdgpu_buffer_rsrc_t rs, int byte_off) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0));
+#ifndef IBH_X_AUX
+#define IBH_X_AUX 0
+#endif
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, IBH_X_AUX));
 }
+
+// Field batches of one launch (ibh_weighted_apply_many_device): batch q reads x[q] and writes y[q],
+// all with the same nvar / leading dimensions.  Passed by value in the kernarg segment, so a launch
+// needs no device-side pointer table and stays stream-ordered and graph-capturable.
+struct BatchPtrs {
+    const double *x[IBH_MAX_BATCH];
+    double *y[IBH_MAX_BATCH];
+};
 
 // FPW = fields per wave, WK = waves that split the nnz range of the row, NW = waves per workgroup.
 // The NW waves form WF = NW/WK groups over fields; a block covers FB = FPW*WF fields and stages
 // the row segment once for all of them.
-// DIAG builds (dev only, ibh_set_tuning("rowblock_diag_*")) stamp s_memtime at the phase boundaries
-// of wave 0 of every workgroup into a side buffer; the product kernel (DIAG == false) has no stamps.
-#define IBH_STAMP(slot)                                                                         \
-    do {                                                                                        \
-        if (DIAG && threadIdx.x == 0) diag[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
+//
+// Batched launches (nbatch > 1): blockIdx.y = batch group; a workgroup serves `qi` consecutive
+// batches of its (row, field chunk) with the row segment staged ONCE (rows of <= RB_SEG entries).
+// A 40 MB apply is a latency-sized problem on this chip (launch + rowptr -> segment -> X are
+// ~4 us of an 11 us launch); in one launch over several batches the workgroups of batch q+1 start
+// while those of batch q still stream, so the prologue and the drain are paid once per LAUNCH.
+//
 // DUAL (EvI, EvX; WK == 1): the "row" is a BAND -- the ice cells of one GCM cell whose elevation lies
 // between two neighbouring classes.  Such a cell is a column of two rows of M (weights 1-r and r on
 // the lower and the upper class); as a band entry it carries both values (vals, vals2; bits 30/31 of
@@ -129,15 +155,14 @@ __device__ __forceinline__ double xload(__amdgpu_buffer_rsrc_t rs, int byte_off)
 // then stores the two partial sums of the band (Y = lower-class sums, Y2 = upper-class sums, no
 // fill); dual_combine_kernel adds, for every row, its own lower sum and the upper sum of the band
 // below it.  The band arrays are a filtered copy of the CSR (assemble.hip build_bands).
-template <int FPW, int WK, int UNROLL, int NW, bool DIAG = false, bool DUAL = false>
+template <int FPW, int WK, int UNROLL, int NW, bool DUAL = false>
 __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
-    const double *__restrict__ X, long ldx, int ncol, double *__restrict__ Y, long ldy, int nrow, int nf, int nfc,
-    int xcd_mode, const double *__restrict__ wM, double fill, unsigned long long *__restrict__ diag = nullptr,
+    const BatchPtrs bp, int nbatch, int qi, long ldx, int ncol, long ldy, int nrow, int nf, int nfc,
+    int xcd_mode, const double *__restrict__ wM, double fill,
     const double *__restrict__ vals2 = nullptr, double *__restrict__ Y2 = nullptr)
 {
     static_assert(!DUAL || WK == 1, "bands are not split across waves");
-    IBH_STAMP(0);
     constexpr int RB_THREADS = NW * 64;
     constexpr int RB_STAGE = RB_SEG / RB_THREADS;
     constexpr int WF = NW / WK;
@@ -155,20 +180,11 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // provably wave-uniform
     const int wf = wave % WF, wk = wave / WF;
     const int f0 = fc * FB + wf * FPW;
-
-    __amdgpu_buffer_rsrc_t rs[FPW];
-#pragma unroll
-    for (int j = 0; j < FPW; ++j) {
-        const int f = f0 + j < nf ? f0 + j : nf - 1;    // clamp: tail fields read valid memory, never stored
-        rs[j] = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)f * ldx), 0, ncol * 8, 0x00020000);
-    }
-    double acc[FPW], acc2[DUAL ? FPW : 1];
-#pragma unroll
-    for (int j = 0; j < FPW; ++j) { acc[j] = 0.0; if (DUAL) acc2[j] = 0.0; }
+    const int q0 = blockIdx.y * qi, q1 = min(nbatch, q0 + qi);
 
     const int beg = rowptr[r], end = rowptr[r + 1];
-    if (DIAG && threadIdx.x == 0) { diag[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(end - beg); }
-    IBH_STAMP(1);
+    const bool one_seg = end - beg <= RB_SEG;
+    const bool dead = DUAL ? false : wM[r] == 0.0;     // mask_result, IceCoupler.cpp:186-201
     // The row is walked in segments of RB_SEG entries staged in LDS.  The loads of segment s+1 are
     // issued before segment s is processed (they fly while X streams) and written to LDS after it.
     int cc[RB_STAGE];
@@ -189,119 +205,128 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
             if (k < n) { s_col[k] = cc[i]; s_val[k] = vv[i]; if (DUAL) s_val2[k] = vv2[i]; }
         }
     };
-    if (beg < end) {
-        stage_load(beg, min(RB_SEG, end - beg));
-        stage_store(min(RB_SEG, end - beg));
-        __syncthreads();
-    }
-    IBH_STAMP(2);
-    for (int seg = beg; seg < end; seg += RB_SEG) {
-        const int n = min(RB_SEG, end - seg);
-        const int nxt = seg + RB_SEG;
-        const bool more = nxt < end;
-        if (more) stage_load(nxt, min(RB_SEG, end - nxt));
-        // Full batches: every lane issues UNROLL*FPW loads before the first FMA, no predication.
-        const int nfull = n - n % BATCH;
-        int kb = 0;
-        for (; kb < nfull; kb += BATCH) {
-            int off[UNROLL];
-            double v[UNROLL], v2[DUAL ? UNROLL : 1];
-            bool h0[DUAL ? UNROLL : 1], h1[DUAL ? UNROLL : 1];
+
+    for (int q = q0; q < q1; ++q) {
+        const double *__restrict__ X = bp.x[q];
+        double *__restrict__ Y = bp.y[q];
+        __amdgpu_buffer_rsrc_t rs[FPW];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int k = kb + wk * 64 + lane + u * STEP;
-                const int c = s_col[k];
-                off[u] = DUAL ? (c & 0x3fffffff) << 3 : c << 3;
-                v[u] = s_val[k];
-                if (DUAL) { v2[u] = s_val2[k]; h0[u] = (c >> 30) & 1; h1[u] = c < 0; }
-            }
-            double x[FPW][UNROLL];
-#pragma unroll
-            for (int j = 0; j < FPW; ++j)
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) x[j][u] = xload(rs[j], off[u]);
-#pragma unroll
-            for (int j = 0; j < FPW; ++j)
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    if (DUAL) {                          // a missing partner is never multiplied (0*NaN)
-                        acc[j] = h0[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
-                        acc2[j] = h1[u] ? fma(v2[u], x[j][u], acc2[j]) : acc2[j];
-                    } else acc[j] = fma(v[u], x[j][u], acc[j]);
-                }
+        for (int j = 0; j < FPW; ++j) {
+            const int f = f0 + j < nf ? f0 + j : nf - 1;    // clamp: tail fields read valid memory, never stored
+            rs[j] = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)f * ldx), 0, ncol * 8, 0x00020000);
         }
-        IBH_STAMP(3);
-        // Tail batch: lanes past the end re-read the last entry and are masked at the FMA (never
-        // multiplied by 0: 0*NaN must not leak into a row).
-        if (kb + wk * 64 < n) {
-            int off[UNROLL];
-            double v[UNROLL], v2[DUAL ? UNROLL : 1];
-            bool ok[UNROLL], ok2[DUAL ? UNROLL : 1];
+        double acc[FPW], acc2[DUAL ? FPW : 1];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int k = kb + wk * 64 + lane + u * STEP;
-                ok[u] = k < n;
-                const int kk = ok[u] ? k : n - 1;
-                const int c = s_col[kk];
-                off[u] = DUAL ? (c & 0x3fffffff) << 3 : c << 3;
-                v[u] = s_val[kk];
-                if (DUAL) { v2[u] = s_val2[kk]; ok2[u] = ok[u] && c < 0; ok[u] = ok[u] && ((c >> 30) & 1); }
-            }
-            double x[FPW][UNROLL];
-#pragma unroll
-            for (int j = 0; j < FPW; ++j)
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) x[j][u] = xload(rs[j], off[u]);
-#pragma unroll
-            for (int j = 0; j < FPW; ++j)
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    acc[j] = ok[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
-                    if (DUAL) acc2[j] = ok2[u] ? fma(v2[u], x[j][u], acc2[j]) : acc2[j];
-                }
-        }
-        if (more) {
-            __syncthreads();                      // every wave is done reading this segment
-            stage_store(min(RB_SEG, end - nxt));
+        for (int j = 0; j < FPW; ++j) { acc[j] = 0.0; if (DUAL) acc2[j] = 0.0; }
+
+        if (beg < end && (q == q0 || !one_seg)) {       // a row of one segment stays staged for every batch
+            stage_load(beg, min(RB_SEG, end - beg));
+            if (q != q0) __syncthreads();               // every wave is done with the previous batch's last segment
+            stage_store(min(RB_SEG, end - beg));
             __syncthreads();
         }
-    }
-    if (DIAG) { double t = 0; for (int j = 0; j < FPW; ++j) t += acc[j]; if (t == 1.2345e301) diag[1 << 20] = 1; }   // consume the loads before stamping
-    IBH_STAMP(4);
+        for (int seg = beg; seg < end; seg += RB_SEG) {
+            const int n = min(RB_SEG, end - seg);
+            const int nxt = seg + RB_SEG;
+            const bool more = nxt < end;
+            if (more) stage_load(nxt, min(RB_SEG, end - nxt));
+            // Full batches: every lane issues UNROLL*FPW loads before the first FMA, no predication.
+            const int nfull = n - n % BATCH;
+            int kb = 0;
+            for (; kb < nfull; kb += BATCH) {
+                int off[UNROLL];
+                double v[UNROLL], v2[DUAL ? UNROLL : 1];
+                bool h0[DUAL ? UNROLL : 1], h1[DUAL ? UNROLL : 1];
 #pragma unroll
-    for (int j = 0; j < FPW; ++j) acc[j] = wave_sum(acc[j]);
-    IBH_STAMP(5);
-    if (DUAL) {                          // partial sums of the band; fill and the pairing happen in dual_combine_kernel
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int k = kb + wk * 64 + lane + u * STEP;
+                    const int c = s_col[k];
+                    off[u] = DUAL ? (c & 0x3fffffff) << 3 : c << 3;
+                    v[u] = s_val[k];
+                    if (DUAL) { v2[u] = s_val2[k]; h0[u] = (c >> 30) & 1; h1[u] = c < 0; }
+                }
+                double x[FPW][UNROLL];
 #pragma unroll
-        for (int j = 0; j < FPW; ++j) acc2[j] = wave_sum(acc2[j]);
-        if (lane == 0) {
+                for (int j = 0; j < FPW; ++j)
 #pragma unroll
-            for (int j = 0; j < FPW; ++j)
-                if (f0 + j < nf) { Y[(long)(f0 + j) * ldy + r] = acc[j]; Y2[(long)(f0 + j) * ldy + r] = acc2[j]; }
+                    for (int u = 0; u < UNROLL; ++u) x[j][u] = xload(rs[j], off[u]);
+#pragma unroll
+                for (int j = 0; j < FPW; ++j)
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
+                        if (DUAL) {                          // a missing partner is never multiplied (0*NaN)
+                            acc[j] = h0[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
+                            acc2[j] = h1[u] ? fma(v2[u], x[j][u], acc2[j]) : acc2[j];
+                        } else acc[j] = fma(v[u], x[j][u], acc[j]);
+                    }
+            }
+            // Tail batch: lanes past the end re-read the last entry and are masked at the FMA (never
+            // multiplied by 0: 0*NaN must not leak into a row).
+            if (kb + wk * 64 < n) {
+                int off[UNROLL];
+                double v[UNROLL], v2[DUAL ? UNROLL : 1];
+                bool ok[UNROLL], ok2[DUAL ? UNROLL : 1];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int k = kb + wk * 64 + lane + u * STEP;
+                    ok[u] = k < n;
+                    const int kk = ok[u] ? k : n - 1;
+                    const int c = s_col[kk];
+                    off[u] = DUAL ? (c & 0x3fffffff) << 3 : c << 3;
+                    v[u] = s_val[kk];
+                    if (DUAL) { v2[u] = s_val2[kk]; ok2[u] = ok[u] && c < 0; ok[u] = ok[u] && ((c >> 30) & 1); }
+                }
+                double x[FPW][UNROLL];
+#pragma unroll
+                for (int j = 0; j < FPW; ++j)
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) x[j][u] = xload(rs[j], off[u]);
+#pragma unroll
+                for (int j = 0; j < FPW; ++j)
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
+                        acc[j] = ok[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
+                        if (DUAL) acc2[j] = ok2[u] ? fma(v2[u], x[j][u], acc2[j]) : acc2[j];
+                    }
+            }
+            if (more) {
+                __syncthreads();                      // every wave is done reading this segment
+                stage_store(min(RB_SEG, end - nxt));
+                __syncthreads();
+            }
         }
-        return;
-    }
-
-    const bool dead = wM[r] == 0.0;     // mask_result, IceCoupler.cpp:186-201
-    if (WK == 1) {
-        if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j < FPW; ++j)
-                if (f0 + j < nf) Y[(long)(f0 + j) * ldy + r] = dead ? fill : acc[j];
+        for (int j = 0; j < FPW; ++j) acc[j] = wave_sum(acc[j]);
+        if (DUAL) {                          // partial sums of the band; fill and the pairing happen in dual_combine_kernel
+#pragma unroll
+            for (int j = 0; j < FPW; ++j) acc2[j] = wave_sum(acc2[j]);
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < FPW; ++j)
+                    if (f0 + j < nf) { Y[(long)(f0 + j) * ldy + r] = acc[j]; Y2[(long)(f0 + j) * ldy + r] = acc2[j]; }
+            }
+            continue;
         }
-        IBH_STAMP(6);
-    } else {
-        if (lane == 0) {
+        if (WK == 1) {
+            if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j < FPW; ++j) s_part[wk][wf * FPW + j] = acc[j];
-        }
-        __syncthreads();
-        if (threadIdx.x < FB) {
-            const int f = fc * FB + threadIdx.x;
-            double s = s_part[0][threadIdx.x];
+                for (int j = 0; j < FPW; ++j)
+                    if (f0 + j < nf) Y[(long)(f0 + j) * ldy + r] = dead ? fill : acc[j];
+            }
+        } else {
+            if (lane == 0) {
 #pragma unroll
-            for (int q = 1; q < WK; ++q) s += s_part[q][threadIdx.x];
-            if (f < nf) Y[(long)f * ldy + r] = dead ? fill : s;
+                for (int j = 0; j < FPW; ++j) s_part[wk][wf * FPW + j] = acc[j];
+            }
+            __syncthreads();
+            if (threadIdx.x < FB) {
+                const int f = fc * FB + threadIdx.x;
+                double s = s_part[0][threadIdx.x];
+#pragma unroll
+                for (int qq = 1; qq < WK; ++qq) s += s_part[qq][threadIdx.x];
+                if (f < nf) Y[(long)f * ldy + r] = dead ? fill : s;
+            }
+            if (q + 1 < q1) __syncthreads();           // s_part is reused by the next batch
         }
     }
 }
@@ -486,19 +511,45 @@ void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int6
 }
 
 // ---- dispatch ------------------------------------------------------------------------------
+void ensure_rowsum1(const ibh_weighted *w, hipStream_t stream);
+// Scratch owned by the handle grows OUTSIDE stream capture only (hipMalloc is illegal while capturing
+// and synchronises the device): ibh_weighted_reserve() sizes it up front; an apply that still finds a
+// buffer too small grows it after a device synchronisation (an earlier apply may be reading the old
+// block), or fails when its stream is being captured.
+template <class T>
+static void grow_scratch(DevBuf<T> &b, size_t count, hipStream_t stream, const char *what) {
+    if (b.p && count * sizeof(T) <= b.granted) { b.n = count; return; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
+    IBH_CHECK(cs == hipStreamCaptureStatusNone,
+              "apply inside a stream capture needs %zu more bytes of %s scratch: call ibh_weighted_reserve() before capturing",
+              count * sizeof(T), what);
+    if (b.p) IBH_HIP(hipDeviceSynchronize());
+    b.alloc(count);
+}
+
+static long rowblock_grid(int nrow, int nfc, int &xcd_mode) {
+    xcd_mode = (nfc % 8 == 0 || nfc == 1 || nfc == 2 || nfc == 4) ? 1 : 0;
+    xcd_mode = get_tuning("rowblock_xcd_mode", xcd_mode);
+    if (xcd_mode == 1 && !(nfc % 8 == 0 || nfc == 1 || nfc == 2 || nfc == 4)) xcd_mode = 0;
+    long nb = ((long)nrow * nfc + 7) & ~7l;
+    if (xcd_mode == 1) {
+        if (nfc < 8) {                        // 8/nfc XCDs per chunk, each a row range of <= ceil(nrow/m) rows
+            const int m = 8 / nfc;
+            nb = 8l * ((nrow + m - 1) / m + 1);
+        } else nb = (long)nrow * nfc;         // nfc % 8 == 0
+    }
+    return nb;
+}
+
 template <int FPW, int WK, int NW>
-static void launch_rowblock(const ibh_weighted *w, const double *dA, int nvar, long lda, double *dB, long ldb,
+static void launch_rowblock(const ibh_weighted *w, const BatchPtrs &bp, int nbatch, int nvar, long lda, long ldb,
                             double fill, hipStream_t stream)
 {
     constexpr int FB = FPW * (NW / WK);
     const int nfc = ceil_div(nvar, FB);
-    int xcd_mode = (nfc % 8 == 0 || nfc == 1 || nfc == 2 || nfc == 4) ? 1 : 0;
-    xcd_mode = get_tuning("rowblock_xcd_mode", xcd_mode);
-    long nb = (long)w->nrow * nfc;
-    if (xcd_mode == 1 && nfc < 8) {           // 8/nfc XCDs per chunk, each a row range of <= ceil(nrow/m) rows
-        const int m = 8 / nfc;
-        nb = 8l * ((w->nrow + m - 1) / m + 1);
-    }
+    int xcd_mode;
+    const long nb = rowblock_grid(w->nrow, nfc, xcd_mode);
     IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
     IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
     // loads in flight per lane and field: enough 64-entry slots to cover a typical row in one batch
@@ -507,21 +558,20 @@ static void launch_rowblock(const ibh_weighted *w, const double *dA, int nvar, l
         const double mean = w->nrow ? (double)w->nnz / (double)w->nrow / (64.0 * WK) : 1.0;
         unroll = mean > 4.0 ? 8 : mean > 2.0 ? 4 : mean > 1.0 ? 2 : 1;
     }
-    if (get_tuning("rowblock_diag_lo", 0) || get_tuning("rowblock_diag_hi", 0)) {
-        auto *diag = reinterpret_cast<unsigned long long *>(((unsigned long long)(unsigned)get_tuning("rowblock_diag_hi", 0) << 32) |
-                                                            (unsigned)get_tuning("rowblock_diag_lo", 0));
-        hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, 8, NW, true>), dim3((unsigned)nb), dim3(NW * 64), 0, stream,
-                           w->rowptr.p, w->colind.p, w->val.p, dA, lda, w->ncol, dB, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill, diag);
-        IBH_HIP(hipGetLastError());
-        return;
+    // batches per workgroup: the staged row segment and the prologue are shared by qi batches
+    int qi = 1;
+    if (nbatch > 1) {
+        qi = get_tuning("rowblock_many_qi", 0);
+        if (qi <= 0) qi = nbatch >= 4 ? 2 : 1;       // measured at the 5 km headline shape: depth 16 7.5 (qi 2) / 8.2 (qi 1) / 8.0 us (qi 8)
+        if (qi > nbatch) qi = nbatch;
     }
+    const dim3 grid((unsigned)nb, (unsigned)ceil_div(nbatch, qi));
 #define IBH_RB(U)                                                                                        \
-    hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U, NW>), dim3((unsigned)nb), dim3(NW * 64), 0, stream, \
-                       w->rowptr.p, w->colind.p, w->val.p, dA, lda, w->ncol, dB, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill)
+    hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U, NW>), grid, dim3(NW * 64), 0, stream,           \
+                       w->rowptr.p, w->colind.p, w->val.p, bp, nbatch, qi, lda, w->ncol, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill)
     if (unroll == 1) IBH_RB(1);
     else if (unroll == 2) IBH_RB(2);
     else if (unroll == 8) IBH_RB(8);
-    else if (unroll == 14 && FPW <= 2) IBH_RB(14);
     else IBH_RB(4);
 #undef IBH_RB
     IBH_HIP(hipGetLastError());
@@ -540,29 +590,31 @@ __global__ void dual_combine_kernel(const double *__restrict__ P0, const double 
     Y[(long)f * ldy + r] = wM[r] == 0.0 ? fill : t;
 }
 
+static size_t band_part_count(const ibh_weighted *w, int nvar) {
+    const long ldp = ((long)w->nrow + 63) & ~63l;
+    return 2 * (size_t)nvar * (size_t)ldp;
+}
 template <int FPW>
 static void launch_rowdual(const ibh_weighted *w, const double *dA, int nvar, long lda, double *dB, long ldb,
                            double fill, hipStream_t stream)
 {
     constexpr int NW = 4, FB = FPW * NW;
     const int nfc = ceil_div(nvar, FB);
-    const int xcd_mode = (nfc % 8 == 0 || nfc == 1 || nfc == 2 || nfc == 4) ? 1 : 0;
-    long nb = (long)w->nrow * nfc;
-    if (xcd_mode == 1 && nfc < 8) {
-        const int m = 8 / nfc;
-        nb = 8l * ((w->nrow + m - 1) / m + 1);
-    }
+    int xcd_mode;
+    const long nb = rowblock_grid(w->nrow, nfc, xcd_mode);
     IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
     IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
     const long ldp = ((long)w->nrow + 63) & ~63l;
-    w->band_part.alloc(2 * (size_t)nvar * (size_t)ldp);
+    grow_scratch(w->band_part, band_part_count(w, nvar), stream, "band");
     double *P0 = w->band_part.p, *P1 = P0 + (size_t)nvar * (size_t)ldp;
     const double mean = w->nrow ? (double)w->band_n / (double)w->nrow / 64.0 : 1.0;
     const int unroll = mean > 4.0 ? 8 : mean > 2.0 ? 4 : mean > 1.0 ? 2 : 1;
+    BatchPtrs bp{};
+    bp.x[0] = dA; bp.y[0] = P0;
 #define IBH_RD(U)                                                                                                  \
-    hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, 1, U, NW, false, true>), dim3((unsigned)nb), dim3(NW * 64), 0, stream, \
-                       w->band_ptr.p, w->band_col.p, w->band_v0.p, dA, lda, w->ncol, P0, ldp, w->nrow, nvar, nfc, xcd_mode, \
-                       w->wM.p, fill, (unsigned long long *)nullptr, w->band_v1.p, P1)
+    hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, 1, U, NW, true>), dim3((unsigned)nb), dim3(NW * 64), 0, stream,   \
+                       w->band_ptr.p, w->band_col.p, w->band_v0.p, bp, 1, 1, lda, w->ncol, ldp, w->nrow, nvar, nfc, xcd_mode, \
+                       w->wM.p, fill, w->band_v1.p, P1)
     if (unroll == 1) IBH_RD(1); else if (unroll == 2) IBH_RD(2); else if (unroll == 8) IBH_RD(8); else IBH_RD(4);
 #undef IBH_RD
     hipLaunchKernelGGL(dual_combine_kernel, dim3((unsigned)ceil_div(w->nrow, 256), (unsigned)nvar), dim3(256), 0, stream,
@@ -570,12 +622,8 @@ static void launch_rowdual(const ibh_weighted *w, const double *dA, int nvar, lo
     IBH_HIP(hipGetLastError());
 }
 
-void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda, double *dB, int64_t ldb,
-                 double fill, int force_conservation, hipStream_t stream)
-{
-    if (nvar <= 0 || w->nrow == 0) return;
-    IBH_CHECK(lda >= w->ncol && ldb >= w->nrow, "apply: leading dimensions (%ld, %ld) smaller than (%d, %d)",
-              (long)lda, (long)ldb, w->ncol, w->nrow);
+// which kernel serves (w, nvar): 1 rowblock, 2 shortrow, 3 rowdual
+static int pick_kernel(const ibh_weighted *w, int nvar) {
     int kernel = w->kernel_override;
     if (kernel == 0) {
         const double mean = w->nrow ? (double)w->nnz / (double)w->nrow : 0.0;
@@ -583,15 +631,56 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
     }
     if (kernel == 1 && w->kernel_override == 0 && w->band_n > 0 && nvar >= 4 && get_tuning("rowdual_auto", 1)) kernel = 3;
     if (kernel == 3 && w->band_n == 0) kernel = 1;            // no bands were built for this matrix
-    w->last_kernel = kernel;
+    return kernel;
+}
+struct ShortrowPlan { int fper, g, use_xt, ldt; bool one_entry, big; };
+static ShortrowPlan shortrow_plan(const ibh_weighted *w, int nvar) {
+    // fields per thread.  Small problems (5 km: 76 k rows) are latency-bound and want many short
+    // threads (4 fields for ~1 entry per row, 8 for 2-3); at 1 km (1.9 M rows) the stores dominate
+    // and 16-32 fields per thread amortise the row's CSR reads (measured, scratch/tune_shortrow.py).
+    ShortrowPlan p;
+    p.one_entry = (double)w->nnz <= 1.5 * (double)w->nrow;
+    p.big = w->nrow >= (1 << 19);
+    p.fper = get_tuning("shortrow_fper", p.big ? (p.one_entry ? 16 : 32) : (p.one_entry ? 4 : 8));
+    if (p.fper < 1) p.fper = 1;
+    p.g = get_tuning("shortrow_group", p.big ? (p.one_entry ? 8 : 4) : p.fper >= 8 ? 8 : 4);
+    // transposed input: pays when the lanes of a wave gather different columns (>= 2 entries per row:
+    // 5 km IvE 26.9 -> 18.5 us, 1 km IvE 302 -> 183 us) and at bandwidth-bound sizes (1 km IvA 207 ->
+    // 176 us); a latency-bound one-entry apply (5 km IvA, 14 us) only pays for the extra launch
+    p.use_xt = get_tuning("shortrow_xt", -1);
+    if (p.use_xt < 0) p.use_xt = (!p.one_entry || p.big) ? 1 : 0;
+    if (p.fper % p.g != 0 || (p.g & 1)) p.use_xt = 0;
+    p.ldt = (nvar + 15) & ~15;
+    return p;
+}
+
+void weighted_reserve(const ibh_weighted *w, int nvar) {
+    if (nvar <= 0) return;
+    const int kernel = pick_kernel(w, nvar);
+    if (kernel == 3 || w->band_n > 0) grow_scratch(w->band_part, band_part_count(w, nvar), nullptr, "band");
+    if (kernel == 2 || w->kernel_override == 0) {
+        const ShortrowPlan p = shortrow_plan(w, nvar);
+        if (p.use_xt && pick_kernel(w, nvar) == 2) grow_scratch(w->xt, (size_t)w->ncol * (size_t)p.ldt, nullptr, "transposed-input");
+    }
+    grow_scratch(w->consv, 2 * (size_t)nvar, nullptr, "conservation");
+    // apply_transformed: the small side holds nvar fields
+    grow_scratch(w->scratch, (size_t)nvar * (size_t)std::min(w->nrow, w->ncol), nullptr, "transform");
+    ensure_rowsum1(w, nullptr);
+}
+
+static void launch_one(const ibh_weighted *w, int kernel, const BatchPtrs &bp, int nbatch, int nvar, int64_t lda,
+                       int64_t ldb, double fill, hipStream_t stream)
+{
     if (kernel == 3) {
         const long pairs = (long)w->nrow * nvar;
         const int fpw = get_tuning("rowdual_fpw", pairs >= 4 * 8192 ? 4 : pairs >= 2 * 8192 ? 2 : 1);
-        if (fpw >= 4) launch_rowdual<4>(w, dA, nvar, (long)lda, dB, (long)ldb, fill, stream);
-        else if (fpw == 2) launch_rowdual<2>(w, dA, nvar, (long)lda, dB, (long)ldb, fill, stream);
-        else launch_rowdual<1>(w, dA, nvar, (long)lda, dB, (long)ldb, fill, stream);
+        for (int q = 0; q < nbatch; ++q) {
+            if (fpw >= 4) launch_rowdual<4>(w, bp.x[q], nvar, (long)lda, bp.y[q], (long)ldb, fill, stream);
+            else if (fpw == 2) launch_rowdual<2>(w, bp.x[q], nvar, (long)lda, bp.y[q], (long)ldb, fill, stream);
+            else launch_rowdual<1>(w, bp.x[q], nvar, (long)lda, bp.y[q], (long)ldb, fill, stream);
+        }
     } else if (kernel == 1) {
-        int fpw = get_tuning("rowblock_fpw", 0), wk = get_tuning("rowblock_wk", 0);
+        int fpw = get_tuning(nbatch > 1 ? "rowblock_many_fpw" : "rowblock_fpw", 0), wk = get_tuning("rowblock_wk", 0);
         if (fpw == 0 || wk == 0) {
             // enough workgroups to give every CU ~8: small problems are latency-bound and want many
             // small tasks, big ones amortise the staged row segment over more fields
@@ -602,12 +691,12 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
             else if (nvar >= 2) { fpw = 1; wk = 2; }
             else { fpw = 1; wk = 4; }
         }
-        const int nw = get_tuning("rowblock_waves", 4);
-#define IBH_L(F, K, N) launch_rowblock<F, K, N>(w, dA, nvar, lda, dB, ldb, fill, stream)
+        // deep batched launches: 8 waves (8 fields) per workgroup halve the workgroup count per batch
+        // (measured at the 5 km headline shape, depth 16: 7.36 against 7.51 us per apply)
+        const int nw = get_tuning("rowblock_waves", nbatch >= 8 && fpw == 1 && wk == 1 ? 8 : 4);
+#define IBH_L(F, K, N) launch_rowblock<F, K, N>(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream)
         if (nw == 8 && wk == 1) {
             if (fpw == 1) IBH_L(1, 1, 8); else if (fpw == 2) IBH_L(2, 1, 8); else IBH_L(4, 1, 8);
-        } else if (nw == 16 && wk == 1) {
-            if (fpw == 1) IBH_L(1, 1, 16); else if (fpw == 2) IBH_L(2, 1, 16); else IBH_L(4, 1, 16);
         } else if (fpw == 4 && wk == 1) IBH_L(4, 1, 4);
         else if (fpw == 8 && wk == 1) IBH_L(8, 1, 4);
         else if (fpw == 2 && wk == 1) IBH_L(2, 1, 4);
@@ -620,76 +709,104 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
         else IBH_L(1, 4, 4);
 #undef IBH_L
     } else {
-        // fields per thread.  Small problems (5 km: 76 k rows) are latency-bound and want many short
-        // threads (4 fields for ~1 entry per row, 8 for 2-3); at 1 km (1.9 M rows) the stores dominate
-        // and 16-32 fields per thread amortise the row's CSR reads (measured, scratch/tune_shortrow.py).
-        const bool one_entry = (double)w->nnz <= 1.5 * (double)w->nrow;
-        const bool big = w->nrow >= (1 << 19);
-        int fper = get_tuning("shortrow_fper", big ? (one_entry ? 16 : 32) : (one_entry ? 4 : 8));
-        if (fper < 1) fper = 1;
-        // planes of B that do not start on 64-byte lines are re-aligned through LDS (see the kernel)
-        const bool realign = get_tuning("shortrow_realign", -1) >= 0 ? get_tuning("shortrow_realign", -1) != 0
-                           : ((reinterpret_cast<uintptr_t>(dB) & 63) != 0 || (ldb & 7) != 0) && w->nrow >= (1 << 18);   // below: latency-bound, the two extra barriers cost more
-        const long nblk = (long)ceil_div(w->nrow, realign ? SR_STEP : SR_THREADS) * ceil_div(nvar, fper);
-        IBH_CHECK(nblk < (1l << 31), "spmm grid too large (%ld blocks)", nblk);
-        dim3 grid((unsigned)nblk);
-        const int g = get_tuning("shortrow_group", big ? (one_entry ? 8 : 4) : fper >= 8 ? 8 : 4);
-        // transposed input: pays when the lanes of a wave gather different columns (>= 2 entries per row:
-        // 5 km IvE 26.9 -> 18.5 us, 1 km IvE 302 -> 183 us) and at bandwidth-bound sizes (1 km IvA 207 ->
-        // 176 us); a latency-bound one-entry apply (5 km IvA, 14 us) only pays for the extra launch
-        int use_xt = get_tuning("shortrow_xt", -1);
-        if (use_xt < 0) use_xt = (!one_entry || big) ? 1 : 0;
-        if (fper % g != 0 || (g & 1)) use_xt = 0;
-        const double *xin = dA;
-        long xld = (long)lda;
-        if (use_xt) {
-            const int ldt = (nvar + 15) & ~15;
-            w->xt.alloc((size_t)w->ncol * (size_t)ldt);
-            hipLaunchKernelGGL(transpose_fields_kernel, dim3((unsigned)ceil_div(w->ncol, 64), (unsigned)(ldt / 16)), dim3(256), 0, stream,
-                               dA, (long)lda, nvar, w->ncol, w->xt.p, ldt);
-            xin = w->xt.p; xld = ldt;
-        }
+        const ShortrowPlan p = shortrow_plan(w, nvar);
+        const int fper = p.fper, g = p.g;
+        if (p.use_xt) grow_scratch(w->xt, (size_t)w->ncol * (size_t)p.ldt, stream, "transposed-input");
+        for (int q = 0; q < nbatch; ++q) {
+            const double *dA = bp.x[q];
+            double *dB = bp.y[q];
+            // planes of B that do not start on 64-byte lines are re-aligned through LDS (see the kernel)
+            const bool realign = get_tuning("shortrow_realign", -1) >= 0 ? get_tuning("shortrow_realign", -1) != 0
+                               : ((reinterpret_cast<uintptr_t>(dB) & 63) != 0 || (ldb & 7) != 0) && w->nrow >= (1 << 18);   // below: latency-bound, the two extra barriers cost more
+            const long nblk = (long)ceil_div(w->nrow, realign ? SR_STEP : SR_THREADS) * ceil_div(nvar, fper);
+            IBH_CHECK(nblk < (1l << 31), "spmm grid too large (%ld blocks)", nblk);
+            dim3 grid((unsigned)nblk);
+            const double *xin = dA;
+            long xld = (long)lda;
+            if (p.use_xt) {
+                hipLaunchKernelGGL(transpose_fields_kernel, dim3((unsigned)ceil_div(w->ncol, 64), (unsigned)(p.ldt / 16)), dim3(256), 0, stream,
+                                   dA, (long)lda, nvar, w->ncol, w->xt.p, p.ldt);
+                xin = w->xt.p; xld = p.ldt;
+            }
 #define IBH_SR4(NT, GG, RA, XTT)                                                                                \
     hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, RA, XTT>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
                        w->val.p, xin, xld, dB, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill)
 #define IBH_SR(NT, GG)                                                                                          \
     do {                                                                                                        \
-        if (realign) { if (use_xt) IBH_SR4(NT, GG, true, true); else IBH_SR4(NT, GG, true, false); }            \
-        else { if (use_xt) IBH_SR4(NT, GG, false, true); else IBH_SR4(NT, GG, false, false); }                  \
+        if (realign) { if (p.use_xt) IBH_SR4(NT, GG, true, true); else IBH_SR4(NT, GG, true, false); }          \
+        else { if (p.use_xt) IBH_SR4(NT, GG, false, true); else IBH_SR4(NT, GG, false, false); }                \
     } while (0)
-        const bool nt = get_tuning("shortrow_nt", 1) != 0;
-        if (g >= 16) { if (nt) IBH_SR(true, 16); else IBH_SR(false, 16); }
-        else if (g >= 8) { if (nt) IBH_SR(true, 8); else IBH_SR(false, 8); }
-        else { if (nt) IBH_SR(true, 4); else IBH_SR(false, 4); }
+            const bool nt = get_tuning("shortrow_nt", 1) != 0;
+            if (g >= 16) { if (nt) IBH_SR(true, 16); else IBH_SR(false, 16); }
+            else if (g >= 8) { if (nt) IBH_SR(true, 8); else IBH_SR(false, 8); }
+            else { if (nt) IBH_SR(true, 4); else IBH_SR(false, 4); }
 #undef IBH_SR4
 #undef IBH_SR
+        }
         IBH_HIP(hipGetLastError());
     }
-    if (!w->conservative && force_conservation) {
-        // factor_k = (Mw . A_k) / (wM . B_k); rows with wM == 0 hold `fill` and are skipped
-        DevBuf<double> T(2 * (size_t)nvar);
-        weight_dot_launch(w->Mw.p, w->ncol, dA, nvar, lda, T.p, stream);
-        weight_dot_launch(w->wM.p, w->nrow, dB, nvar, ldb, T.p + nvar, stream);
-        dim3 grid((unsigned)ceil_div(w->nrow, 256), (unsigned)nvar);
-        hipLaunchKernelGGL(conserve_scale_kernel, grid, dim3(256), 0, stream, dB, (long)ldb, w->nrow, w->wM.p,
-                           T.p, T.p + nvar);
-        IBH_HIP(hipGetLastError());
-        IBH_HIP(hipStreamSynchronize(stream));   // T is freed on return
+}
+
+void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA, int nvar, int64_t lda,
+                      double *const *dB, int64_t ldb, double fill, int force_conservation, hipStream_t stream)
+{
+    if (nvar <= 0 || w->nrow == 0 || nbatch <= 0) return;
+    IBH_CHECK(lda >= w->ncol && ldb >= w->nrow, "apply: leading dimensions (%ld, %ld) smaller than (%d, %d)",
+              (long)lda, (long)ldb, w->ncol, w->nrow);
+    const int kernel = pick_kernel(w, nvar);
+    w->last_kernel = kernel;
+    const bool correct = !w->conservative && force_conservation;
+    if (correct) grow_scratch(w->consv, 2 * (size_t)nvar, stream, "conservation");
+    for (int b0 = 0; b0 < nbatch; b0 += IBH_MAX_BATCH) {
+        const int nb = std::min(IBH_MAX_BATCH, nbatch - b0);
+        BatchPtrs bp{};
+        for (int q = 0; q < nb; ++q) {
+            IBH_CHECK(dA[b0 + q] && dB[b0 + q], "apply: null field pointer in batch %d", b0 + q);
+            bp.x[q] = dA[b0 + q]; bp.y[q] = dB[b0 + q];
+        }
+        launch_one(w, kernel, bp, nb, nvar, lda, ldb, fill, stream);
+        if (correct) {
+            // factor_k = (Mw . A_k) / (wM . B_k); rows with wM == 0 hold `fill` and are skipped.  The two
+            // dot products live in handle-owned scratch: stream-ordered, no allocation, no host sync.
+            for (int q = 0; q < nb; ++q) {
+                double *T = w->consv.p;
+                weight_dot_launch(w->Mw.p, w->ncol, bp.x[q], nvar, lda, T, stream);
+                weight_dot_launch(w->wM.p, w->nrow, bp.y[q], nvar, ldb, T + nvar, stream);
+                dim3 grid((unsigned)ceil_div(w->nrow, 256), (unsigned)nvar);
+                hipLaunchKernelGGL(conserve_scale_kernel, grid, dim3(256), 0, stream, bp.y[q], (long)ldb, w->nrow, w->wM.p,
+                                   T, T + nvar);
+            }
+            IBH_HIP(hipGetLastError());
+        }
     }
+}
+
+void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda, double *dB, int64_t ldb,
+                 double fill, int force_conservation, hipStream_t stream)
+{
+    spmm_launch_many(w, 1, &dA, nvar, lda, &dB, ldb, fill, force_conservation, stream);
 }
 
 // ---- coupler-shaped product M * (V*T + b) ---------------------------------------------------
 // out[k, j] = sum_l T[l,k] * in[l, j] + b[k] * (scale ? scale[j] : 1): the variable transform, applied
 // on whichever side of M is small.  T entries that are exactly 0 are structural (skipped: a NaN in an
-// unused input variable must not reach the outputs).  One thread per column j, all k in registers.
-__global__ void transform_kernel(const double *__restrict__ in, long ldin, int nin, const double *__restrict__ Tm,
-                                 const double *__restrict__ b, const double *__restrict__ scale,
+// unused input variable must not reach the outputs).  One thread per column j.
+// T (row-major nvar_in x nvar_out) and b travel in the kernarg segment (TB_MAX doubles): the caller's
+// host arrays are consumed at launch time, nothing is copied asynchronously from them and the call
+// stays stream-ordered and graph-capturable.  Larger transforms go through a device copy.
+constexpr int TB_MAX = 384;
+struct TransformArgs { double tb[TB_MAX]; };
+template <bool INLINE>
+__global__ void transform_kernel(const double *__restrict__ in, long ldin, int nin, const TransformArgs ta,
+                                 const double *__restrict__ Tdev, const double *__restrict__ scale,
                                  const double *__restrict__ wM, double fill, double *__restrict__ out, long ldout,
                                  int nout, int n)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = blockIdx.y;
     if (j >= n) return;
+    const double *Tm = INLINE ? ta.tb : Tdev;
+    const double *b = Tm + (size_t)nin * nout;
     double acc = 0.0;
     for (int l = 0; l < nin; ++l) {
         const double t = Tm[l * nout + k];
@@ -699,9 +816,25 @@ __global__ void transform_kernel(const double *__restrict__ in, long ldin, int n
     if (wM && wM[j] == 0.0) acc = fill;
     out[(long)k * ldout + j] = acc;
 }
-__global__ void fill_ones_kernel(double *p, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 1.0;
+// rowsum1[r] = sum of row r of M (= M * 1, the factor of the offset term b): one wave per row
+__global__ void rowsum_kernel(const int *__restrict__ rowptr, const double *__restrict__ vals, int nrow,
+                              double *__restrict__ out)
+{
+    const int r = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= nrow) return;
+    double acc = 0.0;
+    for (int k = rowptr[r] + lane; k < rowptr[r + 1]; k += 64) acc += vals[k];
+    acc = wave_sum(acc);
+    if (lane == 0) out[r] = acc;
+}
+void ensure_rowsum1(const ibh_weighted *w, hipStream_t stream) {
+    if (w->have_rowsum1 || w->nrow == 0) return;
+    grow_scratch(w->rowsum1, (size_t)w->nrow, stream, "row-sum");
+    hipLaunchKernelGGL(rowsum_kernel, dim3(ceil_div((long)w->nrow * 64, 256)), dim3(256), 0, stream, w->rowptr.p, w->val.p,
+                       w->nrow, w->rowsum1.p);
+    IBH_HIP(hipGetLastError());
+    w->have_rowsum1 = true;
 }
 
 void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_in, int64_t lda, const double *T,
@@ -710,38 +843,41 @@ void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_i
     if (nvar_out <= 0 || w->nrow == 0) return;
     IBH_CHECK(nvar_in > 0 && T && b, "apply_transformed: empty transform");
     IBH_CHECK(lda >= w->ncol && ldb >= w->nrow, "apply_transformed: leading dimensions too small");
-    // device copy of T (row-major nvar_in x nvar_out) followed by b
-    std::vector<double> tb((size_t)nvar_in * nvar_out + nvar_out);
-    std::copy(T, T + (size_t)nvar_in * nvar_out, tb.begin());
-    std::copy(b, b + nvar_out, tb.begin() + (size_t)nvar_in * nvar_out);
-    w->tbuf.alloc(tb.size());
-    IBH_HIP(hipMemcpyAsync(w->tbuf.p, tb.data(), sizeof(double) * tb.size(), hipMemcpyHostToDevice, stream));
-    IBH_HIP(hipStreamSynchronize(stream));      // tb is a stack-lifetime staging buffer
-    const double *dT = w->tbuf.p, *db = w->tbuf.p + (size_t)nvar_in * nvar_out;
+    const size_t ntb = (size_t)nvar_in * nvar_out + nvar_out;
+    const bool inl = ntb <= (size_t)TB_MAX;
+    TransformArgs ta;
+    const double *dT = nullptr;
+    if (inl) {
+        std::copy(T, T + (size_t)nvar_in * nvar_out, ta.tb);
+        std::copy(b, b + nvar_out, ta.tb + (size_t)nvar_in * nvar_out);
+    } else {
+        // more than TB_MAX coefficients: staged through a device copy (synchronises; not capturable)
+        std::vector<double> tb(ntb);
+        std::copy(T, T + (size_t)nvar_in * nvar_out, tb.begin());
+        std::copy(b, b + nvar_out, tb.begin() + (size_t)nvar_in * nvar_out);
+        grow_scratch(w->tbuf, ntb, stream, "transform-coefficient");
+        IBH_HIP(hipStreamSynchronize(stream));      // an earlier apply may still read tbuf
+        IBH_HIP(hipMemcpyAsync(w->tbuf.p, tb.data(), sizeof(double) * ntb, hipMemcpyHostToDevice, stream));
+        IBH_HIP(hipStreamSynchronize(stream));      // tb is a stack-lifetime staging buffer
+        dT = w->tbuf.p;
+    }
+    auto transform = [&](const double *in, long ldin, const double *scale, const double *wM, double *out, long ldout, int n) {
+        dim3 grid((unsigned)ceil_div(n, 256), (unsigned)nvar_out);
+        if (inl) hipLaunchKernelGGL(transform_kernel<true>, grid, dim3(256), 0, stream, in, ldin, nvar_in, ta, dT, scale, wM, fill, out, ldout, nvar_out, n);
+        else hipLaunchKernelGGL(transform_kernel<false>, grid, dim3(256), 0, stream, in, ldin, nvar_in, ta, dT, scale, wM, fill, out, ldout, nvar_out, n);
+        IBH_HIP(hipGetLastError());
+    };
     if (w->ncol <= w->nrow) {
         // inputs are the small side: X' = V*T + b, then B = M * X'
-        w->scratch.alloc((size_t)nvar_out * (size_t)w->ncol);
-        dim3 grid((unsigned)ceil_div(w->ncol, 256), (unsigned)nvar_out);
-        hipLaunchKernelGGL(transform_kernel, grid, dim3(256), 0, stream, dA, (long)lda, nvar_in, dT, db,
-                           (const double *)nullptr, (const double *)nullptr, 0.0, w->scratch.p, (long)w->ncol, nvar_out, w->ncol);
-        IBH_HIP(hipGetLastError());
+        grow_scratch(w->scratch, (size_t)nvar_out * (size_t)w->ncol, stream, "transform");
+        transform(dA, (long)lda, nullptr, nullptr, w->scratch.p, (long)w->ncol, w->ncol);
         spmm_launch(w, w->scratch.p, nvar_out, w->ncol, dB, ldb, fill, 0, stream);
     } else {
         // outputs are the small side: Z = M * V, then B = T^T Z + b * (M * 1), rows with wM == 0 -> fill
-        if (!w->have_rowsum1) {
-            DevBuf<double> ones((size_t)w->ncol);
-            hipLaunchKernelGGL(fill_ones_kernel, dim3(ceil_div(w->ncol, 256)), dim3(256), 0, stream, ones.p, w->ncol);
-            w->rowsum1.alloc((size_t)w->nrow);
-            spmm_launch(w, ones.p, 1, w->ncol, w->rowsum1.p, w->nrow, 0.0, 0, stream);
-            IBH_HIP(hipStreamSynchronize(stream));
-            w->have_rowsum1 = true;
-        }
-        w->scratch.alloc((size_t)nvar_in * (size_t)w->nrow);
+        ensure_rowsum1(w, stream);
+        grow_scratch(w->scratch, (size_t)nvar_in * (size_t)w->nrow, stream, "transform");
         spmm_launch(w, dA, nvar_in, lda, w->scratch.p, w->nrow, 0.0, 0, stream);
-        dim3 grid((unsigned)ceil_div(w->nrow, 256), (unsigned)nvar_out);
-        hipLaunchKernelGGL(transform_kernel, grid, dim3(256), 0, stream, w->scratch.p, (long)w->nrow, nvar_in, dT, db,
-                           (const double *)w->rowsum1.p, (const double *)w->wM.p, fill, dB, (long)ldb, nvar_out, w->nrow);
-        IBH_HIP(hipGetLastError());
+        transform(w->scratch.p, (long)w->nrow, w->rowsum1.p, w->wM.p, dB, (long)ldb, w->nrow);
     }
 }
 

@@ -195,6 +195,36 @@ class linear_Weighted:
                                              float(fill), int(force_conservation), C.c_void_p(s)))
         return out
 
+    def apply_many_device(self, dAs, outs=None, fill=float("nan"), force_conservation=True, stream=None):
+        """Several field batches through one launch (ibh_weighted_apply_many_device): dAs is a list of
+        torch.float64 CUDA tensors [nvar, ncol_d] of equal shape and row stride; returns the list of
+        results.  Bitwise the results of separate apply_device calls."""
+        import torch
+        nb = len(dAs)
+        if nb == 0:
+            return []
+        nvar, lda = dAs[0].shape[0], max(dAs[0].stride(0), self.ncol_d)
+        for a in dAs:
+            assert a.is_cuda and a.dtype == torch.float64 and a.dim() == 2 and a.stride(1) == 1
+            assert a.shape == (nvar, self.ncol_d) and max(a.stride(0), self.ncol_d) == lda
+        if outs is None:
+            outs = [_aligned_planes(torch, nvar, self.nrow_d, dAs[0].device) for _ in range(nb)]
+        ldb = max(outs[0].stride(0), self.nrow_d)
+        for o in outs:
+            assert o.is_cuda and o.dtype == torch.float64 and o.shape == (nvar, self.nrow_d) and o.stride(1) == 1
+            assert max(o.stride(0), self.nrow_d) == ldb
+        xp = (C.c_void_p * nb)(*[a.data_ptr() for a in dAs])
+        yp = (C.c_void_p * nb)(*[o.data_ptr() for o in outs])
+        s = torch.cuda.current_stream(dAs[0].device).cuda_stream if stream is None else stream
+        check(lib().ibh_weighted_apply_many_device(self._h, nb, xp, nvar, lda, yp, ldb, float(fill), int(force_conservation),
+                                                  C.c_void_p(s)))
+        return outs
+
+    def reserve(self, nvar):
+        """Size the handle's per-apply scratch for up to nvar variables (needed before capturing
+        applies into a hipGraph: growing scratch allocates)."""
+        check(lib().ibh_weighted_reserve(self._h, int(nvar)))
+
     def apply_transformed_device(self, dV, T, b, out=None, fill=float("nan"), stream=None):
         """The coupler's fused product  M * (V*T + b)  on HBM-resident fields (IceCoupler.cpp:203-252,
         :445): dV torch.float64 CUDA [nvar_in, ncol_d]; T [nvar_in, nvar_out] (the sparse variable

@@ -164,7 +164,8 @@ int ibh_weighted_get_csr(const ibh_weighted *w, int32_t *rowptr, int32_t *colind
  * dense index spaces; rows with wM == 0 receive `fill`; when the matrix is
  * not conservative and force_conservation != 0 each variable is rescaled by
  * (Mw . A) / (wM . B).  _host takes host pointers (copies over PCIe);
- * _device takes device pointers and only enqueues work on `stream`.  lda/ldb:
+ * _device takes device pointers and only enqueues work on `stream` (no allocation, copy or
+ * synchronisation once the handle's scratch is sized: ibh_weighted_reserve).  lda/ldb:
  * distance in doubles between consecutive variables (>= dense extents); any value
  * works, ldb a multiple of 64 (512-byte planes) is fastest for the I-row matrices.
  * The handle keeps small per-apply scratch buffers: use one stream at a time per handle. */
@@ -173,13 +174,32 @@ int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nv
 int ibh_weighted_apply_device(const ibh_weighted *w, const double *dA_b, int32_t nvar, int64_t lda,
                               double *dB_b, int64_t ldb, double fill, int force_conservation,
                               void *stream);
+/* Several field batches through ONE launch: for q < nbatch, dB_b[q] = M * dA_b[q], every batch
+ * [nvar x ncol_d] -> [nvar x nrow_d] with the same nvar / lda / ldb -- what a caller that applies one
+ * matrix to several groups of variables in a row does (Weighted_Eigen::apply call sites
+ * modele/merge_topo.cpp:65, modele/icebin22m.cpp:153; the coupler's per-sheet products IceCoupler.cpp:237,445).
+ * dA_b / dB_b are HOST arrays of nbatch DEVICE pointers, read during the call (they travel in the
+ * kernel arguments: no device-side table, nothing left pending on them).  Results are bitwise those of
+ * nbatch separate ibh_weighted_apply_device calls.  A 64-field 5 km apply is a latency-sized problem
+ * (launch + dependent loads are a third of its 11 us); batched, that cost is paid once per launch.
+ * More than IBH_MAX_BATCH batches are split into several launches. */
+#define IBH_MAX_BATCH 16
+int ibh_weighted_apply_many_device(const ibh_weighted *w, int32_t nbatch, const double *const *dA_b, int32_t nvar,
+                                   int64_t lda, double *const *dB_b, int64_t ldb, double fill,
+                                   int force_conservation, void *stream);
+/* Size the handle's per-apply scratch for applies of up to nvar variables (transposed inputs of the
+ * I-row kernels, band partial sums, conservation factors, transform scratch).  Applies grow it on
+ * demand, but growing allocates: inside a stream capture that is an error, so reserve first. */
+int ibh_weighted_reserve(const ibh_weighted *w, int32_t nvar);
 /* The coupler's fused product B = M * (A*T + b) (IceCoupler.cpp:203-252 construct_ice_ivalsI and
  * :445 gcm_ivalsX = M * (ice_ovalsI*T + b)): dA_b [nvar_in x ncol_d] field-major device pointer,
  * T [nvar_in x nvar_out] row-major HOST array holding the sparse variable transform (exact zeros are
  * structural and skipped, as Eigen's dense*sparse product does), b [nvar_out] host, dB_b
  * [nvar_out x nrow_d] device.  The small dense transform is applied on the SMALL side of M (inputs
  * when ncol_d <= nrow_d, outputs otherwise), so no transformed copy of the large field array is
- * ever written.  Uses scratch owned by the handle: calls on one handle must be stream-ordered. */
+ * ever written.  Uses scratch owned by the handle: calls on one handle must be stream-ordered.
+ * T and b are consumed during the call (kernel arguments) when nvar_in*nvar_out + nvar_out <= 384;
+ * larger transforms are staged through a device copy and synchronise the stream. */
 int ibh_weighted_apply_transformed_device(const ibh_weighted *w, const double *dA_b, int32_t nvar_in, int64_t lda,
                                           const double *T, const double *b, int32_t nvar_out,
                                           double *dB_b, int64_t ldb, double fill, void *stream);

@@ -548,6 +548,66 @@ def test_apply_is_graph_capturable():
         assert rel_linf(z.cpu().numpy(), oI.apply(yr)) <= 10 * FIELD_RTOL
 
 
+@pytest.mark.parametrize("name", ["AvI", "EvI", "IvA", "IvE"])
+@pytest.mark.parametrize("nbatch,nvar", [(1, 5), (2, 3), (5, 8), (16, 16), (19, 64)])
+def test_apply_many_is_bitwise_separate_applies(name, nbatch, nvar):
+    # ibh_weighted_apply_many_device: ONE launch over several field batches (the staged row segment is
+    # reused across the batches of a workgroup); results must be bitwise those of separate applies, for
+    # every batches-per-workgroup setting, including more batches than one launch takes (IBH_MAX_BATCH)
+    import torch
+    g, em, mm, rg = setup("g20")
+    w = mm.regrid_matrices("greenland", em, scale=True, correctA=True).matrix(name)
+    o = rg.matrix_d(name, em, scale=True, correctA=True)
+    xs = [torch.from_numpy(syn.fields(nvar, w.ncol_d, seed=100 + q)).cuda() for q in range(nbatch)]
+    xs[0][0, ::7] = float("nan")              # NaN inputs stay confined to the rows that read them
+    ref = [w.apply_device(x, force_conservation=False).clone() for x in xs]
+    torch.cuda.synchronize()
+    assert rel_linf(ref[-1].cpu().numpy(), o.apply(xs[-1].cpu().numpy())) <= FIELD_RTOL
+    try:
+        for qi in (0, 1, 2, 3, 16):
+            icebin_amd.set_tuning("rowblock_many_qi", qi)
+            outs = w.apply_many_device(xs, force_conservation=False)
+            torch.cuda.synchronize()
+            for q in range(nbatch):
+                a, b = outs[q].cpu().numpy(), ref[q].cpu().numpy()
+                np.testing.assert_array_equal(a.view(np.uint64), b.view(np.uint64), err_msg="%s batch %d qi %d" % (name, q, qi))
+    finally:
+        icebin_amd.set_tuning("rowblock_many_qi", 0)
+
+
+def test_apply_many_long_rows_and_graph_capture():
+    # rows longer than one staged segment (1024 entries) re-stage per batch; the batched launch is
+    # capturable (pointer table travels in the kernel arguments)
+    import torch
+    rng = np.random.default_rng(5)
+    nrow, ncol = 7, 6000
+    rowlen = [0, 1, 1023, 1024, 1025, 2500, 3000]
+    rowptr = np.concatenate([[0], np.cumsum(rowlen)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(ncol, n, replace=False)) for n in rowlen]).astype(np.int32)
+    val = rng.standard_normal(len(col))
+    wM = np.ones(nrow); wM[0] = 0.0
+    w = icebin_amd.linear_Weighted.from_csr((nrow, ncol), rowptr, col, val, wM, np.ones(ncol))
+    w.set_kernel("rowblock")
+    import scipy.sparse
+    M = scipy.sparse.csr_matrix((val, col, rowptr), shape=(nrow, ncol))
+    xs = [torch.from_numpy(rng.standard_normal((6, ncol))).cuda() for _ in range(5)]
+    outs = [torch.empty((6, nrow), dtype=torch.float64, device="cuda") for _ in range(5)]
+    w.apply_many_device(xs, outs, fill=-7.0, force_conservation=False)      # warm-up outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        w.apply_many_device(xs, outs, fill=-7.0, force_conservation=False)
+    for o in outs:
+        o.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for x, o in zip(xs, outs):
+        ref = (M @ x.cpu().numpy().T).T
+        ref[:, 0] = -7.0
+        got = o.cpu().numpy()
+        assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
 # ---- the ordering primitive behind the assembly (prims.hip "adaptive ordering") ---------------------
 def _selftest_sort(keys, lo_bits, hi_bits):
     import ctypes as C
