@@ -41,10 +41,11 @@ size_t size_class(size_t bytes) {      // 512 B granules below 64 KiB, then eigh
 }
 }  // namespace
 
-void *dev_alloc(size_t bytes, size_t *granted) {
+void *dev_alloc(size_t bytes, size_t *granted, int *device) {
     const size_t cls = size_class(bytes);
     int dev = 0;
     IBH_HIP(hipGetDevice(&dev));
+    *device = dev;
     {
         std::lock_guard<std::mutex> lk(pool().mu);
         auto it = pool().free_blocks.find({dev, cls});
@@ -67,13 +68,13 @@ void *dev_alloc(size_t bytes, size_t *granted) {
     *granted = cls;
     return p;
 }
-void dev_free(void *p, size_t granted) {
+void dev_free(void *p, size_t granted, int device) {
     if (!p) return;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;      // runtime already gone (process exit)
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return;      // runtime already gone (process exit)
     std::lock_guard<std::mutex> lk(pool().mu);
     if (pool().cached_bytes + granted > kMaxCached) { (void)hipFree(p); return; }
-    pool().free_blocks[{dev, granted}].push_back(p);
+    pool().free_blocks[{device, granted}].push_back(p);   // the block's own device, whichever is current now
     pool().cached_bytes += granted;
 }
 void release_cached_memory() {
@@ -298,11 +299,17 @@ int ibh_regrid_matrices_create_device(const ibh_regridder *rg, const double *d_e
 }
 int ibh_regrid_matrices_destroy(ibh_regrid_matrices *rm) { delete rm; return IBH_OK; }
 
+static void check_rm_device(const ibh_regrid_matrices *rm) {
+    int dev = -1;
+    IBH_HIP(hipGetDevice(&dev));
+    IBH_CHECK(dev == rm->rg->device, "regridder belongs to device %d, current device is %d", rm->rg->device, dev);
+}
 int ibh_regrid_matrices_matrix_d(const ibh_regrid_matrices *rm, const char *spec, ibh_sparse_set *dim0,
                                  ibh_sparse_set *dim1, int scale, int correctA, const double sigma[3],
                                  ibh_weighted **out) {
     return guarded([&] {
         IBH_CHECK(rm && spec && out, "null argument");
+        check_rm_device(rm);
         IBH_CHECK(dim0 == nullptr || dim0 != dim1, "dims[0] and dims[1] must be distinct sets");
         assemble_matrix(rm, spec, dim0, dim1, scale, correctA, sigma, out);
     });
@@ -310,6 +317,7 @@ int ibh_regrid_matrices_matrix_d(const ibh_regrid_matrices *rm, const char *spec
 int ibh_regrid_matrices_matrix(const ibh_regrid_matrices *rm, const char *spec, ibh_weighted **out) {
     return guarded([&] {
         IBH_CHECK(rm && spec && out, "null argument");
+        check_rm_device(rm);
         assemble_matrix(rm, spec, nullptr, nullptr, rm->scale, rm->correctA, rm->sigma, out);
     });
 }
@@ -475,6 +483,34 @@ int ibh_weighted_apply_transformed_device(const ibh_weighted *w, const double *d
         check_weighted_device(w);
         IBH_CHECK(nvar_in >= 0 && nvar_out >= 0 && (nvar_out == 0 || (dA && dB && T && b)), "bad arguments");
         spmm_transformed_launch(w, dA, nvar_in, lda, T, b, nvar_out, dB, ldb, fill, static_cast<hipStream_t>(stream));
+    });
+}
+int ibh_weighted_matvec_device(const ibh_weighted *w, const double *dxx, int32_t nvar, int64_t ldx, double *dyy,
+                               int64_t ldy, int ignore_nan, void *stream) {
+    return guarded([&] {
+        check_weighted_device(w);
+        IBH_CHECK(nvar >= 0 && (nvar == 0 || (dxx && dyy)), "bad arguments");
+        matvec_legacy_launch(w, dxx, nvar, ldx, dyy, ldy, ignore_nan, static_cast<hipStream_t>(stream));
+    });
+}
+int ibh_coo_matvec(double *yy, const double *xx, int ignore_nan, int64_t nrow, int64_t ncol, int64_t nnz,
+                   const int32_t *row, const int32_t *col, const double *data) {
+    return guarded([&] {
+        IBH_CHECK(nrow >= 0 && ncol >= 0 && nrow < (1ll << 31) && ncol < (1ll << 31), "bad shape");
+        IBH_CHECK(nnz >= 0 && nnz < (1ll << 31) && (nnz == 0 || (row && col && data)), "bad triplets");
+        IBH_CHECK((nrow == 0 || yy) && (ncol == 0 || xx), "null vector");
+        for (int64_t k = 0; k < nnz; ++k)
+            IBH_CHECK(row[k] >= 0 && row[k] < nrow && col[k] >= 0 && col[k] < ncol,
+                      "triplet %ld: (%d,%d) outside %ld x %ld", (long)k, row[k], col[k], (long)nrow, (long)ncol);
+        if (nrow == 0 || nnz == 0) return;
+        std::vector<double> ones_r((size_t)nrow, 1.0), ones_c((size_t)ncol, 1.0);
+        auto w = new_loaded((int32_t)nrow, (int32_t)ncol, ones_r.data(), ones_c.data(), 1, 1);
+        weighted_from_coo_device(w.get(), (int)nrow, (int)ncol, nnz, row, col, data);
+        DevBuf<double> dx((size_t)ncol), dy((size_t)nrow);
+        dx.upload(xx, (size_t)ncol);
+        dy.upload(yy, (size_t)nrow);
+        matvec_legacy_launch(w.get(), dx.p, 1, ncol, dy.p, nrow, ignore_nan, nullptr);
+        dy.download(yy, (size_t)nrow);
     });
 }
 int ibh_weighted_apply_weight_host(const ibh_weighted *w, int dim, const double *A_b, int32_t nvar, int64_t lda,

@@ -61,8 +61,8 @@ int guarded(F &&f) noexcept {
 // Caching allocator (capi.hip): freed blocks are kept per device and size class and handed out again,
 // so that rebuilding the same matrices every coupling step does no hipMalloc/hipFree (both
 // synchronise the device).  ibh_release_cached_memory() returns everything to the driver.
-void *dev_alloc(size_t bytes, size_t *granted);
-void dev_free(void *p, size_t granted);
+void *dev_alloc(size_t bytes, size_t *granted, int *device);
+void dev_free(void *p, size_t granted, int device);     // filed under the device the block was allocated on
 void release_cached_memory();
 
 template <class T>
@@ -70,13 +70,14 @@ struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     size_t granted = 0;     // bytes actually reserved (size class)
+    int device = 0;         // device the block lives on (the current one at alloc time)
     DevBuf() = default;
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), granted(o.granted) { o.p = nullptr; o.n = 0; o.granted = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), granted(o.granted), device(o.device) { o.p = nullptr; o.n = 0; o.granted = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; granted = o.granted; o.p = nullptr; o.n = 0; o.granted = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; granted = o.granted; device = o.device; o.p = nullptr; o.n = 0; o.granted = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
@@ -84,10 +85,10 @@ struct DevBuf {
         if (p && count * sizeof(T) <= granted) { n = count; return; }
         release();
         n = count;
-        p = static_cast<T *>(dev_alloc((count ? count : 1) * sizeof(T), &granted));
+        p = static_cast<T *>(dev_alloc((count ? count : 1) * sizeof(T), &granted, &device));
     }
     void release() {
-        if (p) dev_free(p, granted);
+        if (p) dev_free(p, granted, device);
         p = nullptr; n = 0; granted = 0;
     }
     void upload(const T *host, size_t count, hipStream_t s = nullptr) {
@@ -196,6 +197,8 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
 void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA, int nvar, int64_t lda,
                       double *const *dB, int64_t ldb, double fill, int force_conservation, hipStream_t stream);
 void weighted_reserve(const ibh_weighted *w, int nvar);
+void matvec_legacy_launch(const ibh_weighted *w, const double *dx, int nvar, int64_t ldx, double *dy, int64_t ldy,
+                          int ignore_nan, hipStream_t stream);
 void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_in, int64_t lda, const double *T,
                               const double *b, int nvar_out, double *dB, int64_t ldb, double fill, hipStream_t stream);
 void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int64_t lda, double *dout,

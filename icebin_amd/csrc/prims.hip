@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 namespace ibh {
 
@@ -24,11 +26,28 @@ void *Arena::get_bytes(size_t bytes) {
     blocks.push_back(nb);
     return nb.p;
 }
-Arena &arena() { static thread_local Arena a; return a; }
+// One arena per (host thread, device): blocks hipMalloc'd on one GPU must never serve a build that
+// runs on another (ibh_set_device switches devices inside one process).
+namespace {
+struct ArenaSet {
+    std::map<int, Arena> by_device;
+};
+ArenaSet &arena_set() { static thread_local ArenaSet s; return s; }
+}  // namespace
+Arena &arena() {
+    int dev = 0;
+    IBH_HIP(hipGetDevice(&dev));
+    return arena_set().by_device[dev];
+}
 void release_workspace() {
-    Arena &a = arena();
-    for (auto &b : a.blocks) (void)hipFree(b.p);
-    a.blocks.clear();
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (auto &kv : arena_set().by_device) {
+        if (have) (void)hipSetDevice(kv.first);
+        for (auto &b : kv.second.blocks) (void)hipFree(b.p);
+        kv.second.blocks.clear();
+    }
+    if (have) (void)hipSetDevice(cur);
 }
 
 void readback_sync(void *dst, const void *dsrc, size_t bytes, hipStream_t stream) {
@@ -724,18 +743,23 @@ void order_and_chunk_sort(uint64_t *keys, uint32_t *idx, size_t n, OrderInfo *d_
         uint32_t *tflags = A.get<uint32_t>(nt);
         hipLaunchKernelGGL(oa_tiles, dim3((unsigned)nt), dim3(OA_T), 0, st, keys, n, tmin, tmax, tflags);
         hipLaunchKernelGGL(oa_tile_prefix, dim3(1), dim3(1024), 0, st, tmin, tmax, tflags, (long)nt, pm, sm, d_info);
-        const uint32_t huge = 0xffffffffu;
-        IBH_HIP(hipMemcpyAsync(&d_info->maxlen, &huge, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        IBH_HIP(hipMemsetAsync(&d_info->maxlen, 0xFF, sizeof(uint32_t), st));     // "longer than any LDS piece"
         return;
     }
     IBH_CHECK(n < (1ul << 32), "sort too large");
     constexpr size_t lds_small = chunk_sort_lds<CS_SMALL, 256>(), lds_mid = chunk_sort_lds<CS_MID, 512>(),
                      lds_big = chunk_sort_lds<CS_BIG, 1024>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&oa_chunk_sort<CS_BIG, CS_MID, 1024>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-        attr_set = true;
+    {   // once per device: the attribute belongs to the function's code object on that device
+        static std::mutex mu;
+        static std::map<int, bool> done;
+        int dev = 0;
+        IBH_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (!done[dev]) {
+            IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&oa_chunk_sort<CS_BIG, CS_MID, 1024>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+            done[dev] = true;
+        }
     }
     Arena &A = arena();
     const size_t nt = (n + OA_TILE - 1) / OA_TILE;

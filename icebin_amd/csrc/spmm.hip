@@ -787,6 +787,51 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
     spmm_launch_many(w, 1, &dA, nvar, lda, &dB, ldb, fill, force_conservation, stream);
 }
 
+// ---- legacy coo_matvec contract (pylib/icebin_cython.cpp:158-192) ----------------------------------
+// yy = M xx with "REPLACE" semantics: a row is written only if at least one of its terms survives;
+// with ignore_nan, terms whose input is NaN are skipped; rows with no surviving term keep whatever
+// the caller put in yy (icebin.coo_multiply presets `fill`).  No wM involved.  One wave per (row,
+// field) for long rows, one thread for short ones; fixed summation order.
+template <bool WAVE>
+__global__ void matvec_legacy_kernel(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                     const double *__restrict__ vals, const double *__restrict__ X, long ldx,
+                                     double *__restrict__ Y, long ldy, int nrow, int ignore_nan)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (int)(WAVE ? t >> 6 : t);
+    const int lane = WAVE ? (int)(threadIdx.x & 63) : 0;
+    if (r >= nrow) return;
+    const double *x = X + (long)blockIdx.y * ldx;
+    double acc = 0.0;
+    int live = 0;
+    for (int k = rowptr[r] + lane; k < rowptr[r + 1]; k += WAVE ? 64 : 1) {
+        const double xv = x[colind[k]];
+        if (ignore_nan && xv != xv) continue;
+        acc = fma(vals[k], xv, acc);
+        ++live;
+    }
+    if (WAVE) {
+        acc = wave_sum(acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) live += __shfl_xor(live, off, 64);
+    }
+    if (lane == 0 && live > 0) Y[(long)blockIdx.y * ldy + r] = acc;
+}
+void matvec_legacy_launch(const ibh_weighted *w, const double *dx, int nvar, int64_t ldx, double *dy, int64_t ldy,
+                          int ignore_nan, hipStream_t stream)
+{
+    if (nvar <= 0 || w->nrow == 0) return;
+    IBH_CHECK(ldx >= w->ncol && ldy >= w->nrow, "coo_matvec: leading dimensions too small");
+    const bool wave = w->nnz >= 8 * (int64_t)w->nrow;
+    if (wave)
+        hipLaunchKernelGGL(matvec_legacy_kernel<true>, dim3((unsigned)ceil_div((long)w->nrow * 64, 256), (unsigned)nvar), dim3(256), 0,
+                           stream, w->rowptr.p, w->colind.p, w->val.p, dx, (long)ldx, dy, (long)ldy, w->nrow, ignore_nan);
+    else
+        hipLaunchKernelGGL(matvec_legacy_kernel<false>, dim3((unsigned)ceil_div(w->nrow, 256), (unsigned)nvar), dim3(256), 0,
+                           stream, w->rowptr.p, w->colind.p, w->val.p, dx, (long)ldx, dy, (long)ldy, w->nrow, ignore_nan);
+    IBH_HIP(hipGetLastError());
+}
+
 // ---- coupler-shaped product M * (V*T + b) ---------------------------------------------------
 // out[k, j] = sum_l T[l,k] * in[l, j] + b[k] * (scale ? scale[j] : 1): the variable transform, applied
 // on whichever side of M is small.  T entries that are exactly 0 are structural (skipped: a NaN in an

@@ -6,6 +6,11 @@ contiguous in memory, the CSR is replicated, and the SpMM needs no communication
 all-gather (torch.distributed, backend "nccl" on ROCm; "gloo" in the CPU tests) reassembles
 the [nf_total, nrow] result on every rank.  The reference has no counterpart: it gathers
 everything to MPI rank 0 and regrids there (modele/GCMCoupler_ModelE.cpp:764-792).
+
+Assembly (config 5: several ice sheets): sheets are independent regridders
+(GCMRegridder.hpp:249, regrid_matrices(sheet_index, ...)), so `sheet_partition` deals whole sheets
+to disjoint rank sets by size; the ranks of one set build the same matrices redundantly (a build is
+1-6 ms, cheaper than broadcasting a 0.5 GB CSR over one xGMI link) and shard the sheet's fields.
 """
 import torch
 import torch.distributed as dist
@@ -16,6 +21,37 @@ def field_shard(nf_total, world, rank):
     base, rem = divmod(nf_total, world)
     f0 = rank * base + min(rank, rem)
     return f0, f0 + base + (1 if rank < rem else 0)
+
+
+def sheet_partition(sheet_sizes, world):
+    """Deal ice sheets to disjoint, contiguous rank sets in proportion to their size (exchange cells).
+
+    sheet_sizes: {name: nX}.  Returns {name: (first_rank, n_ranks)}.  With fewer ranks than sheets
+    the sheets are dealt round-robin to single ranks (largest first).  Deterministic on every rank:
+    no communication."""
+    names = sorted(sheet_sizes, key=lambda k: (-sheet_sizes[k], k))
+    if world <= len(names):
+        load = [0] * world
+        out = {}
+        for n in names:
+            r = min(range(world), key=lambda k: (load[k], k))
+            out[n] = (r, 1)
+            load[r] += sheet_sizes[n]
+        return out
+    total = float(sum(sheet_sizes.values())) or 1.0
+    quota = {n: world * sheet_sizes[n] / total for n in names}
+    share = {n: max(1, int(quota[n])) for n in names}
+    while sum(share.values()) < world:          # largest remainder first
+        n = max(names, key=lambda k: (quota[k] - share[k], sheet_sizes[k]))
+        share[n] += 1
+    while sum(share.values()) > world:          # the minimum of one rank per sheet overshot: trim the most over-served
+        n = min((k for k in names if share[k] > 1), key=lambda k: quota[k] - share[k])
+        share[n] -= 1
+    out, r = {}, 0
+    for n in names:
+        out[n] = (r, share[n])
+        r += share[n]
+    return out
 
 
 def all_gather_fields(y_local, nf_total, group=None, out=None):
@@ -44,6 +80,70 @@ def all_gather_fields(y_local, nf_total, group=None, out=None):
     return out
 
 
+class CudaOps:
+    """Stream / event plumbing of the sharded apply on a HIP device (torch.cuda == HIP on ROCm)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.comm = torch.cuda.Stream(device=device)
+
+    def current(self):
+        return torch.cuda.current_stream(self.device)
+
+    def event(self):
+        return torch.cuda.Event()
+
+    def record(self, ev, stream):
+        ev.record(stream)
+
+    def wait_event(self, stream, ev):
+        stream.wait_event(ev)
+
+    def on_comm(self):
+        return torch.cuda.stream(self.comm)
+
+    def join_comm(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.comm)
+
+    def stream_handle(self, stream):
+        return stream.cuda_stream
+
+
+class HostOps:
+    """The same plumbing for CPU tensors (gloo rehearsals): everything is synchronous."""
+
+    device = torch.device("cpu")
+    comm = None
+
+    class _Ctx:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def current(self):
+        return None
+
+    def event(self):
+        return None
+
+    def record(self, ev, stream):
+        pass
+
+    def wait_event(self, stream, ev):
+        pass
+
+    def on_comm(self):
+        return self._Ctx()
+
+    def join_comm(self):
+        pass
+
+    def stream_handle(self, stream):
+        return 0
+
+
 class FieldShardedApply:
     """Weighted::apply of nf_total fields, sharded by field over the ranks of `group`.
 
@@ -51,87 +151,138 @@ class FieldShardedApply:
     one all-gather per `steps_per_gather` applies (fewer, larger collectives: a [nf_local, nrow]
     AvI result is only tens of KB, far below the size at which an RCCL call is bandwidth- rather
     than latency-bound), issued on a second stream so it overlaps the following SpMMs.  Buffers
-    are double-buffered by group; result(g, slot) is valid after wait()."""
+    are double-buffered by group; result(g, slot) is valid after wait().
 
-    def __init__(self, weighted, nf_total, group=None, device=None, steps_per_gather=1):
-        import ctypes as C
-        from . import _capi
+    `ops` carries the stream/event plumbing (CudaOps on a GPU, HostOps under gloo) and
+    `local_apply(x, y)` / `local_apply_many(xs, ys)` the rank-local SpMM writing into y: by default
+    the C-ABI device apply of `weighted`; the CPU tests inject the oracle, so the buffer layout, the
+    group choreography and the collectives of THIS class run with world > 1 on gloo."""
+
+    def __init__(self, weighted, nf_total, group=None, device=None, steps_per_gather=1, ops=None,
+                 local_apply=None, local_apply_many=None, nrow=None, ncol=None):
         self.w, self.nf_total, self.group = weighted, nf_total, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        assert nf_total % self.world == 0 or steps_per_gather == 1, "grouped gathers need equal shards"
         self.f0, self.f1 = field_shard(nf_total, self.world, self.rank)
-        self.device, self.G = device, int(steps_per_gather)
-        self.comm = torch.cuda.Stream(device=device)
-        nl, nrow = self.f1 - self.f0, weighted.nrow_d
-        self.nl, self.nrow = nl, nrow
-        # field planes padded to 512 bytes: whole-line wave stores (spmm.hip, shortrow) and the padded
-        # buffers stay contiguous, which is what all_gather_into_tensor needs
-        ld = self.ld = (nrow + 63) // 64 * 64 if self.world == 1 or nf_total % self.world == 0 else nrow
-        self._y = [torch.empty((self.G, nl, ld), dtype=torch.float64, device=device) for _ in range(2)]
-        if self.G == 1:
-            self._out = [torch.empty((nf_total, ld), dtype=torch.float64, device=device) for _ in range(2)]
-        else:
-            self._out = [torch.empty((self.world, self.G, nl, ld), dtype=torch.float64, device=device) for _ in range(2)]
-        self._done = [torch.cuda.Event() for _ in range(2)]
-        self._free = [torch.cuda.Event() for _ in range(2)]
+        self.G = int(steps_per_gather)
+        assert self.G >= 1
+        self.ops = ops if ops is not None else CudaOps(device)
+        self.device = self.ops.device
+        nl = self.f1 - self.f0
+        self.nl = nl
+        self.nrow = nrow = weighted.nrow_d if nrow is None else nrow
+        self.ncol = weighted.ncol_d if ncol is None else ncol
+        self.equal = nf_total % self.world == 0
+        self.nmax = -(-nf_total // self.world)                # fields of the largest shard
+        # field planes padded to 512 bytes: whole-line wave stores (spmm.hip, shortrow); ragged shards
+        # are padded to nmax fields (zeros) so that ONE all_gather_into_tensor serves every layout
+        ld = self.ld = (nrow + 63) // 64 * 64
+        dev = self.device
+        self._y = [torch.zeros((self.G, self.nmax, ld), dtype=torch.float64, device=dev) for _ in range(2)]
+        self._out = [torch.empty((self.world, self.G, self.nmax, ld), dtype=torch.float64, device=dev) for _ in range(2)]
+        self._done = [self.ops.event() for _ in range(2)]
+        self._free = [self.ops.event() for _ in range(2)]
         self._used = [False, False]
         self._i = 0
         self._cur = None
-        self._cur_ptr = None
-        # raw C-ABI call, arguments prepared once: the per-apply host cost must stay below the ~10 us kernel
-        self._fn = _capi.lib().ibh_weighted_apply_device
-        self._check = _capi.check
-        self._h = weighted._h
-        self._yp = [[C.c_void_p(self._y[g][s].data_ptr()) for s in range(self.G)] for g in range(2)]
-        self._C = C
+        self._cur_h = 0
+        if local_apply is None:
+            # raw C-ABI calls, arguments prepared once: the per-apply host cost must stay below the ~10 us kernel
+            import ctypes as C
+            from . import _capi
+            L = _capi.lib()
+            h, check, nrow_, ld_ = weighted._h, _capi.check, nrow, ld
+
+            def local_apply(x_ptr, ldx, y, fill, stream_h):
+                rc = L.ibh_weighted_apply_device(h, C.c_void_p(x_ptr), nl, ldx, C.c_void_p(y.data_ptr()), ld_, fill, 0,
+                                                 C.c_void_p(stream_h))
+                if rc != 0:
+                    check(rc)
+
+            def local_apply_many(x_ptrs, ldx, ys, fill, stream_h):
+                m = len(x_ptrs)
+                xa = (C.c_void_p * m)(*x_ptrs)
+                ya = (C.c_void_p * m)(*[y.data_ptr() for y in ys])
+                rc = L.ibh_weighted_apply_many_device(h, m, xa, nl, ldx, ya, ld_, fill, 0, C.c_void_p(stream_h))
+                if rc != 0:
+                    check(rc)
+        self._apply, self._apply_many = local_apply, local_apply_many
+
+    # ---- submission ----------------------------------------------------------------------------
+    def _open_group(self, g):
+        cur = self._cur = self.ops.current()
+        self._cur_h = self.ops.stream_handle(cur)
+        if self._used[g]:
+            self.ops.wait_event(cur, self._free[g])       # this group's buffers are still being gathered
+        return cur
 
     def apply(self, x_local, fill=float("nan")):
-        """x_local: torch.float64 CUDA tensor [nf_local, ncol_d], contiguous.  Returns (group, slot)."""
-        return self.apply_ptr(x_local.data_ptr(), x_local.stride(0), fill)
+        """x_local: float64 tensor [nf_local, ncol_d] on the ops' device, row-contiguous.  Returns (group, slot)."""
+        assert x_local.shape[0] == self.nl
+        return self.apply_ptr(x_local if self._is_host() else x_local.data_ptr(), x_local.stride(0) if self.nl > 1 else self.ncol, fill)
+
+    def _is_host(self):
+        return isinstance(self.ops, HostOps)
 
     def apply_ptr(self, x_ptr, ldx, fill=float("nan")):
         """Same with a raw device pointer (int) and leading dimension: the lean path for callers that
-        keep their field batches resident and call this every few microseconds."""
+        keep their field batches resident and call this every few microseconds.  (Under HostOps the
+        "pointer" is the tensor itself.)"""
         i = self._i
         g, slot = (i // self.G) & 1, i % self.G
         cur = self._cur
         if cur is None or slot == 0:
-            cur = self._cur = torch.cuda.current_stream(self.device)
-            self._cur_ptr = self._C.c_void_p(cur.cuda_stream)
-            if self._used[g]:
-                cur.wait_event(self._free[g])       # this group's buffers are still being gathered
-        rc = self._fn(self._h, x_ptr, self.nl, ldx, self._yp[g][slot], self.ld, fill, 0, self._cur_ptr)
-        if rc != 0:
-            self._check(rc)
+            cur = self._open_group(g)
+        if self.nl:
+            self._apply(x_ptr, ldx, self._y[g][slot][: self.nl], fill, self._cur_h)
         self._i = i + 1
         if slot == self.G - 1:
             self._gather(g, cur)
         return g, slot
 
-    def _gather(self, g, cur):
-        self._done[g].record(cur)
-        with torch.cuda.stream(self.comm):
-            self.comm.wait_event(self._done[g])
-            if self.G == 1:
-                all_gather_fields(self._y[g][0], self.nf_total, self.group, out=self._out[g])      # planes of width ld
+    def apply_many_ptr(self, x_ptrs, ldx, fill=float("nan")):
+        """A whole group (len(x_ptrs) == steps_per_gather applies) through ONE batched launch
+        (ibh_weighted_apply_many_device), then the group's gather.  Must start on a group boundary."""
+        assert len(x_ptrs) == self.G and self._i % self.G == 0, "apply_many_ptr submits whole groups"
+        g = (self._i // self.G) & 1
+        cur = self._open_group(g)
+        if self.nl:
+            if self._apply_many is not None:
+                self._apply_many(list(x_ptrs), ldx, [self._y[g][s][: self.nl] for s in range(self.G)], fill, self._cur_h)
             else:
-                dist.all_gather_into_tensor(self._out[g], self._y[g], group=self.group)
-            self._free[g].record(self.comm)
+                for s, xp in enumerate(x_ptrs):
+                    self._apply(xp, ldx, self._y[g][s][: self.nl], fill, self._cur_h)
+        self._i += self.G
+        self._gather(g, cur)
+        return g
+
+    def _gather(self, g, cur):
+        self.ops.record(self._done[g], cur)
+        with self.ops.on_comm():
+            if self.ops.comm is not None:
+                self.ops.wait_event(self.ops.comm, self._done[g])
+            # flat views: rank r's [G, nmax, ld] block lands at _out[g][r] on both RCCL and gloo
+            dist.all_gather_into_tensor(self._out[g].view(-1), self._y[g].view(-1), group=self.group)
+            self.ops.record(self._free[g], self.ops.comm)
         self._used[g] = True
 
     def flush(self):
         """Gather a partially filled group (end of a run)."""
         if self._i % self.G != 0:
             g = (self._i // self.G) & 1
-            self._gather(g, torch.cuda.current_stream(self.device))
+            self._gather(g, self.ops.current())
             self._i += self.G - self._i % self.G
         self._cur = None
 
     def wait(self):
-        torch.cuda.current_stream(self.device).wait_stream(self.comm)
+        self.ops.join_comm()
 
     def result(self, g, slot):
-        """[world, nf_local, nrow] view (rank-major == field-major) of the gathered fields of one apply."""
-        if self.G == 1:
-            return self._out[g].view(self.world, self.nl, self.ld)[:, :, :self.nrow]
-        return self._out[g][:, slot, :, :self.nrow]
+        """[nf_total, nrow] field-major gathered fields of one apply (a view for equal shards)."""
+        o = self._out[g][:, slot]                         # [world, nmax, ld]
+        if self.equal:
+            return o.reshape(self.world * self.nmax, self.ld)[:, : self.nrow]
+        parts = []
+        for r in range(self.world):
+            r0, r1 = field_shard(self.nf_total, self.world, r)
+            parts.append(o[r, : r1 - r0, : self.nrow])
+        return torch.cat(parts, dim=0)

@@ -300,5 +300,21 @@ def _aligned_planes(torch, nvar, n, device):
     return torch.empty((nvar, ld), dtype=torch.float64, device=device)[:, :n]
 
 
+def coo_multiply(M, xx, fill=np.nan, ignore_nan=False):
+    """icebin.coo_multiply(M, x, fill=nan, ignore_nan=False) (coo_matvec, pylib/icebin_cython.cpp:158-192;
+    tests/test_conserv/test_conserv.py:139): yy = M xx for a scipy.sparse COO matrix in the original
+    (sparse) index spaces; rows with no (surviving) entry hold `fill`."""
+    M = M.tocoo()
+    xx = np.ascontiguousarray(xx, np.float64).reshape(-1)
+    if xx.shape[0] != M.shape[1]:
+        raise ValueError("coo_multiply: xx has %d elements, M has %d columns" % (xx.shape[0], M.shape[1]))
+    yy = np.full(M.shape[0], fill, np.float64)
+    row, col = np.ascontiguousarray(M.row, np.int32), np.ascontiguousarray(M.col, np.int32)
+    data = np.ascontiguousarray(M.data, np.float64)
+    check(lib().ibh_coo_matvec(ptr(yy), ptr(xx), int(bool(ignore_nan)), M.shape[0], M.shape[1], len(data), ptr(row), ptr(col),
+                              ptr(data)))
+    return yy
+
+
 def set_tuning(key, value):
     check(lib().ibh_set_tuning(key.encode(), int(value)))

@@ -203,6 +203,18 @@ int ibh_weighted_reserve(const ibh_weighted *w, int32_t nvar);
 int ibh_weighted_apply_transformed_device(const ibh_weighted *w, const double *dA_b, int32_t nvar_in, int64_t lda,
                                           const double *T, const double *b, int32_t nvar_out,
                                           double *dB_b, int64_t ldb, double fill, void *stream);
+/* The legacy COO product behind icebin.coo_multiply(M, x, fill, ignore_nan) (coo_matvec,
+ * pylib/icebin_cython.cpp:158-192; used by tests/test_conserv/test_conserv.py:139-205 and
+ * pylib/icebin/ibplotter.py:88): yy[row] = sum of data*xx[col] over the row's entries, skipping entries
+ * whose input is NaN when ignore_nan != 0; a row with no surviving entry is NOT written (yy keeps what
+ * the caller preset, i.e. `fill`).  No wM test, no conservation correction.
+ * _device: on the CSR of a Weighted, field-major device arrays, only enqueues work on `stream`.
+ * ibh_coo_matvec: the reference's signature (host arrays, arbitrary triplet order, duplicates add up). */
+int ibh_weighted_matvec_device(const ibh_weighted *w, const double *dxx, int32_t nvar, int64_t ldx,
+                               double *dyy, int64_t ldy, int ignore_nan, void *stream);
+int ibh_coo_matvec(double *yy /* [nrow] in/out */, const double *xx /* [ncol] */, int ignore_nan,
+                   int64_t nrow, int64_t ncol, int64_t nnz, const int32_t *row, const int32_t *col,
+                   const double *data);
 /* linear_Weighted.apply_weight(dim, A) (matrix_formats.rst:167-186):
  * out[k] = sum_j w[j] * A_b[k*lda + j], w = wM (dim 0) or Mw (dim 1); host pointers. */
 int ibh_weighted_apply_weight_host(const ibh_weighted *w, int dim, const double *A_b,

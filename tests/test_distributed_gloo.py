@@ -60,6 +60,103 @@ def test_field_shard_all_gather(world, nf_total):
     assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
 
 
+def _worker_class(rank, world, port, nf_total, G, nsteps, q):
+    """The real FieldShardedApply under gloo: HostOps for the stream plumbing, the oracle as the
+    rank-local SpMM; buffer layout, group choreography, flush of a partial group and the collectives
+    are the class's own."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from icebin_amd import synthetic as syn
+        from icebin_amd.distributed import FieldShardedApply, HostOps, field_shard
+        from oracle import oracle as orc
+        g = syn.make_grids("g50")
+        em = syn.dome_elevmask(g)
+        o = orc.Regridder(g).matrix_d("AvI", em)
+        f0, f1 = field_shard(nf_total, world, rank)
+        calls = {"one": 0, "many": 0}
+
+        def local_apply(x, ldx, y, fill, stream_h):
+            calls["one"] += 1
+            y[:, :o.nrow] = torch.from_numpy(o.apply(x.numpy()))
+
+        def local_apply_many(xs, ldx, ys, fill, stream_h):
+            calls["many"] += 1
+            for x, y in zip(xs, ys):
+                y[:, :o.nrow] = torch.from_numpy(o.apply(x.numpy()))
+
+        sh = FieldShardedApply(None, nf_total, ops=HostOps(), steps_per_gather=G, local_apply=local_apply,
+                               local_apply_many=local_apply_many, nrow=o.nrow, ncol=o.ncol)
+        xs = [syn.fields(nf_total, o.ncol, seed=900 + k) for k in range(nsteps)]       # same on every rank
+        refs = [o.apply(x) for x in xs]
+        ok = True
+
+        def check_group(grp, steps):
+            nonlocal ok
+            sh.wait()
+            for slot, k in enumerate(steps):
+                got = sh.result(grp, slot).numpy()
+                ok = ok and got.shape == refs[k].shape and bool(np.array_equal(got, refs[k]))
+
+        k = 0
+        # first group through the batched entry when it is a whole group, the rest one apply at a time
+        if nsteps >= G:
+            grp = sh.apply_many_ptr([torch.from_numpy(xs[j][f0:f1].copy()) for j in range(G)], o.ncol)
+            check_group(grp, list(range(G)))
+            k = G
+        pending = []
+        while k < nsteps:
+            grp, slot = sh.apply(torch.from_numpy(xs[k][f0:f1].copy()))
+            pending.append(k)
+            if slot == G - 1:
+                check_group(grp, pending)
+                pending = []
+            k += 1
+        if pending:
+            grp = (sh._i // G) & 1
+            sh.flush()
+            check_group(grp, pending)
+        q.put((rank, ok, calls["one"], calls["many"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nf_total,G,nsteps", [(2, 8, 1, 3), (2, 8, 4, 10), (2, 7, 1, 3), (3, 8, 4, 6), (3, 9, 2, 5),
+                                                     (2, 1, 2, 3)])
+def test_field_sharded_apply_class_under_gloo(world, nf_total, G, nsteps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_class, args=(r, world, port, nf_total, G, nsteps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert all(ok for _, ok, _, _ in got), got
+    # the whole first group went through the batched entry on every rank that owns fields
+    assert all(many == (1 if nsteps >= G and rank < nf_total else 0) for rank, _, _, many in got)
+
+
+def test_sheet_partition():
+    from icebin_amd.distributed import sheet_partition
+    sizes = {"greenland": 4_366_000, "antarctica": 38_800_000}
+    p8 = sheet_partition(sizes, 8)
+    assert p8 == {"antarctica": (0, 7), "greenland": (7, 1)}
+    assert sheet_partition(sizes, 2) == {"antarctica": (0, 1), "greenland": (1, 1)}
+    assert sheet_partition(sizes, 1) == {"antarctica": (0, 1), "greenland": (0, 1)}
+    for world in range(1, 17):
+        p = sheet_partition({"a": 5, "b": 3, "c": 1}, world)
+        if world >= 3:      # disjoint contiguous rank sets covering every rank
+            spans = sorted(p.values())
+            assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:])) and sum(n for _, n in spans) == world
+        else:
+            assert all(n == 1 and 0 <= r < world for r, n in p.values())
+
+
 def test_field_shard_partition():
     from icebin_amd.distributed import field_shard
     for nf in (1, 7, 8, 64, 128):

@@ -292,6 +292,17 @@ def test_device_resident_apply_torch():
     assert rel_linf(dy.cpu().numpy(), o.apply(x)) <= FIELD_RTOL
 
 
+_BIG = {}
+
+
+def _big_grids(config):
+    """Full-size synthetic grids, one kept at a time (the Antarctic ones take a minute to generate)."""
+    if config not in _BIG:
+        _BIG.clear()
+        _BIG[config] = syn.make_grids(config)
+    return _BIG[config]
+
+
 def _conservation(W, x, y):
     a = math.fsum((W.Mw * x).tolist())
     b = math.fsum((W.wM * y).tolist())
@@ -324,7 +335,7 @@ def test_config4_full_size_1km_properties_and_parity():
 def test_config5_antarctica_1km_assembly_and_apply_properties():
     # BASELINE config 5 (the Antarctic sheet, 36 012 001 ice cells, 1/2 deg GCM): COO -> CSR assembly +
     # apply at full size.  Too large for the single-core oracle: checked through properties.
-    g = syn.make_grids("a1h")
+    g = _big_grids("a1h")
     assert g["nI"] == 36012001
     em = syn.dome_elevmask(g)
     mm = icebin_amd.from_synthetic(g)
@@ -355,6 +366,123 @@ def test_config5_antarctica_1km_assembly_and_apply_properties():
     assert IvA.nnz == AvI.nnz and IvA.last_kernel() == "none"
     back = IvA.apply(AvI.apply(np.ones((1, AvI.ncol_d))))
     assert IvA.last_kernel() == "shortrow" and np.all(np.abs(back - 1.0) < 1e-11)
+
+
+def _sheet_properties(config, names, nI_expected):
+    """Size-independent checks of a full-size sheet (too large for the single-core oracle): structure,
+    scaled rows sum to 1, sum(wM) == sum(Mw) == unmasked overlap area, conservation < 1e-13, and the
+    constant field survives the round trips."""
+    g = _big_grids(config)
+    assert g["nI"] == nI_expected
+    em = syn.dome_elevmask(g)
+    rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em, scale=True, correctA=False)
+    ok = np.isfinite(em[g["ex_indices"][:, 1]])
+    total = math.fsum(g["ex_area"][ok].tolist())
+    n_unmasked = int(np.isfinite(em).sum())
+    W = {}
+    for name in names:
+        w = W[name] = rm.matrix(name)
+        rowptr, col, val = w.csr_dense()
+        assert rowptr[0] == 0 and rowptr[-1] == w.nnz and np.all(np.diff(rowptr) >= 0), name
+        assert col.min() >= 0 and col.max() < w.ncol_d, name
+        # columns ascending inside every row
+        inner = np.ones(w.nnz, bool); inner[rowptr[:-1][np.diff(rowptr) > 0]] = False
+        assert np.all(np.diff(col)[inner[1:]] > 0), name
+        nz = np.diff(rowptr) > 0
+        rs = np.add.reduceat(val, rowptr[:-1][nz])
+        assert np.all(np.abs(rs - 1.0) < 1e-12), name                       # M = diag(1/wM) * (unscaled)
+        wM, Mw = w.wM, w.Mw
+        assert np.all(wM[nz] > 0) and np.all(Mw >= 0), name
+        assert abs(math.fsum(wM.tolist()) - total) / total < 1e-13, name
+        assert abs(math.fsum(Mw.tolist()) - total) / total < 1e-13, name
+        if name[0] in "AE":
+            assert w.ncol_d == n_unmasked and np.array_equal(np.sort(w.dim(1)), np.flatnonzero(np.isfinite(em))), name
+        else:
+            assert w.nrow_d == n_unmasked, name
+        x = syn.fields(2, w.ncol_d)
+        y = w.apply(x)
+        for k in range(2):
+            assert _conservation(w, x[k], y[k]) < 1e-13, name
+    return W
+
+
+def test_config5_antarctica_1km_elevation_class_matrices():
+    # the shapes recorded in a faulting scratch run of round 1 (a1h EvI; DESIGN.md "the a1h EvI fault"):
+    # EvI and IvE of the Antarctic sheet at full size, through the same properties
+    W = _sheet_properties("a1h", ("EvI", "IvE"), 36012001)
+    EvI, IvE = W["EvI"], W["IvE"]
+    assert EvI.nnz == IvE.nnz and EvI.nrow_d == IvE.ncol_d
+    # every ice cell lies between two classes: at most two entries per column of EvI / row of IvE
+    rowptr = IvE.csr_dense()[0]
+    assert np.diff(rowptr).max() <= 2 * 4        # <= 4 GCM cells under one ice cell, two classes each
+    # dims of the shared E space agree as sets (first-seen orders differ between the two generators)
+    assert np.array_equal(np.sort(EvI.dim(0)), np.sort(IvE.dim(1)))
+    one = np.ones((1, EvI.ncol_d))
+    back = IvE.apply(EvI.apply(one)[:, np.argsort(EvI.dim(0))[np.searchsorted(np.sort(EvI.dim(0)), IvE.dim(1))]])
+    assert np.all(np.abs(back - 1.0) < 1e-11)
+
+
+def test_config5_greenland_1km_half_degree_sheet():
+    # the other sheet of config 5: Greenland 1 km <-> 1/2 deg
+    W = _sheet_properties("g1h", ("AvI", "IvA"), 4204301)
+    AvI, IvA = W["AvI"], W["IvA"]
+    assert IvA.nnz == AvI.nnz
+    back = IvA.apply(AvI.apply(np.ones((1, AvI.ncol_d))))
+    assert np.all(np.abs(back - 1.0) < 1e-11)
+
+
+def test_config5_two_sheets_on_one_regridder():
+    # combined Greenland + Antarctica: two sheets on ONE GCMRegridder (GCMRegridder.hpp:249, per-sheet
+    # regridders); each sheet's matrices are those of the sheet alone (reduced sizes: g20 grids, the two
+    # domains placed on the same GCM grid)
+    g1 = syn.make_grids("g20")
+    g2 = syn.make_grids(dict(sheet="antarctica", dx_km=100, gcm="2x2.5"))
+    assert g1["nA"] == g2["nA"]
+    # one A grid covering both sheets' realised cells
+    allA = np.union1d(g1["A_to_sparse"], g2["A_to_sparse"])
+    native = np.zeros(len(allA)); proj = np.zeros(len(allA))
+    for g in (g2, g1):
+        pos = np.searchsorted(allA, g["A_to_sparse"])
+        native[pos], proj[pos] = g["A_native_area"], g["A_proj_area"]
+    mm = icebin_amd.GCMRegridder(dict(nA=g1["nA"], to_sparse=allA, native_area=native), g1["hcdefs"], True)
+    for name, g in (("greenland", g1), ("antarctica", g2)):
+        mm.add_sheet(name, dict(nI=g["nI"]), dict(indices=g["ex_indices"], overlaps=g["ex_area"]), "Z_INTERP", proj)
+    for name, g in (("greenland", g1), ("antarctica", g2)):
+        em = syn.dome_elevmask(g)
+        g = dict(g, A_to_sparse=allA, A_native_area=native, A_proj_area=proj)
+        rg = orc.Regridder(g)
+        rm = mm.regrid_matrices(name, em, scale=True, correctA=True)
+        for spec in ("AvI", "IvA", "EvI", "IvE", "EvA"):
+            assert_same_weighted(rm.matrix(spec), rg.matrix_d(spec, em, scale=True, correctA=True), name + " " + spec)
+
+
+def test_coo_multiply_legacy_contract():
+    # icebin.coo_multiply(M, x, fill, ignore_nan) (coo_matvec, pylib/icebin_cython.cpp:158-192): rows with no
+    # (surviving) entry keep `fill`; NaN inputs are skipped with ignore_nan, propagate without
+    g, em, mm, rg = setup("g20")
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    for name in ("AvI", "IvA", "IvE"):
+        w = rm.matrix(name)
+        M = w.to_coo()
+        rng = np.random.default_rng(3)
+        x = rng.standard_normal(M.shape[1])
+        x[rng.random(M.shape[1]) < 0.3] = np.nan
+        for ignore_nan in (False, True):
+            for fill in (np.nan, -5.0):
+                got = icebin_amd.coo_multiply(M, x, fill=fill, ignore_nan=ignore_nan)
+                ref = orc.coo_matvec(M, x, fill=fill, ignore_nan=ignore_nan)
+                assert np.array_equal(np.isnan(got), np.isnan(ref)), (name, ignore_nan, fill)
+                m = np.isfinite(ref)
+                assert np.max(np.abs(got[m] - ref[m])) <= FIELD_RTOL * max(np.max(np.abs(ref[m])), 1e-300)
+        # shuffled triplets with duplicates: same result up to rounding
+        perm = rng.permutation(len(M.data))
+        import scipy.sparse
+        M2 = scipy.sparse.coo_matrix((np.concatenate([M.data[perm] * 0.25, M.data * 0.75]),
+                                      (np.concatenate([M.row[perm], M.row]), np.concatenate([M.col[perm], M.col]))), shape=M.shape)
+        a = icebin_amd.coo_multiply(M2, np.nan_to_num(x), fill=np.nan)
+        b = orc.coo_matvec(M, np.nan_to_num(x), fill=np.nan)
+        m = np.isfinite(b)
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.max(np.abs(a[m] - b[m])) <= 1e-12 * np.max(np.abs(b[m]))
 
 
 def test_field_sharded_apply_rccl_world1():
