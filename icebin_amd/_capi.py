@@ -89,6 +89,10 @@ _SIGS = {
     "ibh_weighted_device_view_get": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
     "ibh_weighted_set_kernel": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ibh_weighted_last_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "ibh_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "ibh_event_destroy": (C.c_int, [C.c_void_p]),
+    "ibh_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "ibh_set_launch_events": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ibh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "ibh_release_cached_memory": (C.c_int, []),
     "ibh_selftest_sort": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),

@@ -575,6 +575,28 @@ int ibh_selftest_sort(const uint64_t *keys, int64_t n, int lo_bits, int hi_bits,
         *path_out = !(h.flags & ORD_FULL_DEC) ? 0 : h.maxlen <= (uint32_t)CS_BIG ? 1 : 2;
     });
 }
+int ibh_event_create(void **out) {
+    return guarded([&] {
+        IBH_CHECK(out != nullptr, "null argument");
+        require_device();
+        hipEvent_t e;
+        IBH_HIP(hipEventCreate(&e));
+        *out = e;
+    });
+}
+int ibh_event_destroy(void *ev) {
+    return guarded([&] { if (ev) IBH_HIP(hipEventDestroy(static_cast<hipEvent_t>(ev))); });
+}
+int ibh_event_elapsed_ms(void *start, void *stop, float *ms) {
+    return guarded([&] {
+        IBH_CHECK(start && stop && ms, "null argument");
+        IBH_HIP(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+        IBH_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    });
+}
+int ibh_set_launch_events(void *start, void *stop) {
+    return guarded([&] { set_launch_events(static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)); });
+}
 int ibh_release_cached_memory(void) {
     return guarded([&] { release_workspace(); release_cached_memory(); });
 }

@@ -184,6 +184,8 @@ struct ibh_weighted {
     ibh::DevBuf<double> band_v0, band_v1;                // [band_n] lower-class / upper-class weight
     mutable ibh::DevBuf<double> band_part;               // per-apply partial sums [2][nvar][nrow padded]
     mutable bool have_rowsum1 = false;
+    mutable ibh::DevBuf<int32_t> rowperm;                // rows by descending length (batched rowblock launches)
+    mutable bool have_rowperm = false;
     ~ibh_weighted() {
         for (int k = 0; k < 2; ++k)
             if (owns[k]) delete dims[k];
@@ -203,6 +205,7 @@ void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_i
                               const double *b, int nvar_out, double *dB, int64_t ldb, double fill, hipStream_t stream);
 void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int64_t lda, double *dout,
                        hipStream_t stream);
+void set_launch_events(hipEvent_t start, hipEvent_t stop);
 int get_tuning(const char *key, int dflt);
 void set_tuning(const char *key, int value);
 }  // namespace ibh

@@ -25,6 +25,7 @@
 //    Y stores -- is fully coalesced (512 B per wave-store, non-temporal); the
 //    small X (nf x nA_d) is served from L2.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <mutex>
 
 namespace ibh {
@@ -51,6 +52,14 @@ void set_tuning(const char *key, int value) {
     std::lock_guard<std::mutex> lk(t.mu);
     t.map[key] = value;
 }
+
+// ---- launch timing (ibh_set_launch_events) ---------------------------------------------------------
+// A caller that wants the duration of the SpMM kernel ITSELF (bench.py's roofline figure: the kernel's
+// launch duration, not the host's submission latency in front of it) hands in a pair of HIP events; the
+// next rowblock launch of this thread attaches them to its own dispatch (hipExtLaunchKernel: start =
+// kernel begins, stop = kernel ends -- the interval rocprofv3's kernel trace reports).  One-shot.
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
 
 // ---- helpers -------------------------------------------------------------------------------
 // Sum over the 64 lanes of a wave, result valid in every lane.  DPP moves instead of ds_bpermute:
@@ -160,7 +169,8 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
     const BatchPtrs bp, int nbatch, int qi, long ldx, int ncol, long ldy, int nrow, int nf, int nfc,
     int xcd_mode, const double *__restrict__ wM, double fill,
-    const double *__restrict__ vals2 = nullptr, double *__restrict__ Y2 = nullptr)
+    const double *__restrict__ vals2 = nullptr, double *__restrict__ Y2 = nullptr,
+    const int *__restrict__ rowperm = nullptr)
 {
     static_assert(!DUAL || WK == 1, "bands are not split across waves");
     constexpr int RB_THREADS = NW * 64;
@@ -176,6 +186,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 
     int r, fc;
     if (!block_to_task(blockIdx.x, nrow, nfc, xcd_mode, r, fc)) return;
+    if (rowperm) r = rowperm[r];        // longest rows first: the launch ends on short workgroups
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // provably wave-uniform
     const int wf = wave % WF, wk = wave / WF;
@@ -528,6 +539,33 @@ static void grow_scratch(DevBuf<T> &b, size_t count, hipStream_t stream, const c
     b.alloc(count);
 }
 
+// rowperm[k] = the row with the k-th most entries (ties by index): longest-processing-time-first order
+// of the (row, chunk) tasks.  Rank by counting, nrow <= LPT_MAX_ROWS.
+constexpr int LPT_MAX_ROWS = 8192;
+__global__ void rowperm_kernel(const int *__restrict__ rowptr, int nrow, int *__restrict__ perm) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    const int len = rowptr[r + 1] - rowptr[r];
+    int rank = 0;
+    for (int q = 0; q < nrow; ++q) {
+        const int lq = rowptr[q + 1] - rowptr[q];
+        rank += (lq > len || (lq == len && q < r)) ? 1 : 0;
+    }
+    perm[rank] = r;
+}
+static bool ensure_rowperm(const ibh_weighted *w, hipStream_t stream) {
+    if (w->have_rowperm) return true;
+    if (w->nrow > LPT_MAX_ROWS || w->nrow < 2) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
+    if (cs != hipStreamCaptureStatusNone && !(w->rowperm.p && (size_t)w->nrow * sizeof(int) <= w->rowperm.granted)) return false;
+    grow_scratch(w->rowperm, (size_t)w->nrow, stream, "row-order");
+    hipLaunchKernelGGL(rowperm_kernel, dim3(ceil_div(w->nrow, 256)), dim3(256), 0, stream, w->rowptr.p, w->nrow, w->rowperm.p);
+    IBH_HIP(hipGetLastError());
+    w->have_rowperm = true;
+    return true;
+}
+
 static long rowblock_grid(int nrow, int nfc, int &xcd_mode) {
     xcd_mode = (nfc % 8 == 0 || nfc == 1 || nfc == 2 || nfc == 4) ? 1 : 0;
     xcd_mode = get_tuning("rowblock_xcd_mode", xcd_mode);
@@ -566,9 +604,14 @@ static void launch_rowblock(const ibh_weighted *w, const BatchPtrs &bp, int nbat
         if (qi > nbatch) qi = nbatch;
     }
     const dim3 grid((unsigned)nb, (unsigned)ceil_div(nbatch, qi));
+    const int *rowperm = nullptr;
+    if (nbatch > 1 && get_tuning("rowblock_lpt", 0) && ensure_rowperm(w, stream)) rowperm = w->rowperm.p;
+    hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
 #define IBH_RB(U)                                                                                        \
-    hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U, NW>), grid, dim3(NW * 64), 0, stream,           \
-                       w->rowptr.p, w->colind.p, w->val.p, bp, nbatch, qi, lda, w->ncol, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill)
+    hipExtLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U, NW>), grid, dim3(NW * 64), 0, stream, ev0, ev1, 0,  \
+                          w->rowptr.p, w->colind.p, w->val.p, bp, nbatch, qi, lda, w->ncol, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill, \
+                          (const double *)nullptr, (double *)nullptr, (const int *)rowperm)
     if (unroll == 1) IBH_RB(1);
     else if (unroll == 2) IBH_RB(2);
     else if (unroll == 8) IBH_RB(8);

@@ -240,20 +240,26 @@ class FieldShardedApply:
         return g, slot
 
     def apply_many_ptr(self, x_ptrs, ldx, fill=float("nan")):
-        """A whole group (len(x_ptrs) == steps_per_gather applies) through ONE batched launch
-        (ibh_weighted_apply_many_device), then the group's gather.  Must start on a group boundary."""
-        assert len(x_ptrs) == self.G and self._i % self.G == 0, "apply_many_ptr submits whole groups"
-        g = (self._i // self.G) & 1
-        cur = self._open_group(g)
+        """len(x_ptrs) applies through ONE batched launch (ibh_weighted_apply_many_device) into the next
+        slots of the current group (they must fit: len <= steps_per_gather - slot); the group is
+        gathered when it fills up (or by flush()).  Returns (group, first slot)."""
+        m, i = len(x_ptrs), self._i
+        g, slot = (i // self.G) & 1, i % self.G
+        assert 1 <= m <= self.G - slot, "apply_many_ptr: %d applies do not fit the %d free slots of the group" % (m, self.G - slot)
+        cur = self._cur
+        if cur is None or slot == 0:
+            cur = self._open_group(g)
         if self.nl:
+            ys = [self._y[g][slot + s][: self.nl] for s in range(m)]
             if self._apply_many is not None:
-                self._apply_many(list(x_ptrs), ldx, [self._y[g][s][: self.nl] for s in range(self.G)], fill, self._cur_h)
+                self._apply_many(list(x_ptrs), ldx, ys, fill, self._cur_h)
             else:
-                for s, xp in enumerate(x_ptrs):
-                    self._apply(xp, ldx, self._y[g][s][: self.nl], fill, self._cur_h)
-        self._i += self.G
-        self._gather(g, cur)
-        return g
+                for xp, y in zip(x_ptrs, ys):
+                    self._apply(xp, ldx, y, fill, self._cur_h)
+        self._i = i + m
+        if slot + m == self.G:
+            self._gather(g, cur)
+        return g, slot
 
     def _gather(self, g, cur):
         self.ops.record(self._done[g], cur)

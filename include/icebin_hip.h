@@ -183,7 +183,7 @@ int ibh_weighted_apply_device(const ibh_weighted *w, const double *dA_b, int32_t
  * nbatch separate ibh_weighted_apply_device calls.  A 64-field 5 km apply is a latency-sized problem
  * (launch + dependent loads are a third of its 11 us); batched, that cost is paid once per launch.
  * More than IBH_MAX_BATCH batches are split into several launches. */
-#define IBH_MAX_BATCH 16
+#define IBH_MAX_BATCH 32
 int ibh_weighted_apply_many_device(const ibh_weighted *w, int32_t nbatch, const double *const *dA_b, int32_t nvar,
                                    int64_t lda, double *const *dB_b, int64_t ldb, double fill,
                                    int force_conservation, void *stream);
@@ -232,6 +232,14 @@ int ibh_weighted_device_view_get(const ibh_weighted *w, ibh_weighted_device_view
 int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow", "rowdual" */
 int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
 int ibh_set_tuning(const char *key, int value);
+/* Measurement hooks (bench.py): HIP events owned by the library, and a one-shot request to attach a
+ * pair of them to the NEXT rowblock SpMM launch of the calling thread (hipExtLaunchKernel: start = the
+ * kernel begins, stop = it ends -- the kernel's own duration, as rocprofv3's kernel trace reports it,
+ * without the host's submission latency in front).  ibh_event_elapsed_ms waits for `stop`. */
+int ibh_event_create(void **out);
+int ibh_event_destroy(void *ev);
+int ibh_event_elapsed_ms(void *start, void *stop, float *ms);
+int ibh_set_launch_events(void *start, void *stop);
 /* Diagnostic: run the assembly's ordering primitive (order analysis + independent-piece LDS sort,
  * falling back to the device-wide radix sort) on host keys with payload 0..n-1 and return the
  * resulting permutation, which must equal a stable sort by key.  key = (hi field << 32) | lo field,

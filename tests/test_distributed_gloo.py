@@ -103,7 +103,8 @@ def _worker_class(rank, world, port, nf_total, G, nsteps, q):
         k = 0
         # first group through the batched entry when it is a whole group, the rest one apply at a time
         if nsteps >= G:
-            grp = sh.apply_many_ptr([torch.from_numpy(xs[j][f0:f1].copy()) for j in range(G)], o.ncol)
+            grp, slot0 = sh.apply_many_ptr([torch.from_numpy(xs[j][f0:f1].copy()) for j in range(G)], o.ncol)
+            assert slot0 == 0
             check_group(grp, list(range(G)))
             k = G
         pending = []

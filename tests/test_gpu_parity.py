@@ -506,7 +506,12 @@ def test_field_sharded_apply_rccl_world1():
             sh = FieldShardedApply(w, 8, None, torch.device("cuda", 0), steps_per_gather=G)
             handles = []
             for i, dx in enumerate(dxs):
-                handles.append(sh.apply(dx))
+                if G == 4 and i < 4:       # the first whole group through ONE batched launch
+                    if i == 0:
+                        grp, _ = sh.apply_many_ptr([d.data_ptr() for d in dxs[:4]], w.ncol_d)
+                    handles.append((grp, i))
+                else:
+                    handles.append(sh.apply(dx))
                 if G == 4 and i == 3:      # first full group gathered: check it before its buffers are reused
                     sh.wait(); torch.cuda.synchronize()
                     for j in range(4):
@@ -677,7 +682,7 @@ def test_apply_is_graph_capturable():
 
 
 @pytest.mark.parametrize("name", ["AvI", "EvI", "IvA", "IvE"])
-@pytest.mark.parametrize("nbatch,nvar", [(1, 5), (2, 3), (5, 8), (16, 16), (19, 64)])
+@pytest.mark.parametrize("nbatch,nvar", [(1, 5), (2, 3), (5, 8), (16, 16), (19, 64), (35, 4)])
 def test_apply_many_is_bitwise_separate_applies(name, nbatch, nvar):
     # ibh_weighted_apply_many_device: ONE launch over several field batches (the staged row segment is
     # reused across the batches of a workgroup); results must be bitwise those of separate applies, for
