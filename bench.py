@@ -257,7 +257,7 @@ def main():
                        "cache": "warm" if args.warm else "cold (rotating batches > Infinity Cache)",
                        "kernel": W.last_kernel(), "queue_depth": depth, "parallelism": par},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, W.last_kernel(), depth),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, W.last_kernel(), depth, args.steps / max(nlaunch, 1)),
                          "kernel_us": kernel_ms * 1e3, "algorithmic_bytes": B,
                          "launches": nlaunch, "steps_per_launch": args.steps / max(nlaunch, 1),
                          "launch_us": meas_ms * 1e3 / max(nlaunch, 1),
@@ -321,10 +321,11 @@ def variant_all_unmasked(torch, icebin_amd, _capi, syn, grids, args, dev, steps=
             "achieved_GBps": B / us / 1e3, "frac": B / us / 1e3 / HBM_PEAK_GBS, "cells_per_s": ncol * nf / us * 1e6}
 
 
-def pmc_traffic(args, kernel, depth):
+def pmc_traffic(args, kernel, depth, applies_per_launch):
     """HBM bytes per LAUNCH of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this very command,
-    FETCH doubled per the gfx950 correction).  None when no profile matches this workload."""
+    FETCH doubled per the gfx950 correction), scaled from the profiled launch (32 applies) to this
+    run's applies per launch.  None when no profile matches this workload."""
     import glob
     key = "spmm_%s_%s_%s_%df_d%d%s" % (kernel, args.config, args.matrix, args.fields, depth, "_allunmasked" if args.all_unmasked else "")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
@@ -333,7 +334,7 @@ def pmc_traffic(args, kernel, depth):
         except (OSError, ValueError):
             continue
         if key in d and not args.warm:
-            return d[key]["traffic_bytes"]
+            return d[key]["traffic_bytes"] / d[key].get("applies_per_launch", 1) * applies_per_launch
     return None
 
 
