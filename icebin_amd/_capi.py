@@ -45,6 +45,8 @@ _SIGS = {
     "ibh_sparse_set_sparse_extent": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ibh_sparse_set_dense_extent": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "ibh_sparse_set_to_sparse": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ibh_sparse_set_to_dense": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
+    "ibh_sparse_set_add_dense": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
     "ibh_regridder_create": (C.c_int, [C.POINTER(RegridderDesc), C.POINTER(C.c_void_p)]),
     "ibh_regridder_destroy": (C.c_int, [C.c_void_p]),
     "ibh_regridder_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),

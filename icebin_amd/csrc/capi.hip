@@ -176,6 +176,33 @@ int ibh_sparse_set_to_sparse(const ibh_sparse_set *s, int64_t *out) {
     });
 }
 
+int ibh_sparse_set_to_dense(const ibh_sparse_set *s, int64_t sparse, int32_t *dense) {
+    return guarded([&] {
+        IBH_CHECK(s && dense, "null argument");
+        if (s->identity) { *dense = sparse >= 0 && sparse < s->n ? (int32_t)sparse : -1; return; }
+        s->ensure_inverse();
+        auto it = s->inv.find(sparse);
+        *dense = it == s->inv.end() ? -1 : it->second;
+    });
+}
+int ibh_sparse_set_add_dense(ibh_sparse_set *s, int64_t sparse, int32_t *dense) {
+    return guarded([&] {
+        IBH_CHECK(s && dense, "null argument");
+        IBH_CHECK(sparse >= 0 && (s->sparse_extent < 0 || sparse < s->sparse_extent), "sparse index %ld outside extent %ld",
+                  (long)sparse, (long)s->sparse_extent);
+        if (s->identity && sparse < s->n) { *dense = (int32_t)sparse; return; }
+        s->ensure_inverse();                     // materialises an identity prefix on the host
+        auto it = s->inv.find(sparse);
+        if (it != s->inv.end()) { *dense = it->second; return; }
+        IBH_CHECK(s->n < 0x7fffffff, "dense extent overflows int32");
+        s->identity = false;
+        s->host.push_back(sparse);
+        s->inv[sparse] = s->n;
+        *dense = s->n++;
+        s->host_n = s->inv_n = s->n;             // the device copy (entries [0, dev_n)) is completed by the next build
+    });
+}
+
 // ---- Regridder -----------------------------------------------------------------------------
 int ibh_regridder_create(const ibh_regridder_desc *d, ibh_regridder **out) {
     return guarded([&] {

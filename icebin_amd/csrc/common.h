@@ -123,6 +123,13 @@ struct ibh_sparse_set {
     mutable int32_t host_n = 0;
     ibh::DevBuf<int64_t> dev;            // entries [0, dev_n) valid
     int32_t dev_n = 0;
+    mutable std::unordered_map<int64_t, int32_t> inv;    // sparse -> dense of entries [0, inv_n): host-side to_dense / add_dense
+    mutable int32_t inv_n = 0;
+    void ensure_inverse() const {
+        ensure_host();
+        for (int32_t i = inv_n; i < n; ++i) inv[host[(size_t)i]] = i;
+        inv_n = n;
+    }
     int32_t dense_extent() const { return n; }
     void ensure_host() const {
         if (host_n >= n) return;

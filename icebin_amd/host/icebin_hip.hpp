@@ -40,6 +40,7 @@ struct ArrayView {
     T *data;
     long extent0, extent1;     // extent1 == 1 for rank-1 views
     int rank;
+    ArrayView() : data(nullptr), extent0(0), extent1(1), rank(1) {}
     ArrayView(T *p, long n) : data(p), extent0(n), extent1(1), rank(1) {}
     ArrayView(T *p, long n0, long n1) : data(p), extent0(n0), extent1(n1), rank(2) {}
     ArrayView(std::vector<typename std::remove_const<T>::type> const &v)
@@ -67,13 +68,30 @@ public:
     static SparseSetT identity(long n) { ibh_sparse_set *h; check(ibh_sparse_set_create_identity(n, &h)); return SparseSetT(h); }
     long sparse_extent() const { int64_t v; check(ibh_sparse_set_sparse_extent(h_, &v)); return (long)v; }
     int dense_extent() const { int32_t v; check(ibh_sparse_set_dense_extent(h_, &v)); return v; }
-    std::vector<long> to_sparse_all() const {
-        std::vector<int64_t> t((size_t)dense_extent());
-        check(ibh_sparse_set_to_sparse(h_, t.data()));
-        return std::vector<long>(t.begin(), t.end());
+    /** The whole dense -> sparse table.  Cached on the host: a set only ever grows (add_dense, or a matrix
+        build appending on the device), so the cache is refreshed when the dense extent has changed and
+        to_sparse(id) is O(1) in the loop shape of IceCoupler.cpp:449-457. */
+    std::vector<long> const &to_sparse_all() const {
+        const int n = dense_extent();
+        if ((int)cache_.size() != n) {
+            std::vector<int64_t> t((size_t)n);
+            check(ibh_sparse_set_to_sparse(h_, t.data()));
+            cache_.assign(t.begin(), t.end());
+        }
+        return cache_;
     }
     long to_sparse(int id) const { return to_sparse_all().at((size_t)id); }
+    /** spsparse::SparseSet::{add_dense, to_dense, in_sparse} (AbbrGrid.cpp:108, IceCoupler.cpp:298) */
+    int add_dense(long sparse) { int32_t d; check(ibh_sparse_set_add_dense(h_, sparse, &d)); return d; }
+    bool in_sparse(long sparse) const { int32_t d; check(ibh_sparse_set_to_dense(h_, sparse, &d)); return d >= 0; }
+    int to_dense(long sparse) const {
+        int32_t d; check(ibh_sparse_set_to_dense(h_, sparse, &d));
+        if (d < 0) throw Exception(IBH_ENOKEY, "SparseSet: sparse index " + std::to_string(sparse) + " is not in the set");
+        return d;
+    }
     ibh_sparse_set *handle() const { return h_; }
+private:
+    mutable std::vector<long> cache_;
 };
 
 // ---- RegridMatrices.hpp:17-37 ----------------------------------------------------------------
@@ -91,6 +109,8 @@ namespace linear {
 /** ibmisc::linear::Weighted / Weighted_Eigen: M plus wM, Mw, dims, conservative, scaled. */
 class Weighted {
     ibh_weighted *h_;
+    mutable std::vector<double> wM_, Mw_;
+    mutable bool have_wM_ = false, have_Mw_ = false;
 public:
     bool conservative, scaled;
     explicit Weighted(ibh_weighted *h) : h_(h) {
@@ -118,14 +138,44 @@ public:
         check(ibh_weighted_dim_to_sparse(h_, k, t.data()));
         return std::vector<long>(t.begin(), t.end());
     }
-    std::vector<double> wM() const { std::vector<double> v((size_t)shape_d()[0]); check(ibh_weighted_get_wM(h_, v.data())); return v; }
-    std::vector<double> Mw() const { std::vector<double> v((size_t)shape_d()[1]); check(ibh_weighted_get_Mw(h_, v.data())); return v; }
+    /** wM / Mw: host mirrors, downloaded once (the matrix is immutable after its build); wM(jj) as at
+        IceCoupler.cpp:456. */
+    std::vector<double> const &wM() const {
+        if (!have_wM_) { wM_.resize((size_t)shape_d()[0]); check(ibh_weighted_get_wM(h_, wM_.data())); have_wM_ = true; }
+        return wM_;
+    }
+    std::vector<double> const &Mw() const {
+        if (!have_Mw_) { Mw_.resize((size_t)shape_d()[1]); check(ibh_weighted_get_Mw(h_, Mw_.data())); have_Mw_ = true; }
+        return Mw_;
+    }
+    double wM(int jj) const { return wM().at((size_t)jj); }
+    double Mw(int jj) const { return Mw().at((size_t)jj); }
     /** ->M as row-major COO in dense index space */
     void M_coo(std::vector<int> &row, std::vector<int> &col, std::vector<double> &val) const {
         size_t n = (size_t)nnz();
         row.resize(n); col.resize(n); val.resize(n);
         check(ibh_weighted_get_coo(h_, row.data(), col.data(), val.data()));
     }
+    /** The `M` member callers poke (IceCoupler.cpp:408 iterates its entries, :445 multiplies with it): the
+        matrix lives in HBM; this view gives its shape and, on demand, a host copy of the triplets. */
+    struct MatrixView {
+        Weighted const *w;
+        int rows() const { return w->shape_d()[0]; }
+        int cols() const { return w->shape_d()[1]; }
+        long nonZeros() const { return w->nnz(); }
+        struct Triplet { int row, col; double value; };
+        std::vector<Triplet> triplets() const {
+            std::vector<int> r, c; std::vector<double> v;
+            w->M_coo(r, c, v);
+            std::vector<Triplet> t(v.size());
+            for (size_t k = 0; k < v.size(); ++k) t[k] = Triplet{r[k], c[k], v[k]};
+            return t;
+        }
+    };
+    MatrixView M{this};
+    /** `tmp`: objects that must live as long as the matrix (RegridMatrices_Dynamic::matrix hands the dims it
+        allocated to M->tmp, RegridMatrices_Dynamic.cpp:429-436). */
+    std::vector<std::shared_ptr<void>> tmp;
 
     /** apply(A_b, fill, force_conservation, tmp): A_b is (nvar, ncol_d) or a rank-1 vector of
         ncol_d values; returns (nvar, nrow_d) row-major.  The reference's TmpAlloc argument owned

@@ -51,6 +51,24 @@ class SparseSet:
         check(lib().ibh_sparse_set_to_sparse(self._h, ptr(out)))
         return out
 
+    def add_dense(self, sparse):
+        """Existing dense id of `sparse`, or the next one (first-seen order)."""
+        d = C.c_int32()
+        check(lib().ibh_sparse_set_add_dense(self._h, int(sparse), C.byref(d)))
+        return d.value
+
+    def to_dense(self, sparse):
+        d = C.c_int32()
+        check(lib().ibh_sparse_set_to_dense(self._h, int(sparse), C.byref(d)))
+        if d.value < 0:
+            raise KeyError(sparse)
+        return d.value
+
+    def in_sparse(self, sparse):
+        d = C.c_int32()
+        check(lib().ibh_sparse_set_to_dense(self._h, int(sparse), C.byref(d)))
+        return d.value >= 0
+
 
 class linear_Weighted:
     """A regrid matrix M plus its two weight vectors, resident in HBM.
@@ -166,6 +184,29 @@ class linear_Weighted:
         import scipy.sparse
         row, col, val = self.coo_dense()
         return scipy.sparse.coo_matrix((val, (self.dim(0)[row], self.dim(1)[col])), shape=self.shape)
+
+    # ---- on-disk "Eigen format" (matrix_formats.rst:9-63) -----------------------------------
+    def ncio(self, ds, vname, dim_names):
+        """Weighted_Eigen::ncio(ncio, vname, {dimB, dimA}) into an icebin_amd.ncio.Dataset (write side;
+        modele/global_ec.cpp:571-629, IceCoupler.cpp:473-488)."""
+        from . import ncio
+        row, col, val = self.coo_dense()
+        ncio.put_weighted(ds, vname, dim_names, (self.dim(0), self.dim(1)), (self.sparse_extent(0), self.sparse_extent(1)),
+                          row, col, val, self.wM, self.Mw, self.conservative, self.scaled)
+
+    @classmethod
+    def nc_read(cls, ds, vname):
+        """ibmisc.nc_read_weighted(nc, vname) (matrix_formats.rst:139-147): the matrix, its weights and its
+        dims from an Eigen-format file (a path or an icebin_amd.ncio.Dataset)."""
+        from . import ncio
+        if isinstance(ds, (str, bytes)) or hasattr(ds, "__fspath__"):
+            ds = ncio.Dataset.read(ds)
+        d = ncio.get_weighted(ds, vname)
+        w = cls.from_coo((len(d["dims"][0]), len(d["dims"][1])), d["row"], d["col"], d["val"], d["wM"], d["Mw"],
+                         d["conservative"], d["scaled"])
+        w._dims = [np.asarray(d["dims"][0], np.int64), np.asarray(d["dims"][1], np.int64)]
+        w._sparse_extents = list(d["sparse_extents"])
+        return w
 
     # ---- products ------------------------------------------------------------------------
     def apply(self, A_b, fill=np.nan, force_conservation=True):
@@ -314,6 +355,11 @@ def coo_multiply(M, xx, fill=np.nan, ignore_nan=False):
     check(lib().ibh_coo_matvec(ptr(yy), ptr(xx), int(bool(ignore_nan)), M.shape[0], M.shape[1], len(data), ptr(row), ptr(col),
                               ptr(data)))
     return yy
+
+
+def nc_read_weighted(nc, vname):
+    """ibmisc.nc_read_weighted (matrix_formats.rst:139-147)."""
+    return linear_Weighted.nc_read(nc, vname)
 
 
 def set_tuning(key, value):

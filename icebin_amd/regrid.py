@@ -45,8 +45,9 @@ class RegridMatrices:
 
 
 class _Sheet:
-    def __init__(self, handle, nI, arrays):
+    def __init__(self, handle, nI, arrays, interp_style="Z_INTERP", centroid=None):
         self.h, self.nI, self.arrays = handle, nI, arrays
+        self.interp_style, self.centroid = interp_style, centroid
 
 
 class GCMRegridder:
@@ -68,13 +69,74 @@ class GCMRegridder:
             self.correctA = bool(correctA)
             # Indexing({"A","HC"}, {0,0}, {nA,nhc}, {1,0}): HC has the largest stride (icebin_cython.cpp:69)
             self._hc_strides = (1, self._nA)
-        elif len(args) in (1, 4):
-            raise NotImplementedError(
-                "GCMRegridder(%s): the NetCDF-file forms are not part of this build (no NetCDF reader); "
-                "use GCMRegridder(gridA, hcdefs, correctA) with in-memory arrays" % ", ".join(map(repr, args)))
+        elif len(args) == 1:
+            # GCMRegridder(regridder_fname): "Load from existing GCMRegridder file" (_icebin.pyx:81-88)
+            self._sheets = {}
+            self._read(args[0], "m")
+            return
+        elif len(args) == 4:
+            # GCMRegridder(gridA_fname, gridA_vname, hcdefs, correctA) (_icebin.pyx:89-100): the grid file holds
+            # an AbbrGrid-shaped record of A (dim, native_area) under vname
+            from . import ncio
+            gridA_fname, gridA_vname, hcdefs, correctA = args
+            a = ncio.get_abbr_grid(ncio.Dataset.read(gridA_fname), gridA_vname)
+            self.__init__(dict(nA=a["sparse_extent"], to_sparse=a["to_sparse"], native_area=a["native_area"]), hcdefs, correctA)
+            return
         else:
             raise ValueError("Invalid arguments: {}".format(args))
         self._sheets = {}
+
+    # ---- GCMRegridder_Standard::ncio (GCMRegridder.cpp:104-150) -----------------------------------
+    def ncio_write(self, fname, vname="m"):
+        """Write the IceBin input file (the arrays the regrid path reads; grid specs / polygons are not
+        part of it): `m.info`, `m.agridA.*`, `m.indexingHC`, `m.hcdefs`, and per sheet `m.<sheet>.info`,
+        `.gridA_proj_area`, `.agridI.*`, `.aexgrid.indices/overlaps`."""
+        from . import ncio
+        ds = ncio.Dataset()
+        names = list(self._sheets)
+        ds.add_var(vname + ".info", np.int32, (), 0, dict(correctA=np.int32(self.correctA), sheets=names))
+        ncio.put_abbr_grid(ds, vname + ".agridA", self._A_to_sparse, self._nA, self._A_native, name="gridA")
+        nhc = len(self._hcdefs)
+        # Indexing({"A","HC"}, base {0,0}, extent {nA,nhc}, indices by descending stride)
+        ncio.put_indexing(ds, vname + ".indexingHC", [0, 0], [self._nA, nhc], [1, 0] if self._hc_strides[1] >= self._hc_strides[0] else [0, 1])
+        ds.add_var(vname + ".hcdefs", np.float64, (ds.add_dim(vname + ".nhc", nhc),), self._hcdefs)
+        ds.add_dim("agridA.ndata", len(self._A_to_sparse))
+        for name in names:
+            s = self._sheets[name]
+            idx, area, proj = s.arrays
+            v = vname + "." + name
+            ds.add_var(v + ".info", np.int32, (), 0, dict(name=name, interp_style=s.interp_style))
+            ds.add_var(v + ".gridA_proj_area", np.float64, ("agridA.ndata",), proj)
+            cen = None if s.centroid is None else np.asarray(s.centroid, np.float64).reshape(-1, 2)
+            ncio.put_abbr_grid(ds, v + ".agridI", np.arange(s.nI, dtype=np.int64), s.nI, np.zeros(s.nI), centroid_xy=cen, name="gridI")
+            ncio.put_exchange_grid(ds, v + ".aexgrid", idx, area)
+        ds.write(fname)
+
+    def _read(self, fname, vname):
+        from . import ncio
+        ds = ncio.Dataset.read(fname)
+        info = ds.variables[vname + ".info"]
+        a = ncio.get_abbr_grid(ds, vname + ".agridA")
+        self._nA = int(a["sparse_extent"])
+        self._A_to_sparse = np.ascontiguousarray(a["to_sparse"], np.int64)
+        self._A_native = np.ascontiguousarray(a["native_area"], np.float64)
+        self._hcdefs = np.ascontiguousarray(ds.variables[vname + ".hcdefs"].data, np.float64)
+        self.correctA = bool(info.correctA)
+        _, extent, indices = ncio.get_indexing(ds, vname + ".indexingHC")
+        st = ncio.indexing_strides(extent, indices)                  # a file may carry either layout (SURVEY.md 8a row 5)
+        self._hc_strides = (int(st[0]), int(st[1]))
+        for name in ncio._strlist(info.sheets):
+            v = vname + "." + name
+            sinfo = ds.variables[v + ".info"]
+            gI = ncio.get_abbr_grid(ds, v + ".agridI")
+            nI = int(gI["sparse_extent"])
+            cen = None
+            if np.any(gI["centroid_xy"] != 0):
+                cen = np.zeros((nI, 2))
+                cen[gI["to_sparse"]] = gI["centroid_xy"]          # dense -> sparse ice index
+            idx, area = ncio.get_exchange_grid(ds, v + ".aexgrid")
+            self.add_sheet(name, dict(nI=nI, centroid_xy=cen), dict(indices=idx, overlaps=area), str(sinfo.interp_style),
+                           np.asarray(ds.variables[v + ".gridA_proj_area"].data, np.float64))
 
     @property
     def nA(self):
@@ -110,7 +172,7 @@ class GCMRegridder:
             I_centroid_xy=None if cen is None else ptr(cen).value)
         h = C.c_void_p()
         check(lib().ibh_regridder_create(C.byref(d), C.byref(h)))
-        self._sheets[name] = _Sheet(h, int(gridI["nI"]), (idx, area, proj))
+        self._sheets[name] = _Sheet(h, int(gridI["nI"]), (idx, area, proj), interp_style, cen)
 
     def __del__(self):
         try:

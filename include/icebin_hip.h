@@ -63,6 +63,10 @@ int ibh_sparse_set_destroy(ibh_sparse_set *s);
 int ibh_sparse_set_sparse_extent(const ibh_sparse_set *s, int64_t *out);
 int ibh_sparse_set_dense_extent(const ibh_sparse_set *s, int32_t *out);
 int ibh_sparse_set_to_sparse(const ibh_sparse_set *s, int64_t *out /* [dense_extent] */);
+/* SparseSet::to_dense (-1 when the key is absent: in_sparse() == false) and add_dense (existing id or the
+ * next one, first-seen order: AbbrGrid.cpp:108, IceCoupler.cpp:298), host side. */
+int ibh_sparse_set_to_dense(const ibh_sparse_set *s, int64_t sparse, int32_t *dense);
+int ibh_sparse_set_add_dense(ibh_sparse_set *s, int64_t sparse, int32_t *dense);
 
 /* ------------------------------------------------------------------------- */
 /* Regridder: the state of GCMRegridder_Standard (GCMRegridder.hpp:207-302) and

@@ -100,6 +100,32 @@ int main() {
     REQUIRE(r0 == r1 && c0 == c1);
     for (size_t k = 0; k < v0.size(); ++k) REQUIRE(std::fabs(wM[(size_t)r0[k]] * v0[k] / v1[k] - 1.0) < 1e-14);
 
+    // the coupler's read-out loop (IceCoupler.cpp:449-457): dims[0]->to_sparse(jj) and wM(jj) per row, O(1) each
+    {
+        auto const &rows = dimO.to_sparse_all();
+        REQUIRE((int)rows.size() == dimO.dense_extent());
+        double s = 0;
+        for (int jj = 0; jj < dimO.dense_extent(); ++jj) {
+            REQUIRE(dimO.to_sparse(jj) == rows[(size_t)jj]);
+            REQUIRE(dimO.to_dense(dimO.to_sparse(jj)) == jj && dimO.in_sparse(rows[(size_t)jj]));
+            s += OvI->wM(jj);
+        }
+        REQUIRE(s > 0 && !dimO.in_sparse(0));
+        // SparseSet::add_dense on the host: an existing key keeps its id, a new one gets the next
+        SparseSetT extra(32);
+        REQUIRE(extra.add_dense(7) == 0 && extra.add_dense(3) == 1 && extra.add_dense(7) == 0 && extra.dense_extent() == 2);
+        REQUIRE(extra.to_sparse(1) == 3);
+        // a set pre-populated that way is appended to by a build (IceCoupler.cpp:366-371 shares dims between builds)
+        SparseSetT dimA2(32);
+        dimA2.add_dense(rows[2]);
+        auto M2 = rmO->matrix_d("AvI", {{&dimA2, &dimI}}, paramsO);
+        REQUIRE(dimA2.dense_extent() == 6 && dimA2.to_sparse(0) == rows[2] && dimA2.to_dense(rows[2]) == 0);
+        // ->M (IceCoupler.cpp:408 iterates the entries)
+        REQUIRE(M2->M.rows() == 6 && M2->M.cols() == nx * ny && M2->M.nonZeros() == M2->nnz());
+        auto trip = OvI->M.triplets();
+        REQUIRE((long)trip.size() == OvI->nnz() && trip.front().row == 0 && std::isfinite(trip.front().value));
+    }
+
     // errors surface as exceptions (error.hpp:28-32)
     bool threw = false;
     try { rm->matrix("BvA"); } catch (Exception const &e) { threw = e.code == IBH_ENOKEY; }

@@ -65,3 +65,27 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
                 assert "liboracle" not in text and "icebin_oracle.h" not in text, f
+
+
+def test_cython_module_builds_and_has_the_reference_surface():
+    # pylib/_icebin.pyx:50-175: `import icebin` gives GCMRegridder / RegridMatrices with the reference's
+    # method names and keyword defaults; compute fails loudly without a GPU (RuntimeError via `except +`)
+    import sys
+    from icebin_amd.cython.build_ext import build
+    build()
+    sys.path.insert(0, os.path.join(ROOT, "icebin_amd", "cython"))
+    import icebin
+    for cls, names in ((icebin.GCMRegridder, ("nA", "nE", "nhc", "wA", "add_sheet", "regrid_matrices")),
+                       (icebin.RegridMatrices, ("matrix",)),
+                       (icebin.linear_Weighted, ("apply_M", "apply_weight", "apply_wM", "apply_Mw", "to_coo", "get_weights", "shape"))):
+        for n in names:
+            assert hasattr(cls, n), (cls, n)
+    g = icebin.GCMRegridder(dict(nA=4, to_sparse=[0, 1], native_area=[1., 1.]), [0., 100.], True)
+    assert (g.nA, g.nE, g.nhc) == (4, 8, 2)
+    with pytest.raises(ValueError, match="Invalid arguments"):
+        icebin.GCMRegridder(1, 2)
+    with pytest.raises(ValueError, match="snative"):
+        g.wA("s", "bogus")
+    if _capi.device_count() == 0:
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            g.add_sheet("s", dict(nI=2), dict(indices=[[0, 0], [1, 1]], overlaps=[1., 1.]))

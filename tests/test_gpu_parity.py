@@ -456,6 +456,114 @@ def test_config5_two_sheets_on_one_regridder():
             assert_same_weighted(rm.matrix(spec), rg.matrix_d(spec, em, scale=True, correctA=True), name + " " + spec)
 
 
+def test_on_disk_formats_roundtrip(tmp_path):
+    # the IceBin input file (GCMRegridder_Standard::ncio, GCMRegridder.cpp:104-150) and the
+    # "Eigen format" of Weighted_Eigen (matrix_formats.rst:9-63).  GCMRegridder(fname) -- the 1-arg form of
+    # _icebin.pyx:81-88 -- on a file the writer produced builds bit-identical matrices; a Weighted survives
+    # write -> read bit-exact and applies identically.
+    from icebin_amd import ncio
+    g, em, mm, rg = setup("g20")
+    fn = str(tmp_path / "icebin_in.nc")
+    mm.ncio_write(fn)
+    ds = ncio.Dataset.read(fn)
+    for v in ("m.info", "m.agridA.dim", "m.agridA.native_area", "m.indexingHC", "m.hcdefs", "m.greenland.info",
+              "m.greenland.gridA_proj_area", "m.greenland.agridI.dim", "m.greenland.agridI.centroid_xy",
+              "m.greenland.aexgrid.indices", "m.greenland.aexgrid.overlaps"):
+        assert v in ds.variables, v
+    assert ds.dims["m.greenland.aexgrid.nindices"] == 2 * len(g["ex_area"]) and ds.dims["m.nhc"] == 40
+    mm2 = icebin_amd.GCMRegridder(fn)
+    assert (mm2.nA, mm2.nhc, mm2.nE, mm2.correctA) == (mm.nA, mm.nhc, mm.nE, mm.correctA)
+    assert np.array_equal(mm2.wA("greenland", "proj"), mm.wA("greenland", "proj"))
+    rm2 = mm2.regrid_matrices("greenland", em, scale=True, correctA=True)
+    for spec in ("AvI", "IvE", "EvA"):
+        assert_same_weighted(rm2.matrix(spec), rg.matrix_d(spec, em, scale=True, correctA=True), "from file " + spec)
+    # sigma != 0 needs the centroids the file carries
+    w_s = mm2.regrid_matrices("greenland", em, scale=True, correctA=True, sigma=(30e3, 30e3, 100.)).matrix("IvA")
+    assert not w_s.conservative
+    # 4-arg form: A grid from a grid file
+    fa = str(tmp_path / "gridA.nc")
+    dsA = ncio.Dataset()
+    ncio.put_abbr_grid(dsA, "grid", g["A_to_sparse"], g["nA"], g["A_native_area"])
+    dsA.write(fa)
+    mm4 = icebin_amd.GCMRegridder(fa, "grid", g["hcdefs"], True)
+    assert mm4.nA == mm.nA and mm4.nhc == 40
+    # the other indexingHC layout survives the file too
+    g2 = syn.make_grids("g50")
+    g2["hc_stride_A"], g2["hc_stride_HC"] = 40, 1
+    em2 = syn.dome_elevmask(g2)
+    f2 = str(tmp_path / "hcfast.nc")
+    icebin_amd.from_synthetic(g2).ncio_write(f2)
+    assert_same_weighted(icebin_amd.GCMRegridder(f2).regrid_matrices("greenland", em2, scale=True, correctA=True).matrix("EvI"),
+                         orc.Regridder(g2).matrix_d("EvI", em2, scale=True, correctA=True), "hc-fastest from file")
+
+    # Eigen format: two matrices sharing dimI in one file (IceCoupler.cpp:473-488 writes dims once)
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    AvI, EvI = rm.matrix("AvI"), rm.matrix("EvI")
+    out = ncio.Dataset()
+    AvI.ncio(out, "AvI", ("dimA", "dimI"))
+    EvI.ncio(out, "EvI", ("dimE", "dimI"))
+    fm = str(tmp_path / "matrices.nc")
+    out.write(fm)
+    for name, w in (("AvI", AvI), ("EvI", EvI)):
+        r = icebin_amd.nc_read_weighted(fm, name)
+        assert (r.nrow_d, r.ncol_d, r.nnz, r.conservative, r.scaled) == (w.nrow_d, w.ncol_d, w.nnz, w.conservative, w.scaled)
+        assert r.shape == w.shape and np.array_equal(r.dim(0), w.dim(0)) and np.array_equal(r.dim(1), w.dim(1))
+        for a, b in zip(r.coo_dense(), w.coo_dense()):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), name
+        assert np.array_equal(r.wM.view(np.uint64), w.wM.view(np.uint64)) and np.array_equal(r.Mw.view(np.uint64), w.Mw.view(np.uint64))
+        x = syn.fields(3, g["nI"])
+        x[:, ~np.isfinite(em)] = np.nan
+        a, b = r.apply_M(x), w.apply_M(x)
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+
+
+def test_cython_module_icebin_on_gpu(tmp_path):
+    # `import icebin` (the reference's module name, pylib/_icebin.pyx) over the C++ host mirror: the script of
+    # tests/test_conserv/test_conserv.py -- GCMRegridder(fname), regrid_matrices(sheet, elevmaskI, correctA=...),
+    # matrix(name), to_coo(), coo_multiply -- against the oracle
+    import os, sys
+    from icebin_amd.cython.build_ext import build
+    build()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "icebin_amd", "cython"))
+    import icebin
+    g, em, mm, rg = setup("g20")
+    fn = str(tmp_path / "icebin_in.nc")
+    mm.ncio_write(fn)
+    mm2 = icebin.GCMRegridder(fn)
+    assert (mm2.nA, mm2.nhc, mm2.nE) == (mm.nA, 40, mm.nA * 40)
+    assert np.array_equal(mm2.wA("greenland", "native"), mm.wA("greenland", "native"))
+    rm = mm2.regrid_matrices("greenland", em.reshape(g["nx"], g["ny"]))        # defaults: scale=True, correctA=True
+    mats = {}
+    for name in ("AvI", "IvA", "EvI", "IvE", "AvE", "EvA"):
+        w = mats[name] = rm.matrix(name)
+        o = rg.matrix_d(name, em, scale=True, correctA=True)
+        assert w.shape == (o.sparse_extents[0], o.sparse_extents[1]) and w.shape_d == (o.nrow, o.ncol)
+        assert np.array_equal(w.dim(0), o.dims[0]) and np.array_equal(w.dim(1), o.dims[1])
+        assert np.array_equal(w.wM.view(np.uint64), o.wM.view(np.uint64)) and np.array_equal(w.Mw.view(np.uint64), o.Mw.view(np.uint64))
+        M = w.to_coo()
+        assert np.array_equal(M.data.view(np.uint64), o.val.view(np.uint64))
+        assert np.array_equal(M.row, o.dims[0][o.row]) and np.array_equal(M.col, o.dims[1][o.col])
+    # test_conserv.py:132-172: a constant survives I -> A -> I and I -> E -> I (coo_multiply) ...
+    AvI, IvA, EvI, IvE = (mats[k].to_coo() for k in ("AvI", "IvA", "EvI", "IvE"))
+    valI = np.ones(g["nI"])
+    valIAI = icebin.coo_multiply(IvA, icebin.coo_multiply(AvI, valI, fill=np.nan), fill=np.nan, ignore_nan=True)
+    m = np.isfinite(valIAI)
+    assert m.sum() == np.isfinite(em).sum() and np.all(np.abs(valIAI[m] - 1.0) < 1e-11)
+    # ... and apply_M on 2-D input + conservation sum(x*Mw) == sum(Mx*wM) (test_conserv.py:174-205)
+    x = syn.fields(2, g["nI"])
+    y = mats["AvI"].apply_M(x)
+    ref = rg.matrix_d("AvI", em, scale=True, correctA=True)
+    yd = ref.apply(x[:, ref.dims[1]])
+    assert rel_linf(y[:, ref.dims[0]], yd) <= FIELD_RTOL and np.isnan(y[:, 0]).all()
+    for k in range(2):
+        a, b = mats["AvI"].apply_Mw(x[k]), mats["AvI"].apply_wM(np.nan_to_num(y[k]))
+        assert abs(a - b) / abs(a) < 1e-12
+    with pytest.raises(RuntimeError, match="unknown regrid matrix"):
+        rm.matrix("BvA")
+    with pytest.raises(KeyError):
+        mm2.regrid_matrices("antarctica", em)
+
+
 def test_coo_multiply_legacy_contract():
     # icebin.coo_multiply(M, x, fill, ignore_nan) (coo_matvec, pylib/icebin_cython.cpp:158-192): rows with no
     # (surviving) entry keep `fill`; NaN inputs are skipped with ignore_nan, propagate without

@@ -1,0 +1,106 @@
+"""The self-contained NetCDF-classic container (icebin_amd/ncio.py) and the reference's on-disk layouts
+(SURVEY.md 8f rank 2): CPU part.  The reader is checked against an independent implementation
+(scipy.io.netcdf_file writes CDF-1 / CDF-2), the CDF-5 writer against the reader, and the Eigen-format /
+IceBin-input-file layouts against the names matrix_formats.rst:9-63 and GCMRegridder.cpp:104-150 spell out."""
+import os
+
+import numpy as np
+import pytest
+
+from icebin_amd import ncio
+
+
+def test_reader_against_scipy_netcdf(tmp_path):
+    from scipy.io import netcdf_file
+    for version in (1, 2):
+        p = str(tmp_path / ("scipy_v%d.nc" % version))
+        f = netcdf_file(p, "w", version=version)
+        f.history = "made by scipy"
+        f.createDimension("n", 5)
+        f.createDimension("BvA.M.rank", 2)
+        v = f.createVariable("BvA.M.indices", "i", ("n", "BvA.M.rank"))
+        v[:] = np.arange(10).reshape(5, 2)
+        v.shape_att = np.array([5, 6], np.int32)
+        w = f.createVariable("vals", "d", ("n",))
+        w[:] = np.linspace(0, 1, 5)
+        w.units = "m2"
+        s = f.createVariable("scalar", "i", ())
+        s.data[...] = 7                 # (scipy's assignValue does not handle 0-d arrays)
+        f.close()
+        ds = ncio.Dataset.read(p)
+        assert ds.dims == {"n": 5, "BvA.M.rank": 2} and ds.attrs["history"] == "made by scipy"
+        assert np.array_equal(ds.variables["BvA.M.indices"].data, np.arange(10).reshape(5, 2))
+        assert np.array_equal(ds.variables["BvA.M.indices"].shape_att, [5, 6])
+        assert np.array_equal(ds.variables["vals"].data, np.linspace(0, 1, 5)) and ds.variables["vals"].units == "m2"
+        assert ds.variables["scalar"].data == 7 and ds.variables["scalar"].dims == ()
+
+
+def test_cdf5_roundtrip_all_types(tmp_path):
+    rng = np.random.default_rng(1)
+    ds = ncio.Dataset()
+    ds.attrs["title"] = "roundtrip"
+    ds.add_dim("a", 3); ds.add_dim("b.c", 4); ds.add_dim("empty", 0)
+    for i, dt in enumerate(("int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float32", "float64")):
+        x = (rng.random((3, 4)) * 100).astype(dt)
+        ds.add_var("v." + dt, dt, ("a", "b.c"), x, {"k": np.asarray([1, 2, 3], dt), "note": "n%d" % i, "one": np.int64(2 ** 40)})
+    ds.add_var("big", np.int64, ("a",), [2 ** 62, -2 ** 62, 5])
+    ds.add_var("nothing", np.float64, ("empty",), np.zeros(0))
+    ds.add_var("s", np.int32, (), 0, {"names": ["x.y", "z"], "nan": np.float64("nan")})
+    p = str(tmp_path / "t.nc")
+    ds.write(p)
+    assert open(p, "rb").read(4) == b"CDF\x05"
+    rd = ncio.Dataset.read(p)
+    assert rd.dims == ds.dims and rd.attrs["title"] == "roundtrip"
+    for k, v in ds.variables.items():
+        r = rd.variables[k]
+        assert r.dims == v.dims and r.data.dtype == v.data.dtype and np.array_equal(r.data, v.data), k
+    assert rd.variables["s"].names == "x.y,z" and ncio._strlist(rd.variables["s"].names) == ["x.y", "z"]
+    assert np.isnan(rd.variables["s"].nan) and rd.variables["v.int8"].one == 2 ** 40
+    assert np.array_equal(rd.variables["v.uint16"].k, [1, 2, 3])
+
+
+def test_eigen_format_layout_and_roundtrip(tmp_path):
+    # the example of matrix_formats.rst:17-40: BvA with dimB (5 of 40) and dimA (6 of 50), 6 nonzeros
+    dimB, dimA = np.array([3, 7, 11, 20, 39]), np.array([17, 1, 2, 30, 44, 49])
+    row, col = np.array([0, 0, 1, 2, 3, 4], np.int32), np.array([0, 1, 1, 2, 4, 5], np.int32)
+    val = np.array([28.9, 1.5, 2.5, -0.0, 1e-300, 3.141592653589793])
+    wM, Mw = np.arange(5) + 0.5, np.arange(6) * 1.25
+    ds = ncio.Dataset()
+    ncio.put_weighted(ds, "BvA", ("dimB", "dimA"), (dimB, dimA), (40, 50), row, col, val, wM, Mw, conservative=False)
+    assert ds.dims == {"dimB.dense_extent": 5, "dimA.dense_extent": 6, "BvA.M.nnz": 6, "BvA.M.rank": 2}
+    assert set(ds.variables) == {"dimB", "dimA", "BvA.info", "BvA.M.info", "BvA.M.indices", "BvA.M.values", "BvA.Mw", "BvA.wM"}
+    assert ds.variables["dimB"].data.dtype == np.int64 and ds.variables["dimB"].sparse_extent == 40
+    assert ds.variables["BvA.info"].type == "EIGEN" and ds.variables["BvA.info"].conservative == 0
+    assert ds.variables["BvA.M.info"].conservative == "f" and list(ds.variables["BvA.M.info"].shape) == [5, 6]
+    assert ds.variables["BvA.Mw"].dims == ("dimA.dense_extent",) and ds.variables["BvA.wM"].dims == ("dimB.dense_extent",)
+    # a second matrix sharing dimA re-uses the dimension variable (IceCoupler.cpp:479-487 writes dims once)
+    ncio.put_weighted(ds, "CvA", ("dimC", "dimA"), (np.arange(2), dimA), (2, 50), [0], [5], [1.0], [1, 1], Mw, conservative=True)
+    p = str(tmp_path / "m.nc")
+    ds.write(p)
+    d = ncio.get_weighted(ncio.Dataset.read(p), "BvA")
+    assert d["dim_names"] == ["dimB", "dimA"] and d["sparse_extents"] == [40, 50] and not d["conservative"]
+    assert np.array_equal(d["dims"][0], dimB) and np.array_equal(d["dims"][1], dimA)
+    assert np.array_equal(d["row"], row) and np.array_equal(d["col"], col)
+    assert np.array_equal(d["val"].view(np.uint64), val.view(np.uint64))          # bit-exact, incl. -0.0
+    assert np.array_equal(d["wM"], wM) and np.array_equal(d["Mw"], Mw)
+    assert ncio.get_weighted(ncio.Dataset.read(p), "CvA")["conservative"]
+
+
+def test_indexing_strides_both_layouts():
+    # Indexing({"A","HC"}, {0,0}, {nA,nhc}, {1,0}): HC has the largest stride (icebin_cython.cpp:69)
+    assert list(ncio.indexing_strides([12960, 40], [1, 0])) == [1, 12960]
+    assert list(ncio.indexing_strides([12960, 40], [0, 1])) == [40, 1]
+
+
+def test_hdf5_files_are_refused_clearly(tmp_path):
+    p = str(tmp_path / "h5.nc")
+    open(p, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    try:
+        import netCDF4  # noqa: F401
+        pytest.skip("netCDF4 present: the HDF5 path is live")
+    except ImportError:
+        with pytest.raises(ImportError, match="nccopy -k cdf5"):
+            ncio.Dataset.read(p)
+    open(p, "wb").write(b"garbage")
+    with pytest.raises(ValueError, match="not a NetCDF classic"):
+        ncio.Dataset.read(p)
