@@ -29,6 +29,11 @@ class RegridderDesc(C.Structure):
     ]
 
 
+class ExgridDesc(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("xedges", C.c_void_p), ("yedges", C.c_void_p), ("x_fastest", C.c_int32),
+                ("npoly", C.c_int32), ("polyptr", C.c_void_p), ("vx", C.c_void_p), ("vy", C.c_void_p), ("iA", C.c_void_p)]
+
+
 class DeviceView(C.Structure):
     _fields_ = [("nrow", C.c_int32), ("ncol", C.c_int32), ("nnz", C.c_int64), ("rowptr", C.c_void_p),
                 ("colind", C.c_void_p), ("val", C.c_void_p), ("wM", C.c_void_p), ("Mw", C.c_void_p)]
@@ -47,6 +52,10 @@ _SIGS = {
     "ibh_sparse_set_to_sparse": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ibh_sparse_set_to_dense": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
     "ibh_sparse_set_add_dense": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]),
+    "ibh_exgrid_generate": (C.c_int, [C.POINTER(ExgridDesc), C.POINTER(C.c_void_p)]),
+    "ibh_exgrid_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ibh_exgrid_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ibh_exgrid_destroy": (C.c_int, [C.c_void_p]),
     "ibh_regridder_create": (C.c_int, [C.POINTER(RegridderDesc), C.POINTER(C.c_void_p)]),
     "ibh_regridder_destroy": (C.c_int, [C.c_void_p]),
     "ibh_regridder_sizes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
@@ -64,6 +73,7 @@ _SIGS = {
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ibh_weighted_from_csr": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "ibh_e1ve0_compute": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]),
     "ibh_weighted_destroy": (C.c_int, [C.c_void_p]),
     "ibh_weighted_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "ibh_weighted_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

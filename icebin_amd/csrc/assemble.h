@@ -12,4 +12,8 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
 // Eigen setFromTriplets (to_eigen_M, eigen_types.cpp:9-34) on device: fills w's CSR from host COO.
 void weighted_from_coo_device(ibh_weighted *w, int nrow, int ncol, int64_t n, const int32_t *row, const int32_t *col,
                               const double *val);
+// compute_E1vE0c (e1ve0.cpp:55-106) on device; `out` comes with identity dims over nE.
+void e1ve0_compute(int nsheets, const ibh_weighted *const *XuE1s, const ibh_weighted *const *XuE0s, int64_t nE, ibh_weighted *out);
+// make_exchange_grid (gridgen/GridGen_Exchange.cpp:175-284) for a rectilinear XY ice grid (gridgen.hip)
+void exgrid_generate(const ibh_exgrid_desc *d, ibh_exgrid *out);
 }  // namespace ibh

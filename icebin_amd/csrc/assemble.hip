@@ -1351,4 +1351,196 @@ void weighted_from_coo_device(ibh_weighted *w, int nrow, int ncol, int64_t n, co
     IBH_HIP(hipStreamSynchronize(st));
 }
 
+// ---- E1vE0 (slib/icebin/e1ve0.cpp:55-106 compute_E1vE0c) ------------------------------------------------
+//   E1vE0c = diag(1 / sum_sheets Mw(XuE1)) * sum_sheets[ E1uX * (XvE0 - XvE1) ], consolidated,
+// XvE = diag(1/wM) * XuE.  Every exchange cell x has <= a handful of entries in XuE1 and XuE0, so the
+// product through X is again a keyed sum: per x, every (e1 of XuE1 row x) x (e of the merged row of
+// XvE0 - XvE1) contributes u1 * d to key (e1, e), summed over x ascending with the first term assigned
+// (Eigen's conservative sparse product) -- the assembly machinery (contributions -> order -> sequential
+// sums) does the rest.  Keys are SPARSE E indices (the reference works on sparsified matrices).
+struct XuEView {
+    const int32_t *rowptr, *colind;
+    const double *val, *wM;
+    const int64_t *col_s;        // dense E -> sparse E
+    const int32_t *rowmap;       // sparse x -> dense row, nullptr: identity
+    int nrow;
+};
+__device__ __forceinline__ int xue_row(const XuEView &m, long x) {
+    if (!m.rowmap) return x < m.nrow ? (int)x : -1;
+    return m.rowmap[x];
+}
+constexpr int E1_MAXROW = 16;    // entries of one XuE row handled in registers (Z_INTERP gives <= 2)
+template <int PASS>
+__global__ void k_e1ve0(XuEView m1, XuEView m0, long nX, uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pos,
+                        uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, double *__restrict__ term,
+                        uint32_t *__restrict__ too_long)
+{
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nX) return;
+    const int r1 = xue_row(m1, x), r0 = xue_row(m0, x);
+    const int b1 = r1 >= 0 ? m1.rowptr[r1] : 0, n1 = r1 >= 0 ? m1.rowptr[r1 + 1] - b1 : 0;
+    const int b0 = r0 >= 0 ? m0.rowptr[r0] : 0, n0 = r0 >= 0 ? m0.rowptr[r0 + 1] - b0 : 0;
+    if (n1 > E1_MAXROW || n0 > E1_MAXROW) { *too_long = 1u; if (!PASS) cnt[x] = 0; return; }
+    // merged row of D = XvE0 - XvE1 by sparse column: entries of E0 first, then the E1 entries E0 lacks
+    int nd = n0;
+    for (int j = 0; j < n1; ++j) {
+        const int64_t e = m1.col_s[m1.colind[b1 + j]];
+        bool in0 = false;
+        for (int i = 0; i < n0; ++i) in0 = in0 || m0.col_s[m0.colind[b0 + i]] == e;
+        nd += in0 ? 0 : 1;
+    }
+    if (!PASS) { cnt[x] = (uint32_t)(n1 * nd); return; }
+    if (n1 == 0 || nd == 0) return;
+    const double s0 = r0 >= 0 ? 1. / m0.wM[r0] : 0.0, s1 = 1. / m1.wM[r1];
+    uint32_t p = pos[x];
+    for (int a = 0; a < n1; ++a) {
+        const int64_t e1 = m1.col_s[m1.colind[b1 + a]];
+        const double u1 = m1.val[b1 + a];
+        for (int i = 0; i < n0; ++i) {                        // columns stored in E0 (a - b, or a)
+            const int64_t e = m0.col_s[m0.colind[b0 + i]];
+            double d = s0 * m0.val[b0 + i];
+            for (int j = 0; j < n1; ++j)
+                if (m1.col_s[m1.colind[b1 + j]] == e) d = d - s1 * m1.val[b1 + j];
+            keys[p] = ((uint64_t)e1 << 32) | (uint64_t)e; idx[p] = p; term[p] = u1 * d; ++p;
+        }
+        for (int j = 0; j < n1; ++j) {                        // columns only E1 stores (0 - b)
+            const int64_t e = m1.col_s[m1.colind[b1 + j]];
+            bool in0 = false;
+            for (int i = 0; i < n0; ++i) in0 = in0 || m0.col_s[m0.colind[b0 + i]] == e;
+            if (in0) continue;
+            keys[p] = ((uint64_t)e1 << 32) | (uint64_t)e; idx[p] = p; term[p] = u1 * (0.0 - s1 * m1.val[b1 + j]); ++p;
+        }
+    }
+}
+__global__ void k_scatter_rowmap(const int64_t *__restrict__ to_sparse, int n, int32_t *__restrict__ rowmap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rowmap[to_sparse[i]] = i;
+}
+__global__ void k_add_by_sparse(const double *__restrict__ v, const int64_t *__restrict__ to_sparse, int n, double *__restrict__ acc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int64_t s = to_sparse[i]; acc[s] = acc[s] + v[i]; }       // sparse ids of one matrix are distinct
+}
+__global__ void k_scale_rows_inv(const int32_t *__restrict__ rowptr, int nrow, double *__restrict__ val, const double *__restrict__ sum) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    const int b = rowptr[r], e = rowptr[r + 1];
+    if (b == e) return;
+    const double s = 1. / sum[r];
+    for (int k = b; k < e; ++k) val[k] = val[k] * s;          // ii->value() *= sE1(iE1)
+}
+__global__ void k_csr_to_contrib(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind, const double *__restrict__ val,
+                                 int nrow, uint32_t base, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, double *__restrict__ term) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const uint32_t p = base + (uint32_t)k;
+        keys[p] = ((uint64_t)(uint32_t)r << 32) | (uint32_t)colind[k]; idx[p] = p; term[p] = val[k];
+    }
+}
+__global__ void k_fill_f64(double *p, size_t n, double v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+static const int64_t *dims_device_table(ibh_sparse_set *set, int n, hipStream_t st) {
+    // dense -> sparse table of a matrix's dims on the device (an identity set is materialised in the arena)
+    Arena &A = arena();
+    int64_t *t = A.get<int64_t>((size_t)n);
+    if (set->identity) {
+        hipLaunchKernelGGL(k_iota_i64, dim3(ceil_div(n, 256)), dim3(256), 0, st, t, (size_t)n);
+    } else if (set->dev_n >= n) {
+        IBH_HIP(hipMemcpyAsync(t, set->dev.p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    } else {
+        set->ensure_host();
+        IBH_HIP(hipMemcpyAsync(t, set->host.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+        IBH_HIP(hipStreamSynchronize(st));
+    }
+    return t;
+}
+
+void e1ve0_compute(int nsheets, const ibh_weighted *const *XuE1s, const ibh_weighted *const *XuE0s, int64_t nE, ibh_weighted *out) {
+    IBH_CHECK(nsheets >= 1 && XuE1s && XuE0s && out, "bad arguments");
+    IBH_CHECK(nE > 0 && nE < (1ll << 31), "nE=%ld out of range", (long)nE);
+    hipStream_t st = nullptr;
+    Arena &A = arena();
+    A.reset();
+    const int T = 256;
+    double *sE1 = A.get<double>((size_t)nE);
+    IBH_HIP(hipMemsetAsync(sE1, 0, sizeof(double) * (size_t)nE, st));
+    std::vector<std::unique_ptr<ibh_weighted>> locals;
+    for (int s = 0; s < nsheets; ++s) {
+        const ibh_weighted *w1 = XuE1s[s], *w0 = XuE0s[s];
+        IBH_CHECK(w1 && w0, "null matrix for sheet %d", s);
+        IBH_CHECK(w1->dims[1]->sparse_extent <= nE && w0->dims[1]->sparse_extent <= nE, "sheet %d: E extent exceeds nE", s);
+        const int64_t nX = w1->dims[0]->sparse_extent;
+        IBH_CHECK(nX == w0->dims[0]->sparse_extent && nX >= 0 && nX < (1ll << 31), "sheet %d: XuE1 and XuE0 disagree on nX", s);
+        XuEView v[2];
+        const ibh_weighted *ws[2] = {w1, w0};
+        for (int k = 0; k < 2; ++k) {
+            const ibh_weighted *w = ws[k];
+            v[k] = XuEView{w->rowptr.p, w->colind.p, w->val.p, w->wM.p, dims_device_table(w->dims[1], w->ncol, st), nullptr, w->nrow};
+            const bool ident = w->dims[0]->identity && w->dims[0]->n >= w->nrow;
+            if (!ident) {
+                int32_t *rm = A.get<int32_t>((size_t)nX);
+                IBH_HIP(hipMemsetAsync(rm, 0xFF, sizeof(int32_t) * (size_t)nX, st));
+                const int64_t *rs = dims_device_table(w->dims[0], w->nrow, st);
+                if (w->nrow) hipLaunchKernelGGL(k_scatter_rowmap, dim3(ceil_div(w->nrow, T)), dim3(T), 0, st, rs, w->nrow, rm);
+                v[k].rowmap = rm;
+            }
+        }
+        if (w1->ncol) hipLaunchKernelGGL(k_add_by_sparse, dim3(ceil_div(w1->ncol, T)), dim3(T), 0, st, w1->Mw.p, v[0].col_s, w1->ncol, sE1);
+        uint32_t *cnt = A.get<uint32_t>((size_t)nX + 2), *pos = A.get<uint32_t>((size_t)nX + 1);
+        uint32_t *d_total = cnt + nX, *too_long = cnt + nX + 1;
+        IBH_HIP(hipMemsetAsync(cnt + nX, 0, 2 * sizeof(uint32_t), st));
+        const dim3 grid(nX ? ceil_div(nX, T) : 1);
+        hipLaunchKernelGGL(k_e1ve0<0>, grid, dim3(T), 0, st, v[0], v[1], (long)nX, cnt, (const uint32_t *)nullptr, (uint64_t *)nullptr,
+                           (uint32_t *)nullptr, (double *)nullptr, too_long);
+        exclusive_scan_u32(cnt, pos, (size_t)nX, d_total, st);
+        uint32_t h[2];
+        readback_sync(h, d_total, sizeof(h), st);
+        IBH_CHECK(!h[1], "E1vE0: an XuE row has more than %d entries", E1_MAXROW);
+        Triplets t;
+        t.n = h[0];
+        t.keys = A.get<uint64_t>(t.n); t.keys_alt = A.get<uint64_t>(t.n);
+        t.idx = A.get<uint32_t>(t.n); t.idx_alt = A.get<uint32_t>(t.n);
+        t.term = A.get<double>(t.n);
+        if (t.n) hipLaunchKernelGGL(k_e1ve0<1>, grid, dim3(T), 0, st, v[0], v[1], (long)nX, cnt, pos, t.keys, t.idx, t.term, too_long);
+        IBH_HIP(hipGetLastError());
+        std::unique_ptr<ibh_weighted> loc(new ibh_weighted);
+        int32_t *row = nullptr;
+        build_csr_from_contributions(loc.get(), t, (int)nE, (int)nE, &row, st);
+        locals.push_back(std::move(loc));
+    }
+    // scale by 1 / (sum over sheets of Mw(XuE1)), then consolidate across sheets
+    for (auto &loc : locals)
+        hipLaunchKernelGGL(k_scale_rows_inv, dim3(ceil_div(nE, T)), dim3(T), 0, st, loc->rowptr.p, (int)nE, loc->val.p, sE1);
+    IBH_HIP(hipGetLastError());
+    if (locals.size() == 1) {
+        out->rowptr = std::move(locals[0]->rowptr); out->colind = std::move(locals[0]->colind); out->val = std::move(locals[0]->val);
+        out->nnz = locals[0]->nnz;
+    } else {
+        Triplets t;
+        t.n = 0;
+        for (auto &loc : locals) t.n += (size_t)loc->nnz;
+        IBH_CHECK(t.n < (1ul << 31), "E1vE0 too large");
+        t.keys = A.get<uint64_t>(t.n); t.keys_alt = A.get<uint64_t>(t.n);
+        t.idx = A.get<uint32_t>(t.n); t.idx_alt = A.get<uint32_t>(t.n);
+        t.term = A.get<double>(t.n);
+        uint32_t base = 0;
+        for (auto &loc : locals) {          // sheet-major emission order: equal (iE1, iE0) are summed in sheet order
+            hipLaunchKernelGGL(k_csr_to_contrib, dim3(ceil_div(nE, T)), dim3(T), 0, st, loc->rowptr.p, loc->colind.p, loc->val.p, (int)nE,
+                               base, t.keys, t.idx, t.term);
+            base += (uint32_t)loc->nnz;
+        }
+        int32_t *row = nullptr;
+        build_csr_from_contributions(out, t, (int)nE, (int)nE, &row, st);
+    }
+    out->nrow = out->ncol = (int)nE;
+    out->wM.alloc((size_t)nE); out->Mw.alloc((size_t)nE);
+    hipLaunchKernelGGL(k_fill_f64, dim3(ceil_div(nE, T)), dim3(T), 0, st, out->wM.p, (size_t)nE, 1.0);
+    hipLaunchKernelGGL(k_fill_f64, dim3(ceil_div(nE, T)), dim3(T), 0, st, out->Mw.p, (size_t)nE, 1.0);
+    IBH_HIP(hipGetLastError());
+    IBH_HIP(hipStreamSynchronize(st));
+}
+
 }  // namespace ibh

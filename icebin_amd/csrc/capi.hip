@@ -203,6 +203,29 @@ int ibh_sparse_set_add_dense(ibh_sparse_set *s, int64_t sparse, int32_t *dense) 
     });
 }
 
+// ---- exchange-grid generation ----------------------------------------------------------------
+int ibh_exgrid_generate(const ibh_exgrid_desc *d, ibh_exgrid **out) {
+    return guarded([&] {
+        IBH_CHECK(d && out, "null argument");
+        require_device();
+        std::unique_ptr<ibh_exgrid> ex(new ibh_exgrid);
+        exgrid_generate(d, ex.get());
+        *out = ex.release();
+    });
+}
+int ibh_exgrid_size(const ibh_exgrid *ex, int64_t *nX) {
+    return guarded([&] { IBH_CHECK(ex && nX, "null argument"); *nX = ex->nX; });
+}
+int ibh_exgrid_get(const ibh_exgrid *ex, int32_t *indices, double *overlaps) {
+    return guarded([&] {
+        IBH_CHECK(ex && (ex->nX == 0 || (indices && overlaps)), "null argument");
+        if (ex->nX == 0) return;
+        ex->indices.download(indices, 2 * (size_t)ex->nX);
+        ex->overlaps.download(overlaps, (size_t)ex->nX);
+    });
+}
+int ibh_exgrid_destroy(ibh_exgrid *ex) { delete ex; return IBH_OK; }
+
 // ---- Regridder -----------------------------------------------------------------------------
 int ibh_regridder_create(const ibh_regridder_desc *d, ibh_regridder **out) {
     return guarded([&] {
@@ -396,6 +419,19 @@ int ibh_weighted_from_csr(int32_t nrow, int32_t ncol, const int32_t *rowptr, con
         w->colind.upload(colind, (size_t)nnz);
         w->val.upload(val, (size_t)nnz);
         IBH_HIP(hipStreamSynchronize(nullptr));
+        *out = w.release();
+    });
+}
+int ibh_e1ve0_compute(int32_t nsheets, const ibh_weighted *const *XuE1s, const ibh_weighted *const *XuE0s, int64_t nE,
+                      ibh_weighted **out) {
+    return guarded([&] {
+        IBH_CHECK(out && nsheets >= 1 && XuE1s && XuE0s, "bad arguments");
+        require_device();
+        for (int s = 0; s < nsheets; ++s) { check_weighted_device(XuE1s[s]); check_weighted_device(XuE0s[s]); }
+        std::unique_ptr<ibh_weighted> w(new ibh_weighted);
+        IBH_HIP(hipGetDevice(&w->device));
+        for (int k = 0; k < 2; ++k) { w->dims[k] = new ibh_sparse_set; w->owns[k] = true; make_identity(w->dims[k], nE); }
+        e1ve0_compute(nsheets, XuE1s, XuE0s, nE, w.get());
         *out = w.release();
     });
 }

@@ -199,6 +199,12 @@ struct ibh_weighted {
     }
 };
 
+struct ibh_exgrid {
+    int64_t nX = 0;
+    ibh::DevBuf<int32_t> indices;       // [2*nX] interleaved (iA, iI), sorted by (iA, iI)
+    ibh::DevBuf<double> overlaps;       // [nX]
+};
+
 namespace ibh {
 // spmm.hip
 void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda, double *dB, int64_t ldb,

@@ -357,6 +357,19 @@ def coo_multiply(M, xx, fill=np.nan, ignore_nan=False):
     return yy
 
 
+def compute_E1vE0c(XuE1s, XuE0s, nE):
+    """e1ve0::compute_E1vE0c (slib/icebin/e1ve0.cpp:55-106): lists of XvE matrices (unscaled, one per ice sheet) for
+    the new (E1) and the previous (E0) elevation mask -> the correction matrix as a linear_Weighted over the
+    sparse E space; .to_coo() gives the reference's (iE1, iE0, value) tuples, sorted and consolidated."""
+    n = len(XuE1s)
+    assert n == len(XuE0s) and n >= 1
+    a1 = (C.c_void_p * n)(*[w._h.value for w in XuE1s])
+    a0 = (C.c_void_p * n)(*[w._h.value for w in XuE0s])
+    h = C.c_void_p()
+    check(lib().ibh_e1ve0_compute(n, a1, a0, int(nE), C.byref(h)))
+    return linear_Weighted(h)
+
+
 def nc_read_weighted(nc, vname):
     """ibmisc.nc_read_weighted (matrix_formats.rst:139-147)."""
     return linear_Weighted.nc_read(nc, vname)

@@ -112,6 +112,9 @@ def make_grids(config="g5", nhc=40, x_fastest=False, ratio_amp=0.03, order="sort
         A_to_sparse=A_to_sparse, A_native_area=native_area, A_proj_area=proj_area,
         hcdefs=hcdefs, hc_stride_A=1, hc_stride_HC=int(im * jm),   # icebin_cython.cpp:69
         interp_style=0, I_centroid_xy=centroid,
+        # the projected GCM block (for the exchange-grid generator's tests): cell (kx, ky) is
+        # [A_xedges[kx], A_xedges[kx+1]] x [A_yedges[ky], A_yedges[ky+1]], sparse index (j0+ky)*im + (i0+kx)
+        A_xedges=ex, A_yedges=ey, A_i0=int(i0), A_j0=int(j0),
     )
 
 

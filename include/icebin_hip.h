@@ -69,6 +69,29 @@ int ibh_sparse_set_to_dense(const ibh_sparse_set *s, int64_t sparse, int32_t *de
 int ibh_sparse_set_add_dense(ibh_sparse_set *s, int64_t sparse, int32_t *dense);
 
 /* ------------------------------------------------------------------------- */
+/* Exchange-grid generation: make_exchange_grid (slib/icebin/gridgen/GridGen_Exchange.cpp:175-284) for a
+ * rectilinear ice grid in the projected plane (gridgen/searise_grid.cpp) under convex GCM-cell polygons
+ * whose vertices the caller has projected to that plane (OGrid, GridGen_Exchange.cpp:120-166; counter-
+ * clockwise, 3..16 vertices, ascending iA).  Every non-empty overlap becomes one exchange cell
+ * (iA, iI, area) with area = Cell::proj_area of the overlap polygon (Grid.cpp:42-70); cells come out
+ * sorted by (iA, iI) like ExchangeGrid's constructor leaves them (AbbrGrid.cpp:10-21).  The result
+ * stays in HBM; ibh_exgrid_get copies it out (the layout ibh_regridder_desc takes). */
+typedef struct ibh_exgrid_desc {
+    int32_t        nx, ny;          /* ice cells along x and y                                   */
+    const double  *xedges, *yedges; /* [nx+1], [ny+1] cell edges, ascending                      */
+    int32_t        x_fastest;       /* iI = iy*nx + ix when non-zero, else ix*ny + iy            */
+    int32_t        npoly;           /* realised GCM cells                                        */
+    const int32_t *polyptr;         /* [npoly+1] vertex ranges                                   */
+    const double  *vx, *vy;         /* projected vertices                                        */
+    const int64_t *iA;              /* [npoly] sparse atmosphere index, ascending                */
+} ibh_exgrid_desc;
+typedef struct ibh_exgrid ibh_exgrid;
+int ibh_exgrid_generate(const ibh_exgrid_desc *desc, ibh_exgrid **out);
+int ibh_exgrid_size(const ibh_exgrid *ex, int64_t *nX);
+int ibh_exgrid_get(const ibh_exgrid *ex, int32_t *indices /* [2*nX] */, double *overlaps /* [nX] */);
+int ibh_exgrid_destroy(ibh_exgrid *ex);
+
+/* ------------------------------------------------------------------------- */
 /* Regridder: the state of GCMRegridder_Standard (GCMRegridder.hpp:207-302) and
  * one IceRegridder_L0 (IceRegridder.hpp:46-133) that the path reads, uploaded
  * to HBM once.  Replaces GCMRegridder_Standard::init + add_sheet
@@ -150,6 +173,15 @@ int ibh_weighted_from_csr(int32_t nrow, int32_t ncol, const int32_t *rowptr,
                           const double *wM, const double *Mw,
                           int conservative, int scaled, ibh_weighted **out);
 int ibh_weighted_destroy(ibh_weighted *w);
+
+/* compute_E1vE0c (slib/icebin/e1ve0.cpp:55-106): the matrix that carries fields on last step's elevation
+ * grid (E0) to this step's (E1), E1vE0c = diag(1/sum_sheets Mw(XuE1)) * sum_sheets[E1uX * (XvE0 - XvE1)].
+ * XuE1s / XuE0s: one unscaled XvE matrix per ice sheet for the new and the old elevation mask
+ * (IceCoupler.cpp:464-468 builds them; dims[0] over the exchange grid, dims[1] over E).  The result is a
+ * Weighted over the SPARSE E space (identity dims of extent nE, rows iE1, columns iE0, entries sorted
+ * by (iE1, iE0), duplicates summed; wM = Mw = 1): the reference returns the same tuples as a TupleList. */
+int ibh_e1ve0_compute(int32_t nsheets, const ibh_weighted *const *XuE1s, const ibh_weighted *const *XuE0s,
+                      int64_t nE, ibh_weighted **out);
 
 /* Public members of Weighted_Eigen, read back to host. */
 int ibh_weighted_shape(const ibh_weighted *w, int32_t *nrow_d, int32_t *ncol_d, int64_t *nnz);

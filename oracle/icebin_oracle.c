@@ -953,3 +953,96 @@ double orc_time_apply(const orc_weighted *cw, const double *A_b, int nvar, doubl
     free(cut); free(th); free(jobs);
     return dt;
 }
+
+/* ========================================================================= */
+/* E1vE0 (slib/icebin/e1ve0.cpp:55-106 compute_E1vE0c): the matrix that carries fields on the
+ * elevation grid of the previous coupling step (E0) to that of the current one (E1),
+ *     E1vE0c = diag(1 / sum_sheets Mw(XuE1)) * sum_sheets[ E1uX * (XvE0 - XvE1) ],   consolidated.
+ * The reference takes "sparsified" XuE matrices (sparse X and E indices); here the Weighted inputs
+ * are mapped through their dims first.  Output: tuples sorted by (iE1, iE0), duplicates summed. */
+static csc *sparsify_csc(const orc_weighted *w, long nrow_s, long ncol_s, int transpose) {
+    const csc *m = w->M;
+    dtrip t; t.n = m->nnz;
+    t.r = (int *)xmalloc(sizeof(int) * (size_t)(m->nnz ? m->nnz : 1));
+    t.c = (int *)xmalloc(sizeof(int) * (size_t)(m->nnz ? m->nnz : 1));
+    t.v = (double *)xmalloc(sizeof(double) * (size_t)(m->nnz ? m->nnz : 1));
+    long k = 0;
+    for (int j = 0; j < m->ncol; ++j)
+        for (long p = m->colptr[j]; p < m->colptr[j + 1]; ++p, ++k) {
+            int rs = (int)orc_sset_to_sparse(w->dims[0], m->row[p]), cs = (int)orc_sset_to_sparse(w->dims[1], j);
+            t.r[k] = transpose ? cs : rs; t.c[k] = transpose ? rs : cs; t.v[k] = m->val[p];
+        }
+    csc *out = transpose ? to_eigen(&t, (int)ncol_s, (int)nrow_s) : to_eigen(&t, (int)nrow_s, (int)ncol_s);
+    dtrip_free(&t);
+    return out;
+}
+/* Eigen sparse a - b: union of the stored entries per column, rows ascending; a-b where both are
+ * stored, a where only a is, 0-b where only b is */
+static csc *csc_sub(const csc *a, const csc *b) {
+    csc *m = csc_alloc(a->nrow, a->ncol, a->nnz + b->nnz);
+    long n = 0;
+    for (int j = 0; j < a->ncol; ++j) {
+        long p = a->colptr[j], q = b->colptr[j];
+        const long pe = a->colptr[j + 1], qe = b->colptr[j + 1];
+        while (p < pe || q < qe) {
+            if (q >= qe || (p < pe && a->row[p] < b->row[q])) { m->row[n] = a->row[p]; m->val[n] = a->val[p]; ++p; }
+            else if (p >= pe || b->row[q] < a->row[p]) { m->row[n] = b->row[q]; m->val[n] = 0.0 - b->val[q]; ++q; }
+            else { m->row[n] = a->row[p]; m->val[n] = a->val[p] - b->val[q]; ++p; ++q; }
+            ++n;
+        }
+        m->colptr[j + 1] = n;
+    }
+    m->nnz = n;
+    return m;
+}
+typedef struct { long i, j; double v; long seq; } e_tuple;
+static int cmp_tuple(const void *pa, const void *pb) {
+    const e_tuple *a = (const e_tuple *)pa, *b = (const e_tuple *)pb;
+    if (a->i != b->i) return a->i < b->i ? -1 : 1;
+    if (a->j != b->j) return a->j < b->j ? -1 : 1;
+    return a->seq < b->seq ? -1 : a->seq > b->seq;      /* std::sort leaves equal tuples unordered: taken in sheet order */
+}
+long orc_e1ve0c(int nsheets, const orc_weighted *const *XuE1s, const orc_weighted *const *XuE0s, long nE,
+                long **out_i, long **out_j, double **out_v)
+{
+    e_tuple *tl = NULL; long nt = 0, cap = 0;
+    double *sE1 = (double *)xcalloc((size_t)nE, sizeof(double));
+    for (int s = 0; s < nsheets; ++s) {
+        const orc_weighted *XuE1 = XuE1s[s], *XuE0 = XuE0s[s];
+        long nX = orc_sset_sparse_extent(XuE1->dims[0]);
+        /* sXuE0 = 1 / XuE0->wM, sXuE1 = 1 / XuE1->wM  (sparse X indexing) */
+        double *s0 = (double *)xcalloc((size_t)nX, sizeof(double)), *s1 = (double *)xcalloc((size_t)nX, sizeof(double));
+        for (int d = 0; d < XuE0->M->nrow; ++d) s0[orc_sset_to_sparse(XuE0->dims[0], d)] = XuE0->wM[d];
+        for (int d = 0; d < XuE1->M->nrow; ++d) s1[orc_sset_to_sparse(XuE1->dims[0], d)] = XuE1->wM[d];
+        for (long x = 0; x < nX; ++x) { s0[x] = 1. / s0[x]; s1[x] = 1. / s1[x]; }
+        csc *E1uX = sparsify_csc(XuE1, nX, nE, 1);                    /* XuE1->M->transpose() */
+        csc *M1 = sparsify_csc(XuE1, nX, nE, 0), *M0 = sparsify_csc(XuE0, nX, nE, 0);
+        csc *XvE1 = csc_scale_rows(M1, s1), *XvE0 = csc_scale_rows(M0, s0);
+        csc *D = csc_sub(XvE0, XvE1);
+        csc *L = spgemm(E1uX, D);                                     /* E1uX * (XvE0 - XvE1) */
+        for (int j = 0; j < L->ncol; ++j)                             /* spcopy(accum::ref(E1vE0c), local) */
+            for (long p = L->colptr[j]; p < L->colptr[j + 1]; ++p) {
+                if (nt == cap) { cap = cap ? 2 * cap : 1024; tl = (e_tuple *)xrealloc(tl, sizeof(e_tuple) * (size_t)cap); }
+                tl[nt].i = L->row[p]; tl[nt].j = j; tl[nt].v = L->val[p]; tl[nt].seq = nt; ++nt;
+            }
+        for (int d = 0; d < XuE1->M->ncol; ++d) { long e = orc_sset_to_sparse(XuE1->dims[1], d); sE1[e] += XuE1->Mw[d]; }
+        csc_free(E1uX); csc_free(M1); csc_free(M0); csc_free(XvE1); csc_free(XvE0); csc_free(D); csc_free(L);
+        free(s0); free(s1);
+    }
+    for (long e = 0; e < nE; ++e) sE1[e] = 1. / sE1[e];
+    for (long k = 0; k < nt; ++k) tl[k].v *= sE1[tl[k].i];
+    /* consolidate(): sort by index, sum equal indices */
+    qsort(tl, (size_t)nt, sizeof(e_tuple), cmp_tuple);
+    long n = 0;
+    for (long k = 0; k < nt; ++k) {
+        if (n && tl[n - 1].i == tl[k].i && tl[n - 1].j == tl[k].j) tl[n - 1].v += tl[k].v;
+        else tl[n++] = tl[k];
+    }
+    *out_i = (long *)xmalloc(sizeof(long) * (size_t)(n ? n : 1));
+    *out_j = (long *)xmalloc(sizeof(long) * (size_t)(n ? n : 1));
+    *out_v = (double *)xmalloc(sizeof(double) * (size_t)(n ? n : 1));
+    for (long k = 0; k < n; ++k) { (*out_i)[k] = tl[k].i; (*out_j)[k] = tl[k].j; (*out_v)[k] = tl[k].v; }
+    free(tl); free(sE1);
+    return n;
+}
+void orc_free(void *p) { free(p); }

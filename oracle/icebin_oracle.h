@@ -126,6 +126,12 @@ void orc_elevmask_pism(long n, const signed char *mask, const double *thk,
 void orc_coo_matvec(double *yy, const double *xx, int ignore_nan, long nrow, long ncol,
                     long nnz, const int *row, const int *col, const double *data);
 
+/* compute_E1vE0c (slib/icebin/e1ve0.cpp:55-106): returns the number of tuples; arrays are malloc'd
+ * (release with orc_free), sorted by (iE1, iE0) sparse indices. */
+long orc_e1ve0c(int nsheets, const orc_weighted *const *XuE1s, const orc_weighted *const *XuE0s, long nE,
+                long **out_i, long **out_j, double **out_v);
+void orc_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

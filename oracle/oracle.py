@@ -82,6 +82,10 @@ def lib():
         L.orc_elevmask_pism.argtypes = [C.c_long] + [C.c_void_p] * 5
         L.orc_coo_matvec.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_long, C.c_long,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_e1ve0c.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.POINTER(C.POINTER(C.c_long)),
+                                 C.POINTER(C.POINTER(C.c_long)), C.POINTER(C.POINTER(C.c_double))]
+        L.orc_e1ve0c.restype = C.c_long
+        L.orc_free.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -287,3 +291,19 @@ def coo_matvec(M, xx, fill=np.nan, ignore_nan=False):
     dat = np.ascontiguousarray(M.data, np.float64)
     lib().orc_coo_matvec(_p(yy), _p(xx), int(ignore_nan), M.shape[0], M.shape[1], len(dat), _p(row), _p(col), _p(dat))
     return yy
+
+
+def e1ve0c(XuE1s, XuE0s, nE):
+    """compute_E1vE0c (slib/icebin/e1ve0.cpp:55-106): lists of oracle Weighted (one per ice sheet) -> (iE1, iE0, val)
+    sorted by (iE1, iE0), sparse E indices."""
+    n = len(XuE1s)
+    a1 = (C.c_void_p * n)(*[w._h for w in XuE1s])
+    a0 = (C.c_void_p * n)(*[w._h for w in XuE0s])
+    pi, pj, pv = C.POINTER(C.c_long)(), C.POINTER(C.c_long)(), C.POINTER(C.c_double)()
+    cnt = lib().orc_e1ve0c(n, a1, a0, int(nE), C.byref(pi), C.byref(pj), C.byref(pv))
+    i = np.ctypeslib.as_array(pi, shape=(max(cnt, 1),))[:cnt].copy()
+    j = np.ctypeslib.as_array(pj, shape=(max(cnt, 1),))[:cnt].copy()
+    v = np.ctypeslib.as_array(pv, shape=(max(cnt, 1),))[:cnt].copy()
+    for q in (pi, pj, pv):
+        lib().orc_free(q)
+    return i, j, v

@@ -564,6 +564,116 @@ def test_cython_module_icebin_on_gpu(tmp_path):
         mm2.regrid_matrices("antarctica", em)
 
 
+def _clip_numpy(poly, x0, x1, y0, y1):
+    """Independent Sutherland-Hodgman + shoelace in numpy (checker for the device clipper)."""
+    def clip(pts, axis, bound, lower):
+        out = []
+        for k in range(len(pts)):
+            a, b = pts[k], pts[(k + 1) % len(pts)]
+            ina = a[axis] >= bound if lower else a[axis] <= bound
+            inb = b[axis] >= bound if lower else b[axis] <= bound
+            if ina:
+                out.append(a)
+            if ina != inb:
+                t = (bound - a[axis]) / (b[axis] - a[axis])
+                out.append(a + t * (b - a))
+        return out
+    pts = [np.asarray(p, float) for p in poly]
+    for axis, bound, lower in ((0, x0, True), (0, x1, False), (1, y0, True), (1, y1, False)):
+        pts = clip(pts, axis, bound, lower)
+        if len(pts) < 3:
+            return 0.0
+    P = np.array(pts)
+    return 0.5 * float(np.sum(P[:, 0] * np.roll(P[:, 1], -1) - np.roll(P[:, 0], -1) * P[:, 1]))
+
+
+def test_exchange_grid_generation():
+    # make_exchange_grid (gridgen/GridGen_Exchange.cpp:175-284) for the rectilinear case, SURVEY.md 8f rank 4
+    from icebin_amd import gridgen
+    # (1) tests/test_grid.cpp:200-201: unit squares have area 1 -- two unit ice cells under one 2 x 1 GCM cell
+    ex = gridgen.make_exchange_grid([0., 1., 2.], [0., 1.], [[(0, 0), (2, 0), (2, 1), (0, 1)]], [7])
+    assert ex["indices"].tolist() == [[7, 0], [7, 1]] and ex["overlaps"].tolist() == [1.0, 1.0]
+    # (2) the synthetic configurations' exact interval products (icebin_amd/synthetic.py), both index orders
+    for cfg, xf in (("g50", False), ("g20", True), ("g5", False)):
+        g = syn.make_grids(cfg, x_fastest=xf)
+        axe, aye = g["A_xedges"], g["A_yedges"]
+        polys, iA = [], []
+        for ky in range(len(aye) - 1):
+            for kx in range(len(axe) - 1):
+                polys.append([(axe[kx], aye[ky]), (axe[kx + 1], aye[ky]), (axe[kx + 1], aye[ky + 1]), (axe[kx], aye[ky + 1])])
+                iA.append((g["A_j0"] + ky) * g["im"] + g["A_i0"] + kx)
+        order = np.argsort(iA)
+        ex = gridgen.make_exchange_grid(np.arange(g["nx"] + 1) * g["dx"], np.arange(g["ny"] + 1) * g["dx"],
+                                        [polys[k] for k in order], np.asarray(iA)[order], x_fastest=xf)
+        assert np.array_equal(ex["indices"], g["ex_indices"]), cfg
+        assert np.max(np.abs(ex["overlaps"] - g["ex_area"]) / g["ex_area"]) <= 1e-12, cfg
+        # the generated grid drives the regridder to the same matrices (values to rounding: areas differ in the last bit)
+    em = syn.dome_elevmask(g)
+    g2 = dict(g, ex_indices=ex["indices"], ex_area=ex["overlaps"])
+    a = icebin_amd.from_synthetic(g2).regrid_matrices("greenland", em).matrix("AvI")
+    b = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em).matrix("AvI")
+    assert np.array_equal(a.dim(1), b.dim(1)) and np.array_equal(a.coo_dense()[1], b.coo_dense()[1])
+    assert np.max(np.abs(a.coo_dense()[2] - b.coo_dense()[2])) <= 1e-12 * np.max(b.coo_dense()[2])
+    # (3) general convex polygons (a projected lon/lat box is a skewed quadrilateral): against an independent numpy clipper,
+    #     cell by cell, and area conservation -- the overlaps of a polygon inside the domain add up to its area
+    rng = np.random.default_rng(11)
+    xe, ye = np.cumsum(rng.uniform(0.5, 1.5, 41)), np.cumsum(rng.uniform(0.5, 1.5, 31))
+    polys, iA = [], []
+    for k in range(12):
+        c = np.array([rng.uniform(xe[8], xe[-9]), rng.uniform(ye[8], ye[-9])])
+        ang = np.sort(rng.uniform(0, 2 * np.pi, rng.integers(3, 9)))
+        rad = rng.uniform(2.0, 5.0)
+        polys.append(c + rad * np.stack([np.cos(ang), np.sin(ang)], axis=1))       # convex, counter-clockwise
+        iA.append(100 + 3 * k)
+    ex = gridgen.make_exchange_grid(xe, ye, polys, iA)
+    ny = len(ye) - 1
+    assert np.all(np.diff(ex["indices"][:, 0].astype(np.int64) * 10 ** 6 + ex["indices"][:, 1]) > 0)      # sorted by (iA, iI), unique
+    for k, poly in enumerate(polys):
+        sel = ex["indices"][:, 0] == iA[k]
+        P = np.asarray(poly)
+        full = 0.5 * float(np.sum(P[:, 0] * np.roll(P[:, 1], -1) - np.roll(P[:, 0], -1) * P[:, 1]))
+        assert abs(ex["overlaps"][sel].sum() - full) <= 1e-12 * full
+        for iI, a_dev in zip(ex["indices"][sel, 1], ex["overlaps"][sel]):
+            ix, iy = divmod(int(iI), ny)
+            ref = _clip_numpy(poly, xe[ix], xe[ix + 1], ye[iy], ye[iy + 1])
+            assert abs(a_dev - ref) <= 1e-12 * max(ref, 1e-3), (k, iI)
+    # errors: clockwise polygons give no cells (negative areas are not overlaps); unsorted iA is refused
+    assert len(gridgen.make_exchange_grid([0., 1.], [0., 1.], [[(0, 0), (0, 1), (1, 1), (1, 0)]], [0])["overlaps"]) == 0
+    with pytest.raises(icebin_amd.IcebinHipError, match="ascending iA"):
+        gridgen.make_exchange_grid([0., 1.], [0., 1.], [[(0, 0), (1, 0), (1, 1)]] * 2, [5, 5])
+
+
+def test_e1ve0_bit_exact_against_oracle():
+    # compute_E1vE0c (slib/icebin/e1ve0.cpp:55-106) on the device assembly machinery vs the oracle's SpGEMM restatement:
+    # one sheet and two sheets (the second one a different mask pair on the same grids), identity and own X dims
+    g = syn.make_grids("g50")
+    nX, nE = len(g["ex_area"]), g["nA"] * len(g["hcdefs"])
+    em0 = syn.dome_elevmask(g)
+    em1 = np.where(np.isfinite(syn.dome_elevmask(g, frac=0.80)), syn.dome_elevmask(g, frac=0.80) + 35.0, np.nan)
+    em2 = np.where(np.isfinite(em0), em0 * 0.9 + 10.0, np.nan)
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+
+    def pair(em, identity_x):
+        dX = icebin_amd.SparseSet.identity(nX) if identity_x else None
+        w = mm.regrid_matrices("greenland", em, scale=False, correctA=True).matrix_d("XvE", (dX, None), scale=False, correctA=True)
+        oX = orc.SparseSet(nX, init=np.arange(nX)) if identity_x else None
+        o = rg.matrix_d("XvE", em, dims=(oX, None), scale=False, correctA=True)
+        assert_same_weighted(w, o, "XvE")
+        return w, o
+    for identity_x in (True, False):
+        (w1, o1), (w0, o0), (w2, o2) = pair(em1, identity_x), pair(em0, identity_x), pair(em2, identity_x)
+        for ws, os_ in ((([w1], [w0]), ([o1], [o0])), (([w1, w2], [w0, w0]), ([o1, o2], [o0, o0]))):
+            E = icebin_amd.compute_E1vE0c(ws[0], ws[1], nE)
+            i, j, v = orc.e1ve0c(os_[0], os_[1], nE)
+            M = E.to_coo()
+            assert M.shape == (nE, nE) and len(M.data) == len(v)
+            assert np.array_equal(M.row, i) and np.array_equal(M.col, j)
+            assert np.array_equal(M.data.view(np.uint64), v.view(np.uint64)), (identity_x, len(ws[0]))
+    # E1 == E0 -> exact zeros
+    Z = icebin_amd.compute_E1vE0c([w0], [w0], nE).to_coo()
+    assert len(Z.data) > 0 and not np.any(Z.data)
+
+
 def test_coo_multiply_legacy_contract():
     # icebin.coo_multiply(M, x, fill, ignore_nan) (coo_matvec, pylib/icebin_cython.cpp:158-192): rows with no
     # (surviving) entry keep `fill`; NaN inputs are skipped with ignore_nan, propagate without

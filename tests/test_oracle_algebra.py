@@ -206,3 +206,47 @@ def test_force_conservation_branch():
     x = np.array([[2.0, 4.0]])
     assert w.apply(x, force_conservation=False).tolist() == [[1.0, 2.0]]
     assert w.apply(x, force_conservation=True).tolist() == [[2.0, 4.0]]
+
+
+def _xue_pair(config="g50", shift=35.0):
+    """XvE (unscaled, correctA) for an elevation mask and for a slightly grown / raised one."""
+    g = syn.make_grids(config)
+    em0 = syn.dome_elevmask(g)
+    em1 = syn.dome_elevmask(g, frac=0.80)
+    em1 = np.where(np.isfinite(em1), em1 + shift, np.nan)
+    rg = orc.Regridder(g)
+    nX, nE = len(g["ex_area"]), g["nA"] * len(g["hcdefs"])
+    out = []
+    for em in (em1, em0):
+        dimX = orc.SparseSet(nX, init=np.arange(nX))
+        out.append(rg.matrix_d("XvE", em, dims=(dimX, None), scale=False, correctA=True))
+    return g, out[0], out[1], nE
+
+
+def test_e1ve0_against_scipy_and_identity_case():
+    # compute_E1vE0c (slib/icebin/e1ve0.cpp:55-106): E1vE0c = diag(1/Mw1) * XuE1^T * (diag(1/wM0) XuE0 - diag(1/wM1) XuE1)
+    import scipy.sparse as sp
+    g, XuE1, XuE0, nE = _xue_pair()
+    i, j, v = orc.e1ve0c([XuE1], [XuE0], nE)
+    assert len(v) > 0 and np.all(np.diff(i * nE + j) > 0)                 # sorted by (iE1, iE0), consolidated
+    nX = XuE1.sparse_extents[0]
+
+    def sparse_mat(w):
+        return sp.coo_matrix((w.val, (w.dims[0][w.row], w.dims[1][w.col])), shape=(nX, nE)).tocsr()
+    M1, M0 = sparse_mat(XuE1), sparse_mat(XuE0)
+    inv = lambda w, n: sp.diags(1.0 / np.bincount(w.dims[0], w.wM, n).clip(1e-300))   # noqa: E731
+    D = inv(XuE0, nX) @ M0 - inv(XuE1, nX) @ M1
+    Mw1 = np.bincount(XuE1.dims[1], XuE1.Mw, nE)
+    ref = (sp.diags(np.where(Mw1 > 0, 1.0 / np.where(Mw1 > 0, Mw1, 1), 0.0)) @ (M1.T @ D)).tocoo()
+    got = sp.coo_matrix((v, (i, j)), shape=(nE, nE))
+    diff = abs(got.tocsr() - ref.tocsr())
+    assert (diff.max() if diff.nnz else 0.0) <= 1e-12 * np.max(np.abs(ref.data))
+    assert got.nnz >= ref.tocsr().nnz > 1000
+    # where both masks carry ice, (XvE0 - XvE1) 1 = 0: rows of E1vE0c fed only by such exchange cells sum to 0
+    both = np.isin(np.arange(nX), XuE0.dims[0][np.unique(XuE0.row)]) & np.isin(np.arange(nX), XuE1.dims[0][np.unique(XuE1.row)])
+    touched_by_new = np.asarray((M1[~both].T @ np.ones((~both).sum()))).ravel() != 0
+    rs = np.asarray(got.sum(axis=1)).ravel()
+    assert np.max(np.abs(rs[~touched_by_new])) < 1e-12 and np.any(rs[touched_by_new] != 0)
+    # E1 == E0: the correction vanishes identically (stored entries, all exactly zero)
+    i0, j0, v0 = orc.e1ve0c([XuE0], [XuE0], nE)
+    assert len(v0) > 0 and not np.any(v0)
