@@ -19,6 +19,7 @@
 #include "assemble.h"
 #include "prims.h"
 #include <cstdlib>
+#include <mutex>
 
 namespace ibh {
 
@@ -1162,6 +1163,8 @@ static void smooth_matrix(ibh_weighted *w, const ibh_regrid_matrices *rm, const 
     w->conservative = 0;            // conservative = !smooth, RegridMatrices_Dynamic.cpp:167
 }
 
+#include "fastasm.inl"
+
 // ---- RegridMatrices_Dynamic::matrix_d ----------------------------------------------------------
 void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_sparse_set *dim0, ibh_sparse_set *dim1,
                      int scale, int correctA, const double sigma[3], ibh_weighted **out) {
@@ -1196,6 +1199,15 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     auto extent_of = [&](int key) -> int64_t {
         return key == KEY_A ? g->nA : key == KEY_E ? g->nA * (int64_t)g->nhc : key == KEY_I ? g->nI : g->nX;
     };
+    // sorted exchange grid + dims shapes it covers: the plan-based fast path (fastasm.inl); smoothing and the
+    // band structure work on intermediates of the general pipeline
+    const bool bands_wanted = sp->row_key == KEY_E && (sp->col_key == KEY_I || sp->col_key == KEY_X) && get_tuning("assemble_bands", 0);
+    if (!smooth && !bands_wanted && fast_build(rm, sp, dims, scale, correctA, rg, w.get(), st)) {
+        w->built_fast = 1;
+        *out = w.release();
+        return;
+    }
+    A.reset();
     // counters read back with ONE sync: [0] first out-of-range exchange cell, [1] new row keys,
     // [2] new column keys, [3] number of contributions
     // [first(rows) | first(cols) | counters] are one allocation, preset to 0xFF.. with one fill

@@ -615,6 +615,9 @@ int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen) {
         snprintf(buf, (size_t)buflen, "%s", w->last_kernel == 1 ? "rowblock" : w->last_kernel == 2 ? "shortrow" : w->last_kernel == 3 ? "rowdual" : "none");
     });
 }
+int ibh_weighted_built_fast(const ibh_weighted *w, int *out) {
+    return guarded([&] { IBH_CHECK(w && out, "null argument"); *out = w->built_fast; });
+}
 int ibh_selftest_sort(const uint64_t *keys, int64_t n, int lo_bits, int hi_bits, uint32_t *perm_out, int *path_out) {
     return guarded([&] {
         IBH_CHECK(n >= 0 && n < (1ll << 31) && (n == 0 || (keys && perm_out)) && path_out, "bad arguments");

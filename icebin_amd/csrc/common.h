@@ -123,6 +123,9 @@ struct ibh_sparse_set {
     mutable int32_t host_n = 0;
     ibh::DevBuf<int64_t> dev;            // entries [0, dev_n) valid
     int32_t dev_n = 0;
+    ibh::DevBuf<int32_t> tab;            // device sparse -> dense table (-1 missing) of entries [0, tab_n), built on demand
+    int32_t tab_n = -1;
+    int64_t tab_extent = -1;
     mutable std::unordered_map<int64_t, int32_t> inv;    // sparse -> dense of entries [0, inv_n): host-side to_dense / add_dense
     mutable int32_t inv_n = 0;
     void ensure_inverse() const {
@@ -144,8 +147,25 @@ struct ibh_sparse_set {
     }
 };
 
+// Mask-independent structure of one exchange grid (fastasm.inl): built once, on the device, the first
+// time a matrix of this sheet is assembled.  Only for grids sorted by (iA, iI) -- the order
+// ExchangeGrid's constructor leaves them in (AbbrGrid.cpp:10-21).
+struct ibh_plan {
+    bool tried = false, ok = false;
+    int32_t nAr = 0;                     // atmosphere cells with exchange cells ("ranges" of consecutive x)
+    ibh::DevBuf<int32_t> arng;           // [nAr+1] first exchange cell of every range
+    ibh::DevBuf<int32_t> aidx;           // [nX] range of every exchange cell
+    ibh::DevBuf<int32_t> ilptr, ilist;   // [nI+1], [nX] exchange cells of every ice cell, ascending
+    ibh::DevBuf<int32_t> ifirst;         // [nI] first exchange cell of the ice cell with area != 0, -1: none
+    ibh::DevBuf<uint8_t> isdup;          // [nX] bit 0: same (iA, iI) as the cell before; bit 1: every exchange cell of this
+                                         //      cell's ice cell lies in this range (the ice cell straddles no GCM-cell edge)
+    ibh::DevBuf<int32_t> mlist;          // [nmulti] ice cells with exchange cells in more than one range
+    int32_t nmulti = 0;
+};
+
 struct ibh_regridder {
     int device = 0;
+    mutable ibh_plan plan;
     int64_t nX = 0, nI = 0, nA = 0;
     int32_t nA_dense = 0, nhc = 0, interp_style = 0;
     int64_t hc_stride_A = 1, hc_stride_HC = 0;
@@ -177,6 +197,7 @@ struct ibh_weighted {
     ibh_sparse_set *dims[2] = {nullptr, nullptr};
     bool owns[2] = {false, false};
     int conservative = 1, scaled = 1;
+    int built_fast = 0;                 // assembled by the plan-based fast path (fastasm.inl); introspection only
     // SpMM dispatch
     int kernel_override = 0;            // 0 auto, 1 rowblock, 2 shortrow, 3 rowdual
     mutable int last_kernel = 0;

@@ -1,0 +1,762 @@
+// fastasm.inl -- the assembly fast path for SORTED exchange grids (textually included at the end of
+// assemble.hip, inside namespace ibh: it reuses the generators load_cell / contributions of the
+// general pipeline unchanged).
+//
+// ExchangeGrid's constructor sorts the cells by (iA, iI) (AbbrGrid.cpp:10-21), and what a coupler
+// rebuilds every step (IceCoupler.cpp:361-468) depends on the elevation mask only -- the exchange grid
+// is static.  So everything that is mask-independent is computed ONCE per ice sheet (ibh_plan):
+//   * the cells of one atmosphere cell form a contiguous RANGE of exchange cells;
+//   * every ice cell has a (static) list of its <= 8 exchange cells, ascending;
+//   * the position at which an ice cell is first seen (spsparse's first-seen numbering) is static, only
+//     WHETHER it is seen depends on the mask; atmosphere cells are first seen in range order, elevation
+//     classes in first-seen order inside their range (a 64-entry LDS table per range).
+// A build is then a handful of streaming kernels instead of three generator passes + scan + ordering +
+// segment sums + column slots (~45 launches):
+//   numbering  first-occurrence flags (written by k_fa_count) -> scan       (ice / exchange keys; skipped for identity dims)
+//              k_fa_count (one workgroup per range) -> k_fa_rscan    (A / E keys, entry counts)
+//   A/E rows   k_fa_range<EMIT>: every entry is written straight to its CSR slot -- inside a row the
+//              columns first seen in this range ascend in x order (rank = a per-class running count),
+//              only the ice cells that straddle in from an earlier range (a few %) are ranked in LDS --
+//              then sequential row sums, weights and scaling in the same workgroup;
+//              k_fa_pelem<SUMS>: Mw per ice cell from its static list (entries already in row order)
+//   I/X rows   k_fa_pelem<COUNT> -> scan -> k_fa_pelem<EMIT> (one thread per row: <= 8 entries),
+//              k_fa_range<SUMS>: column sums through the same placement, summed sequentially.
+// Every sum runs in the order the general pipeline (and the oracle) uses -- duplicates in emission
+// order with the first term assigned, row sums by ascending column, column sums by ascending row -- so
+// the results are bit-identical; the general pipeline remains the fallback for unsorted grids,
+// partially pre-populated dims, EvA / AvE, and anything a limit below excludes.
+
+constexpr int FA_NC = 64;           // elevation classes per range (nhc <= 64)
+constexpr int FA_ILMAX = 8;         // exchange cells per ice cell
+constexpr int FA_DUPMAX = 4;        // consecutive cells with the same (iA, iI)
+constexpr int FA_OLDMAX = 512;      // straddling entries of one range ranked in LDS
+constexpr int FA_T = 256;
+enum { FA_ERR_OLDOVER = 1, FA_ERR_MISSING = 2 };
+
+struct PlanView {
+    const int32_t *arng, *aidx, *ilptr, *ilist, *ifirst;
+    const uint8_t *isdup;       // bit 0 duplicate of the previous cell, bit 1 the ice cell lives in this range only
+    const int32_t *mlist;       // ice cells spread over several ranges
+    int nAr, nmulti;
+};
+
+// ---- static plan ---------------------------------------------------------------------------------
+__global__ void k_plan_flags(const int32_t *__restrict__ exi, long nX, uint32_t *__restrict__ head, uint8_t *__restrict__ isdup,
+                             uint32_t *__restrict__ bad) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nX) return;
+    const int iA = exi[2 * x], iI = exi[2 * x + 1];
+    bool h = true, d = false;
+    if (x > 0) {
+        const int pA = exi[2 * x - 2], pI = exi[2 * x - 1];
+        h = pA != iA;
+        d = !h && pI == iI;
+        if (iA < pA || (iA == pA && iI < pI)) *bad = 1u;           // not sorted by (iA, iI)
+    }
+    head[x] = h ? 1u : 0u;
+    isdup[x] = d ? 1 : 0;
+}
+__global__ void k_plan_ranges(const uint32_t *__restrict__ head, const uint32_t *__restrict__ hpos, const uint8_t *__restrict__ isdup,
+                              long nX, int32_t *__restrict__ aidx, int32_t *__restrict__ arng, uint32_t nAr, uint32_t *__restrict__ bad) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nX) return;
+    const int r = (int)(hpos[x] + head[x]) - 1;
+    aidx[x] = r;
+    if (head[x]) arng[r] = (int32_t)x;
+    if (x == 0) arng[nAr] = (int32_t)nX;
+    if (x >= FA_DUPMAX - 1) {                                    // FA_DUPMAX-1 duplicates in a row -> a group of FA_DUPMAX is fine, more is not
+        bool all = true;
+        for (int j = 0; j < FA_DUPMAX; ++j) all = all && x - j >= 0 && (isdup[x - j] & 1);
+        if (all) *bad = 1u;
+    }
+}
+__global__ void k_plan_ikeys(const int32_t *__restrict__ exi, long nX, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < nX) { keys[x] = (uint64_t)(uint32_t)exi[2 * x + 1]; vals[x] = (uint32_t)x; }
+}
+__global__ void k_plan_ifirst(const int32_t *__restrict__ ilptr, const int32_t *__restrict__ ilist, const double *__restrict__ area,
+                              const int32_t *__restrict__ aidx, long nI, int32_t *__restrict__ ifirst, uint8_t *__restrict__ isdup,
+                              uint32_t *__restrict__ multi, uint32_t *__restrict__ bad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nI) return;
+    const int b = ilptr[i], e = ilptr[i + 1];
+    if (e - b > FA_ILMAX) *bad = 1u;
+    int f = -1;
+    bool one = true;
+    for (int k = b; k < e; ++k) {
+        if (f < 0 && area[ilist[k]] != 0) f = ilist[k];
+        one = one && aidx[ilist[k]] == aidx[ilist[b]];
+    }
+    ifirst[i] = f;
+    if (one) for (int k = b; k < e; ++k) isdup[ilist[k]] |= 2;     // exchange cells of one ice cell: no two threads share a byte's bits... (own cells only)
+    multi[i] = (e > b && !one) ? 1u : 0u;
+}
+__global__ void k_plan_mlist(const uint32_t *__restrict__ multi, const uint32_t *__restrict__ mpos, long nI, int32_t *__restrict__ mlist) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nI && multi[i]) mlist[mpos[i]] = (int32_t)i;
+}
+__global__ void k_u32_to_i32(const uint32_t *__restrict__ in, long n, int32_t *__restrict__ out) {
+    const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < n) out[u] = (int32_t)in[u];
+}
+
+static bool ensure_plan(const ibh_regridder *g, hipStream_t st) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    ibh_plan &P = g->plan;
+    if (P.tried) return P.ok;
+    P.tried = true;
+    if (g->nX == 0 || g->nhc > FA_NC) return false;
+    Arena &A = arena();
+    A.reset();
+    const long nX = g->nX, nI = g->nI;
+    const int T = 256;
+    uint32_t *head = A.get<uint32_t>((size_t)nX), *hpos = A.get<uint32_t>((size_t)nX), *d_cnt = A.get<uint32_t>(2);
+    IBH_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(uint32_t), st));
+    P.isdup.alloc((size_t)nX);
+    hipLaunchKernelGGL(k_plan_flags, dim3(ceil_div(nX, T)), dim3(T), 0, st, g->ex_indices.p, nX, head, P.isdup.p, d_cnt + 1);
+    exclusive_scan_u32(head, hpos, (size_t)nX, d_cnt, st);
+    uint32_t h[2];
+    readback_sync(h, d_cnt, sizeof(h), st);
+    if (h[1]) return false;                                      // unsorted grid: the general pipeline serves it
+    P.nAr = (int32_t)h[0];
+    P.aidx.alloc((size_t)nX); P.arng.alloc((size_t)P.nAr + 1);
+    hipLaunchKernelGGL(k_plan_ranges, dim3(ceil_div(nX, T)), dim3(T), 0, st, head, hpos, P.isdup.p, nX, P.aidx.p, P.arng.p,
+                       (uint32_t)P.nAr, d_cnt + 1);
+    // exchange cells of every ice cell, ascending: stable sort of x by iI
+    uint64_t *k = A.get<uint64_t>((size_t)nX), *k2 = A.get<uint64_t>((size_t)nX);
+    uint32_t *v = A.get<uint32_t>((size_t)nX), *v2 = A.get<uint32_t>((size_t)nX);
+    hipLaunchKernelGGL(k_plan_ikeys, dim3(ceil_div(nX, T)), dim3(T), 0, st, g->ex_indices.p, nX, k, v);
+    KeyField f{0, bits_for((uint64_t)nI)};
+    if (f.nbits > 0 && radix_sort_pairs(k, k2, v, v2, (size_t)nX, &f, 1, st)) { std::swap(k, k2); std::swap(v, v2); }
+    int32_t *srow = A.get<int32_t>((size_t)nX);
+    hipLaunchKernelGGL(k_keys_to_i32, dim3(ceil_div(nX, T)), dim3(T), 0, st, k, nX, srow);
+    P.ilptr.alloc((size_t)nI + 1); P.ilist.alloc((size_t)nX); P.ifirst.alloc((size_t)nI);
+    rowptr_from_rows(srow, nX, (int)nI, P.ilptr.p, st);
+    hipLaunchKernelGGL(k_u32_to_i32, dim3(ceil_div(nX, T)), dim3(T), 0, st, v, nX, P.ilist.p);
+    uint32_t *multi = A.get<uint32_t>((size_t)nI), *mpos = A.get<uint32_t>((size_t)nI);
+    hipLaunchKernelGGL(k_plan_ifirst, dim3(ceil_div(nI, T)), dim3(T), 0, st, P.ilptr.p, P.ilist.p, g->ex_area.p, P.aidx.p, nI, P.ifirst.p,
+                       P.isdup.p, multi, d_cnt + 1);
+    exclusive_scan_u32(multi, mpos, (size_t)nI, d_cnt, st);
+    IBH_HIP(hipGetLastError());
+    readback_sync(h, d_cnt, sizeof(h), st);
+    if (h[1]) return false;
+    P.nmulti = (int32_t)h[0];
+    P.mlist.alloc((size_t)P.nmulti);
+    if (P.nmulti) hipLaunchKernelGGL(k_plan_mlist, dim3(ceil_div(nI, T)), dim3(T), 0, st, multi, mpos, nI, P.mlist.p);
+    IBH_HIP(hipGetLastError());
+    IBH_HIP(hipStreamSynchronize(st));
+    P.ok = true;
+    return true;
+}
+
+// ---- per-build pieces ----------------------------------------------------------------------------
+// G side: the dims side keyed by atmosphere cells (A) or elevation classes (E) -- numbered per range.
+// P side: the side keyed by ice cells (I) or exchange cells (X) -- numbered along x.
+struct FaG {
+    int key, list;              // KEY_A / KEY_E, LIST_AP / LIST_EP
+    int NC;                     // classes per range: 1 (A) or nhc (E)
+    const int32_t *tab;         // pre-populated set: sparse -> dense (-1 missing); nullptr: numbered by this build
+    int8_t *erank;              // [nAr*NC] first-seen rank of the class inside its range, -1 absent
+    uint32_t *ecntn, *ecnto;    // [nAr*NC] entries of the class in the range whose P key is new / old there
+    uint32_t *r_ncls, *r_nent;  // [nAr]
+    uint32_t *gbase, *ebase;    // [nAr+1] exclusive scans of r_ncls / r_nent
+    int64_t *to_sparse;         // numbered by this build: dense -> sparse
+};
+struct FaP {
+    int key, list;              // KEY_I / KEY_X, LIST_I / LIST_AP / LIST_EP
+    int fresh;                  // 1: numbered by this build, 0: identity over the whole extent
+    uint32_t *pflag, *poff;     // [nX] first-occurrence flags and their exclusive scan: the dense id of a new key is
+                                //      poff[its first-seen position] -- for an ice cell poff[ifirst[iI]], no table needed
+    int64_t *to_sparse;
+};
+__device__ __forceinline__ int fa_class(const RgView &rg, int gkey_kind, long key) {
+    if (gkey_kind != KEY_E) return 0;
+    long a, hc;
+    e_decode(rg, key, a, hc);
+    return (int)hc;
+}
+__device__ __forceinline__ int fa_pdense(const FaP &p, const PlanView &pl, long iI, long x) {
+    if (p.key == KEY_I) return p.fresh ? (int)p.poff[pl.ifirst[iI]] : (int)iI;
+    return p.fresh ? (int)p.poff[x] : (int)x;
+}
+// is the P key of this entry numbered inside range [x0, ...)?  (then its dense ids ascend along x)
+__device__ __forceinline__ bool fa_pnew(const FaP &p, const PlanView &pl, long iI, long x0) {
+    if (p.key != KEY_I || !p.fresh) return true;
+    return pl.ifirst[iI] >= x0;
+}
+
+// Entries of the duplicate group that starts at exchange cell x (cells with the same (iA, iI) follow each
+// other in a sorted grid and contribute to the same matrix entries: summed in x order, first term
+// assigned).  <= 2 entries: the two elevation classes of the ice cell.  X-keyed matrices never merge
+// (every exchange cell is its own key).
+struct GEnt {                     // scalar members on purpose: indexed private arrays live in scratch memory
+    int n, cls0, cls1;
+    long gkey0, gkey1;
+    double t0, t1;
+    __device__ __forceinline__ int cls(int j) const { return j ? cls1 : cls0; }
+    __device__ __forceinline__ long gkey(int j) const { return j ? gkey1 : gkey0; }
+    __device__ __forceinline__ double t(int j) const { return j ? t1 : t0; }
+};
+template <bool WITH_EP>
+__device__ __forceinline__ void fa_group(const RgView &rg, const PlanView &pl, const MatSpec &s, bool g_is_row, bool merge,
+                                         const XCell &c0, long x, GEnt &g) {
+    g.n = 0; g.cls0 = g.cls1 = 0; g.gkey0 = g.gkey1 = 0; g.t0 = g.t1 = 0.0;
+    long xm = x;
+    XCell c = c0;
+    while (true) {
+        if (!(WITH_EP && c.range_error)) {
+            Contrib o;
+            const int n = contributions(c, xm, s, o);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j >= n) break;
+                const long gk = g_is_row ? (j ? o.r1 : o.r0) : (j ? o.c1 : o.c0);
+                const double t = j ? o.t1 : o.t0;
+                const int cls = fa_class(rg, g_is_row ? s.row_key : s.col_key, gk);
+                if (g.n > 0 && g.cls0 == cls) g.t0 = g.t0 + t;
+                else if (g.n > 1 && g.cls1 == cls) g.t1 = g.t1 + t;
+                else if (g.n == 0) { g.cls0 = cls; g.gkey0 = gk; g.t0 = t; g.n = 1; }
+                else if (g.n == 1) { g.cls1 = cls; g.gkey1 = gk; g.t1 = t; g.n = 2; }
+            }
+        }
+        ++xm;
+        if (!merge || xm >= rg.nX || !(pl.isdup[xm] & 1)) break;
+        c = load_cell<WITH_EP>(rg, xm);
+    }
+}
+
+// first-occurrence flag of the P key at exchange cell x (the scan of these flags numbers the P set)
+template <bool WITH_EP>
+__device__ __forceinline__ uint32_t fa_pflag_of(const RgView &rg, const PlanView &pl, const FaP &p, const XCell &c, long x) {
+    if (p.key == KEY_I) return (pl.ifirst[c.iI] == (int32_t)x && c.unmasked) ? 1u : 0u;       // GvI: unmasked, area != 0
+    if (WITH_EP && c.range_error) return 0u;
+    long k0, k1;
+    return list_entries(c, x, p.list, KEY_X, k0, k1) > 0 ? 1u : 0u;
+}
+
+// ---- G-side numbering and entry counts: one workgroup per range -----------------------------------
+template <bool WITH_EP>
+__global__ __launch_bounds__(FA_T) void k_fa_count(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int g_is_row, int merge,
+                                                    uint32_t *__restrict__ err_x, uint32_t *__restrict__ flags) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    __shared__ uint32_t s_first[FA_NC], s_cn[FA_NC], s_co[FA_NC];
+    stage_hc<WITH_EP>(rg, s_hc);
+    const int r = blockIdx.x;
+    const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
+    if (threadIdx.x < FA_NC) { s_first[threadIdx.x] = 0xffffffffu; s_cn[threadIdx.x] = 0; s_co[threadIdx.x] = 0; }
+    __syncthreads();
+    for (long x = x0 + threadIdx.x; x < x1; x += FA_T) {
+        const XCell c = load_cell<WITH_EP>(rg, x);
+        if (p.fresh) p.pflag[x] = fa_pflag_of<WITH_EP>(rg, pl, p, c, x);
+        if (WITH_EP && c.range_error) { atomicMin(err_x, (uint32_t)x); continue; }
+        long k0, k1;
+        const int n = list_entries(c, x, g.list, g.key, k0, k1);        // first-seen positions of the G keys: every cell counts
+        if (n > 0) atomicMin(&s_first[fa_class(rg, g.key, k0)], (uint32_t)(2 * x));
+        if (n > 1) atomicMin(&s_first[fa_class(rg, g.key, k1)], (uint32_t)(2 * x + 1));
+        if (merge && (pl.isdup[x] & 1)) continue;
+        GEnt ge;
+        fa_group<WITH_EP>(rg, pl, s, g_is_row != 0, merge != 0, c, x, ge);
+        const bool isnew = fa_pnew(p, pl, c.iI, x0);
+        if (ge.n > 0) atomicAdd(isnew ? &s_cn[ge.cls0] : &s_co[ge.cls0], 1u);
+        if (ge.n > 1) atomicAdd(isnew ? &s_cn[ge.cls1] : &s_co[ge.cls1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < FA_NC && (int)threadIdx.x < g.NC) {
+        const int k = threadIdx.x;
+        const uint32_t f = s_first[k];
+        int rank = -1;
+        if (f != 0xffffffffu) {
+            rank = 0;
+            for (int q = 0; q < g.NC; ++q) rank += s_first[q] < f ? 1 : 0;
+            if (g.tab) {                                                  // pre-populated set: every key must already be there
+                const long iA = rg.exi[2 * x0];
+                const long key = g.key == KEY_E ? iA * rg.sA + (long)k * rg.sHC : iA;
+                if (g.tab[key] < 0) atomicOr(flags, (uint32_t)FA_ERR_MISSING);
+            }
+        } else if (s_cn[k] + s_co[k]) atomicOr(flags, (uint32_t)FA_ERR_MISSING);    // entries of a class that was never listed: cannot happen
+        g.erank[(size_t)r * g.NC + k] = (int8_t)rank;
+        g.ecntn[(size_t)r * g.NC + k] = s_cn[k];
+        g.ecnto[(size_t)r * g.NC + k] = s_co[k];
+    }
+    if (threadIdx.x == 0) {
+        uint32_t nc = 0, ne = 0, no = 0;
+        for (int k = 0; k < g.NC; ++k) { nc += s_first[k] != 0xffffffffu ? 1u : 0u; ne += s_cn[k] + s_co[k]; no += s_co[k]; }
+        g.r_ncls[r] = nc; g.r_nent[r] = ne;
+        if (no > (uint32_t)FA_OLDMAX) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
+    }
+}
+// exclusive scans over the ranges (one workgroup: there are 10^2..10^5 ranges); tot[0] = classes, tot[1] = entries
+__device__ __forceinline__ uint32_t fa_block_excl_scan_1024(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) wbase += t;
+        tot += t;
+    }
+    total = tot;
+    __syncthreads();
+    return wbase + inc - v;
+}
+__global__ __launch_bounds__(1024) void k_fa_rscan(const uint32_t *__restrict__ ncls, const uint32_t *__restrict__ nent, int nAr,
+                                                    uint32_t *__restrict__ gbase, uint32_t *__restrict__ ebase, uint32_t *__restrict__ tot) {
+    __shared__ uint32_t s_wave[16];
+    for (int ch = 0; ch < 2; ++ch) {
+        const uint32_t *in = ch ? nent : ncls;
+        uint32_t *out = ch ? ebase : gbase;
+        uint32_t carry = 0;
+        for (int base = 0; base < nAr; base += 1024) {
+            const int i = base + threadIdx.x;
+            const uint32_t v = i < nAr ? in[i] : 0u;
+            uint32_t t;
+            const uint32_t ex = fa_block_excl_scan_1024(v, s_wave, t);
+            if (i < nAr) out[i] = carry + ex;
+            carry += t;
+        }
+        if (threadIdx.x == 0) { out[nAr] = carry; tot[ch] = carry; }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ int fa_gdense(const FaG &g, int r, int cls, long gkey) {
+    if (g.tab) return g.tab[gkey];
+    return (int)g.gbase[r] + (int)g.erank[(size_t)r * g.NC + cls];
+}
+
+// ---- one workgroup per range: CSR rows (A/E-row matrices) or column sums (I/X-row matrices) ---------
+// Every entry of the range goes straight to slot ebase[r] + start(class) + position inside the class
+// segment, where the segment lists the entries by ascending P dense id: first the "old" ones (ice cells
+// first seen in an earlier range: smaller ids, ranked in LDS), then the "new" ones in x order (their ids
+// ascend along x).  Then one thread per segment adds it up sequentially -- the order of spsparse sum().
+struct FaOut {
+    int32_t *rowptr, *colind;       // EMIT: CSR of the matrix
+    double *val;                    // EMIT: CSR values; SUMS: scratch of the same size
+    double *wM, *Mw;                // EMIT writes wM (rows = G side), SUMS writes Mw (cols = G side)
+    int family, scale, correctA;
+};
+template <bool WITH_EP, bool EMIT>
+__global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, FaOut o,
+                                                    uint32_t *__restrict__ flags) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    __shared__ int s_rank[FA_NC];
+    __shared__ uint32_t s_start[FA_NC + 1], s_seg[FA_NC], s_nold[FA_NC], s_run[FA_NC], s_wcnt[FA_T / 64][FA_NC];
+    __shared__ double s_mul[FA_NC];
+    __shared__ uint32_t s_no;
+    __shared__ int o_cls[FA_OLDMAX], o_did[FA_OLDMAX];
+    __shared__ double o_t[FA_OLDMAX];
+    stage_hc<WITH_EP>(rg, s_hc);
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
+    const uint32_t eb = g.ebase[r];
+    if (tid < FA_NC) {
+        const bool in = tid < g.NC;
+        const int rank = in ? (int)g.erank[(size_t)r * g.NC + tid] : -1;
+        s_rank[tid] = rank;
+        s_nold[tid] = in ? g.ecnto[(size_t)r * g.NC + tid] : 0;
+        s_run[tid] = 0;
+        s_seg[tid] = 0;
+        if (tid == 0) s_no = 0;
+    }
+    __syncthreads();
+    if (tid < g.NC && s_rank[tid] >= 0) s_seg[s_rank[tid]] = g.ecntn[(size_t)r * g.NC + tid] + g.ecnto[(size_t)r * g.NC + tid];
+    __syncthreads();
+    const int ncls = (int)g.r_ncls[r];
+    if (tid == 0) {
+        uint32_t a = 0;
+        for (int q = 0; q < ncls; ++q) { s_start[q] = a; a += s_seg[q]; }
+        s_start[ncls] = a;
+    }
+    __syncthreads();
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const bool g_is_row = EMIT;
+    for (long cb = x0; cb < x1; cb += FA_T) {
+        const long x = cb + tid;
+        const bool head = x < x1 && !(merge && (pl.isdup[x] & 1));
+        GEnt ge;
+        ge.n = 0;
+        long iI = 0;
+        if (head) {
+            const XCell c = load_cell<WITH_EP>(rg, x);
+            iI = c.iI;
+            if (!(WITH_EP && c.range_error)) fa_group<WITH_EP>(rg, pl, s, g_is_row, merge != 0, c, x, ge);
+        }
+        const bool isnew = head && fa_pnew(p, pl, iI, x0);
+        const int did = ge.n ? fa_pdense(p, pl, iI, x) : 0;
+        if (EMIT) {
+            // dims of a P set numbered by this build: the first-seen cell of every key records dense -> sparse
+            if (x < x1 && p.fresh && p.pflag[x]) p.to_sparse[p.poff[x]] = p.key == KEY_I ? (long)rg.exi[2 * x + 1] : x;
+            // Mw of an ice cell that lives in this range only (and of every exchange cell): its <= 2 entries, in
+            // ascending row order, from zero (spsparse sum()).  Ice cells that straddle ranges: k_fa_pelem<SUMS>.
+            if (ge.n > 0 && (p.key == KEY_X || (pl.isdup[x] & 2))) {
+                double sum = 0.0;
+                if (ge.n == 1) sum = sum + ge.t0;
+                else if (s_rank[ge.cls0] < s_rank[ge.cls1]) { sum = sum + ge.t0; sum = sum + ge.t1; }
+                else { sum = sum + ge.t1; sum = sum + ge.t0; }
+                o.Mw[did] = sum;
+            }
+        }
+        // Rank of a new entry inside its class segment = entries of the same class at smaller x.  A cell holds a
+        // class in at most one of its two slots, so the lanes of a wave are matched on both slots at once
+        // (wave ballots, rs_scatter's scheme); every lane takes part in the ballots.
+        for (int i = tid; i < (FA_T / 64) * FA_NC; i += FA_T) (&s_wcnt[0][0])[i] = 0;
+        __syncthreads();
+        const bool has0 = ge.n > 0, has1 = ge.n > 1;
+        const int c0 = has0 ? ge.cls0 : 0, c1 = has1 ? ge.cls1 : 0;
+        const unsigned long long v0 = __ballot(has0 && isnew), v1 = __ballot(has1 && isnew);
+        unsigned long long pa0 = v0, pb0 = v1, pa1 = v0, pb1 = v1;      // pXj: lanes whose slot X holds the class of MY slot j
+        for (int b = 0; b < 6; ++b) {
+            const unsigned long long m0 = __ballot((c0 >> b) & 1), m1 = __ballot((c1 >> b) & 1);
+            const bool b0 = (c0 >> b) & 1, b1 = (c1 >> b) & 1;
+            pa0 &= b0 ? m0 : ~m0; pb0 &= b0 ? m1 : ~m1;
+            pa1 &= b1 ? m0 : ~m0; pb1 &= b1 ? m1 : ~m1;
+        }
+        const unsigned long long u0 = pa0 | pb0, u1 = pa1 | pb1;
+        const uint32_t in0 = (uint32_t)__popcll(u0 & lt), in1 = (uint32_t)__popcll(u1 & lt);
+        if (has0 && isnew && in0 == 0) s_wcnt[wave][c0] = (uint32_t)__popcll(u0);
+        if (has1 && isnew && in1 == 0) s_wcnt[wave][c1] = (uint32_t)__popcll(u1);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j >= ge.n) break;
+            const int cls = ge.cls(j);
+            if (isnew) {
+                uint32_t before = s_run[cls];
+                for (int w = 0; w < wave; ++w) before += s_wcnt[w][cls];
+                const uint32_t pos = eb + s_start[s_rank[cls]] + s_nold[cls] + before + (j ? in1 : in0);
+                if (EMIT) o.colind[pos] = did;
+                o.val[pos] = ge.t(j);
+            } else {                                       // straddler: ranked after the stream
+                const uint32_t q = atomicAdd(&s_no, 1u);
+                if (q < (uint32_t)FA_OLDMAX) { o_cls[q] = cls; o_did[q] = did; o_t[q] = ge.t(j); }
+            }
+        }
+        __syncthreads();
+        if (tid < FA_NC) {
+            uint32_t a = 0;
+            for (int w = 0; w < FA_T / 64; ++w) a += s_wcnt[w][tid];
+            s_run[tid] += a;
+        }
+        __syncthreads();
+    }
+    const uint32_t no = s_no < (uint32_t)FA_OLDMAX ? s_no : (uint32_t)FA_OLDMAX;
+    if (s_no > (uint32_t)FA_OLDMAX && tid == 0) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
+    for (uint32_t e = tid; e < no; e += FA_T) {            // inside a class the old ids are distinct: rank by counting
+        const int cls = o_cls[e], did = o_did[e];
+        uint32_t cnt = 0;
+        for (uint32_t q = 0; q < no; ++q) cnt += (o_cls[q] == cls && o_did[q] < did) ? 1u : 0u;
+        const uint32_t pos = eb + s_start[s_rank[cls]] + cnt;
+        if (EMIT) o.colind[pos] = did;
+        o.val[pos] = o_t[e];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // Sequential sums (the order of spsparse sum()), one WAVE per segment: 64 values are loaded coalesced and the
+    // chain is replayed from registers with v_readlane (every lane computes the identical sum), as k_seg_sums_wave
+    // does; then the weights (k_weights) and, for the rows, the scaling.
+    for (int q = wave; q < ncls; q += FA_T / 64) {
+        const uint32_t b = eb + s_start[q], e = eb + s_start[q + 1];
+        double sum = 0.0;
+        for (uint32_t base = b; base < e; base += 64) {
+            const uint32_t k = base + lane;
+            const double v = k < e ? o.val[k] : 0.0;
+            const int cnt = (int)min(64u, e - base);
+            const int lo = __double2loint(v), hi = __double2hiint(v);
+            if (cnt == 64) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j)
+                    sum = sum + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+            } else {
+                for (int j = 0; j < cnt; ++j)
+                    sum = sum + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+            }
+        }
+        if (lane == 0) {
+            int cls = 0;
+            for (int k = 0; k < g.NC; ++k) cls = s_rank[k] == q ? k : cls;
+            const long iA = rg.exi[2 * x0];
+            const long gkey = g.key == KEY_E ? iA * rg.sA + (long)cls * rg.sHC : iA;
+            const int gd = fa_gdense(g, r, cls, gkey);
+            if (g.to_sparse) g.to_sparse[gd] = gkey;            // a set numbered by this build: dense -> sparse
+            if (EMIT) {                                        // FAM_AEVI rows (RegridMatrices_Dynamic.cpp:100-146)
+                double wM, mul = 1.0;
+                if (o.correctA) {
+                    const double rr = ratio_of(rg, g.key, gkey);
+                    wM = rr * sum;
+                    if (o.scale) mul = (1.0 / rr) * (1.0 / sum);
+                } else {
+                    wM = sum;
+                    if (o.scale) mul = 1.0 / sum;
+                }
+                o.wM[gd] = wM;
+                o.rowptr[gd] = (int32_t)b;
+                s_mul[q] = mul;
+            } else {                                           // FAM_IVAE columns (:201-233)
+                double Mw = sum;
+                if (o.correctA) Mw = ratio_of(rg, g.key, gkey) * sum;
+                o.Mw[gd] = Mw;
+            }
+        }
+    }
+    if (EMIT && r == pl.nAr - 1 && tid == 0) o.rowptr[g.gbase[pl.nAr]] = (int32_t)g.ebase[pl.nAr];      // rowptr[nrow] = nnz
+    if (EMIT && o.scale) {
+        __syncthreads();
+        for (int q = 0; q < ncls; ++q) {
+            const double mul = s_mul[q];
+            for (uint32_t k = eb + s_start[q] + tid; k < eb + s_start[q + 1]; k += FA_T) o.val[k] = mul * o.val[k];
+        }
+    }
+}
+
+// ---- one thread per P element (ice cell or exchange cell): its <= 8 entries --------------------------
+enum { FA_PSUMS = 0, FA_PCOUNT = 1, FA_PEMIT = 2 };
+template <bool WITH_EP, int MODE>
+__global__ __launch_bounds__(FA_T) void k_fa_pelem(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, long np, FaOut o,
+                                                    uint32_t *__restrict__ rowlen, uint32_t *__restrict__ flags) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    stage_hc<WITH_EP>(rg, s_hc);
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= np) return;
+    if (MODE == FA_PSUMS) q = pl.mlist[q];                    // only the ice cells spread over several ranges (the others: k_fa_range)
+    // dense id of this element, -1: not a member of the set
+    int d = -1;
+    int lb = 0, le = 0;
+    long pkey = q;
+    if (p.key == KEY_I) {
+        const double e = rg.em[q];
+        const bool masked = e != e;
+        if (masked && p.fresh) return;                      // not a member of the set: nothing to write
+        const int f = pl.ifirst[q];
+        if (!p.fresh) d = (int)q;
+        else if (f >= 0) d = (int)p.poff[f];
+        if (!masked) { lb = pl.ilptr[q]; le = pl.ilptr[q + 1]; }      // a masked cell has no entries (identity dims: an empty row / column)
+    } else {
+        d = p.fresh ? (p.pflag[q] ? (int)p.poff[q] : -1) : (int)q;
+        le = 1;
+    }
+    if (d < 0) return;
+    (void)flags;
+    const bool g_is_row = MODE == FA_PSUMS;                  // SUMS: the matrix has G rows (AEvI); COUNT / EMIT: G columns (IvAE)
+    // The element's entries are visited group by group (ascending x = ascending range = ascending G dense id when
+    // the G set was numbered by this build; inside a group the two classes go by their rank).  No private arrays:
+    // the cells are simply re-evaluated by every pass (they are in cache).
+    //   pass(emit_at): emit_at < 0 -> returns count / sum / sortedness; >= 0 -> calls the writer for every entry
+    int ne = 0;
+    double sum = 0.0;
+    bool sorted = true;
+    int prev = -1;
+    auto visit = [&](auto &&fn) {
+        for (int k = lb; k < le; ++k) {
+            const long x = p.key == KEY_I ? (long)pl.ilist[k] : q;
+            if (merge && (pl.isdup[x] & 1)) continue;
+            const XCell c = load_cell<WITH_EP>(rg, x);
+            if (WITH_EP && c.range_error) continue;
+            GEnt ge;
+            fa_group<WITH_EP>(rg, pl, s, g_is_row, merge != 0, c, x, ge);
+            if (ge.n == 0) continue;
+            const int r = pl.aidx[x];
+            const int id0 = MODE == FA_PCOUNT ? 0 : fa_gdense(g, r, ge.cls0, ge.gkey0);
+            const int id1 = (MODE == FA_PCOUNT || ge.n < 2) ? 0 : fa_gdense(g, r, ge.cls1, ge.gkey1);
+            if (ge.n == 1) fn(id0, ge.t0, c.iA);
+            else if (id0 <= id1) { fn(id0, ge.t0, c.iA); fn(id1, ge.t1, c.iA); }
+            else { fn(id1, ge.t1, c.iA); fn(id0, ge.t0, c.iA); }
+        }
+    };
+    visit([&](int id, double t, long) { ++ne; sum = sum + t; sorted = sorted && id >= prev; prev = id; });
+    if (MODE == FA_PCOUNT) { rowlen[d] = (uint32_t)ne; return; }
+    if (MODE == FA_PSUMS) { o.Mw[d] = sum; return; }          // FAM_AEVI: Mw = colsum (:100); G numbered by this build: in order
+    // FAM_IVAE rows: wM = rowsum, M = [1/wM] * T [* sApvA]
+    if (p.fresh) p.to_sparse[d] = pkey;
+    const int b0 = o.rowptr[d];
+    auto finish = [&](double t, long iA) {
+        double v = t;
+        if (o.scale) v = (1.0 / sum) * v;
+        if (o.correctA) v = v * rg.ratioA[iA];
+        return v;
+    };
+    if (sorted) {
+        o.wM[d] = sum;
+        int a = 0;
+        visit([&](int id, double t, long iA) { o.colind[b0 + a] = id; o.val[b0 + a] = finish(t, iA); ++a; });
+    } else {
+        // a pre-populated G set numbers the columns in some other order: ascending column by repeated selection, the
+        // row sum taken in that order (spsparse sum() walks the row by ascending column)
+        double rs = 0.0;
+        int last = -1;
+        for (int a = 0; a < ne; ++a) {
+            int best = 0x7fffffff; double bt = 0.0;
+            visit([&](int id, double t, long) { if (id > last && id < best) { best = id; bt = t; } });
+            rs = rs + bt;
+            last = best;
+        }
+        sum = rs;
+        o.wM[d] = sum;
+        last = -1;
+        for (int a = 0; a < ne; ++a) {
+            int best = 0x7fffffff; double bt = 0.0; long ba = 0;
+            visit([&](int id, double t, long iA) { if (id > last && id < best) { best = id; bt = t; ba = iA; } });
+            o.colind[b0 + a] = best; o.val[b0 + a] = finish(bt, ba);
+            last = best;
+        }
+    }
+}
+__global__ void k_fa_zero_identity(double *__restrict__ w, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = 0.0;
+}
+
+// ---- host side --------------------------------------------------------------------------------------
+// Which dims shapes the fast path serves: a G set (A / E) that is fresh or -- E columns only -- pre-populated
+// (the coupler's shared dimE); a P set (I / X) that is fresh or the identity over the whole extent.
+static int fa_pset_mode(const ibh_sparse_set *set, int64_t extent) {       // 1 fresh, 0 identity-complete, -1 unsupported
+    if (set->n == 0) return 1;
+    if (set->identity && set->n == extent) return 0;
+    return -1;
+}
+
+// sparse -> dense table of a pre-populated set on the device, cached in the set (valid while the set has not grown)
+static const int32_t *set_inverse_table(ibh_sparse_set *set, int64_t extent, hipStream_t st) {
+    if (set->tab_n == set->n && set->tab_extent == extent && set->tab.p) return set->tab.p;
+    const int T = 256;
+    set->tab.alloc((size_t)extent);
+    if (set->dev_n < set->n) {                                  // complete the device copy of the dense -> sparse table first
+        set->ensure_host();
+        DevBuf<int64_t> grown((size_t)set->n);
+        IBH_HIP(hipMemcpyAsync(grown.p, set->host.data(), sizeof(int64_t) * (size_t)set->n, hipMemcpyHostToDevice, st));
+        IBH_HIP(hipStreamSynchronize(st));
+        set->dev = std::move(grown);
+        set->dev_n = set->n;
+    }
+    hipLaunchKernelGGL(k_fill_i32, dim3(ceil_div(extent, T)), dim3(T), 0, st, set->tab.p, (size_t)extent, -1);
+    hipLaunchKernelGGL(k_scatter_existing, dim3(ceil_div(set->n, T)), dim3(T), 0, st, set->tab.p, set->dev.p, set->n);
+    set->tab_n = set->n; set->tab_extent = extent;
+    return set->tab.p;
+}
+__global__ void k_fa_init(uint32_t *cnt) {
+    if (threadIdx.x < 8) cnt[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
+}
+
+// returns false when the fast path does not apply (nothing has been touched: the caller runs the general pipeline)
+static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
+                       const RgView &rg, ibh_weighted *w, hipStream_t st) {
+    const ibh_regridder *gr = rm->rg;
+    if (!get_tuning("assemble_fast", 1) || sp->family == FAM_EVA) return false;
+    if (!ensure_plan(gr, st)) return false;
+    const bool g_is_row = sp->family == FAM_AEVI;
+    ibh_sparse_set *gset = dims[g_is_row ? 0 : 1], *pset = dims[g_is_row ? 1 : 0];
+    const int gkey = g_is_row ? sp->row_key : sp->col_key, glist = g_is_row ? sp->row_list : sp->col_list;
+    const int pkey = g_is_row ? sp->col_key : sp->row_key, plist = g_is_row ? sp->col_list : sp->row_list;
+    auto extent_of = [&](int key) -> int64_t {
+        return key == KEY_A ? gr->nA : key == KEY_E ? gr->nA * (int64_t)gr->nhc : key == KEY_I ? gr->nI : gr->nX;
+    };
+    const int pmode = fa_pset_mode(pset, extent_of(pkey));
+    if (pmode < 0) return false;
+    const bool g_fresh = gset->n == 0;
+    if (!g_fresh && (gset->identity || gkey != KEY_E || g_is_row)) return false;      // pre-populated: E columns only
+    const bool uses_ep = sp->row_list == LIST_EP || sp->col_list == LIST_EP;
+    const int merge = (sp->row_key != KEY_X && sp->col_key != KEY_X) ? 1 : 0;
+
+    Arena &A = arena();
+    A.reset();
+    const ibh_plan &P = gr->plan;
+    PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti};
+    const long nX = gr->nX;
+    const int T = FA_T, nAr = P.nAr;
+    FaG g{};
+    g.key = gkey; g.list = glist; g.NC = gkey == KEY_E ? gr->nhc : 1;
+    const size_t nrc = (size_t)nAr * g.NC;
+    g.erank = A.get<int8_t>(nrc); g.ecntn = A.get<uint32_t>(nrc); g.ecnto = A.get<uint32_t>(nrc);
+    g.r_ncls = A.get<uint32_t>((size_t)nAr); g.r_nent = A.get<uint32_t>((size_t)nAr);
+    g.gbase = A.get<uint32_t>((size_t)nAr + 1); g.ebase = A.get<uint32_t>((size_t)nAr + 1);
+    const int64_t gext = extent_of(gkey);
+    if (!g_fresh) g.tab = set_inverse_table(gset, gext, st);
+    FaP p{};
+    p.key = pkey; p.list = plist; p.fresh = pmode;
+    // counters read back with one sync: [0] first out-of-range cell, [1] fallback flags, [2] new P keys, [3] G classes, [4] entries
+    uint32_t *d_cnt = A.get<uint32_t>(8);
+    hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
+    if (p.fresh) { p.pflag = A.get<uint32_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
+    if (uses_ep) hipLaunchKernelGGL(k_fa_count<true>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1);
+    else hipLaunchKernelGGL(k_fa_count<false>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1);
+    if (p.fresh) exclusive_scan_u32(p.pflag, p.poff, (size_t)nX, d_cnt + 2, st);
+    if (nAr > 4096) {                                           // many ranges: the device-wide scan; few: one workgroup, one launch
+        exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
+        exclusive_scan_u32(g.r_nent, g.ebase, (size_t)nAr, g.ebase + nAr, st);
+        IBH_HIP(hipMemcpyAsync(d_cnt + 3, g.gbase + nAr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        IBH_HIP(hipMemcpyAsync(d_cnt + 4, g.ebase + nAr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(k_fa_rscan, dim3(1), dim3(1024), 0, st, g.r_ncls, g.r_nent, nAr, g.gbase, g.ebase, d_cnt + 3);
+    }
+    IBH_HIP(hipGetLastError());
+    uint32_t h[8];
+    readback_sync(h, d_cnt, sizeof(h), st);
+    if (h[0] != 0xffffffffu) {                                  // message of linterp_1d_b, IceRegridder_L0.cpp:84-85
+        int32_t ij[2];
+        IBH_HIP(hipMemcpy(ij, gr->ex_indices.p + 2 * (size_t)h[0], sizeof(ij), hipMemcpyDeviceToHost));
+        double e = 0;
+        IBH_HIP(hipMemcpy(&e, rm->elevmaskI.p + ij[1], sizeof(double), hipMemcpyDeviceToHost));
+        fail(IBH_ERANGE, "Elevation %g out of bounds (%g, %g)", e < 0 ? 0.0 : e, gr->hcdefs_h.front(), gr->hcdefs_h.back());
+    }
+    if (h[1]) return false;                                     // a limit of the fast path was hit: general pipeline
+    const uint32_t n_pnew = h[2], n_g = h[3], nnz = h[4];
+    IBH_CHECK(nnz < (1u << 31) && n_pnew < (1u << 31), "matrix too large for int32 indices");
+    const int np_d = p.fresh ? (int)n_pnew : (int)extent_of(pkey);
+    const int ng_d = g_fresh ? (int)n_g : gset->n;
+    // dims tables of the sets numbered by this build are written straight into the sets' device buffers
+    DevBuf<int64_t> ptable, gtable;
+    if (p.fresh) { ptable.alloc((size_t)np_d); p.to_sparse = ptable.p; }
+    if (g_fresh) { gtable.alloc((size_t)ng_d); g.to_sparse = gtable.p; }
+    const int nrow = g_is_row ? ng_d : np_d, ncol = g_is_row ? np_d : ng_d;
+    w->nrow = nrow; w->ncol = ncol; w->nnz = nnz;
+    w->rowptr.alloc((size_t)nrow + 1); w->colind.alloc(nnz); w->val.alloc(nnz);
+    w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
+    FaOut o{w->rowptr.p, w->colind.p, w->val.p, w->wM.p, w->Mw.p, sp->family, scale, correctA};
+    uint32_t *flags = d_cnt + 1;
+    const long np_s = p.key == KEY_I ? gr->nI : nX;             // P elements by sparse index
+    const dim3 gp(ceil_div(np_s, T));
+    if (g_is_row) {
+        // rows = G: CSR + wM + (most of) Mw from the ranges; members of the P set without entries keep Mw = 0
+        if (ncol) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
+        if (uses_ep) hipLaunchKernelGGL((k_fa_range<true, true>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, o, flags);
+        else hipLaunchKernelGGL((k_fa_range<false, true>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, o, flags);
+        if (p.key == KEY_I && P.nmulti) {                     // Mw of the ice cells that straddle ranges (a few %)
+            const dim3 gm(ceil_div(P.nmulti, T));
+            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags);
+            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags);
+        }
+    } else {
+        // rows = P: count -> scan -> emit per element; Mw (G columns) from the ranges through a scratch copy of the terms
+        uint32_t *rowlen = A.get<uint32_t>((size_t)nrow + 1);
+        if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PCOUNT>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+        else hipLaunchKernelGGL((k_fa_pelem<false, FA_PCOUNT>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+        exclusive_scan_u32(rowlen, reinterpret_cast<uint32_t *>(w->rowptr.p), (size_t)nrow, reinterpret_cast<uint32_t *>(w->rowptr.p) + nrow, st);
+        if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+        else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+        FaOut os = o;
+        os.val = A.get<double>(nnz);
+        if (!g_fresh && ncol) hipLaunchKernelGGL(k_fa_zero_identity, dim3(ceil_div(ncol, T)), dim3(T), 0, st, w->Mw.p, (long)ncol);   // columns of the shared set this mask does not touch
+        if (uses_ep) hipLaunchKernelGGL((k_fa_range<true, false>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, os, flags);
+        else hipLaunchKernelGGL((k_fa_range<false, false>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, os, flags);
+    }
+    IBH_HIP(hipGetLastError());
+    auto commit = [&](ibh_sparse_set *set, int64_t extent, DevBuf<int64_t> &table, int n) {
+        set->sparse_extent = extent;
+        if (n == 0) return;
+        set->host.clear(); set->host_n = 0; set->inv.clear(); set->inv_n = 0;
+        set->dev = std::move(table);
+        set->dev_n = set->n = n;
+        set->identity = false;
+    };
+    if (p.fresh) commit(pset, extent_of(pkey), ptable, np_d); else pset->sparse_extent = extent_of(pkey);
+    if (g_fresh) commit(gset, gext, gtable, ng_d); else gset->sparse_extent = gext;
+    IBH_HIP(hipStreamSynchronize(st));
+    return true;
+}

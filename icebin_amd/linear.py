@@ -328,6 +328,12 @@ class linear_Weighted:
     def set_kernel(self, name):
         check(lib().ibh_weighted_set_kernel(self._h, name.encode()))
 
+    def built_fast(self):
+        """True when the plan-based fast assembly path built this matrix (sorted exchange grids)."""
+        v = C.c_int()
+        check(lib().ibh_weighted_built_fast(self._h, C.byref(v)))
+        return bool(v.value)
+
     def last_kernel(self):
         buf = C.create_string_buffer(32)
         check(lib().ibh_weighted_last_kernel(self._h, buf, 32))

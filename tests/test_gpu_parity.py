@@ -68,6 +68,50 @@ def test_assembly_bit_exact_all_matrices(variant):
                 assert_same_weighted(w, o, "%s scale=%d correctA=%d %s" % (name, scale, correctA, variant))
 
 
+@pytest.mark.parametrize("config", ["g50", "g20"])
+def test_fast_and_general_assembly_paths_agree_with_the_oracle(config):
+    # sorted exchange grids take the plan-based fast path (fastasm.inl) for the A/E-row and I/X-row families; the
+    # general pipeline (forced with assemble_fast=0) must give the same bits.  Own dims, identity I / X dims, and the
+    # coupler's shared dimE (IceCoupler.cpp:361-468).
+    g, em, mm, rg = setup(config)
+    nI, nX, nE = g["nI"], len(g["ex_area"]), g["nA"] * len(g["hcdefs"])
+    try:
+        for fast in (1, 0):
+            icebin_amd.set_tuning("assemble_fast", fast)
+            for scale, correctA in ((True, True), (False, False), (True, False), (False, True)):
+                rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
+                for name in ALL:
+                    w = rm.matrix(name)
+                    assert w.built_fast() == (bool(fast) and name not in ("EvA", "AvE")), (name, fast)
+                    assert_same_weighted(w, rg.matrix_d(name, em, scale=scale, correctA=correctA), "%s fast=%d" % (name, fast))
+            # the coupler's step: EvI / AvI with identity dimI, then IvE / XvE on the dimE that EvI numbered
+            rm = mm.regrid_matrices("greenland", em)
+            dimI, dimX, dimE = icebin_amd.SparseSet.identity(nI), icebin_amd.SparseSet.identity(nX), icebin_amd.SparseSet(nE)
+            oI, oX, oE = orc.SparseSet(nI, init=np.arange(nI)), orc.SparseSet(nX, init=np.arange(nX)), orc.SparseSet(nE)
+            for name, dims, odims, sc, cA in (("EvI", (dimE, dimI), (oE, oI), False, False), ("AvI", (None, dimI), (None, oI), False, True),
+                                              ("IvE", (dimI, dimE), (oI, oE), True, True), ("XvE", (dimX, dimE), (oX, oE), False, True)):
+                w = rm.matrix_d(name, dims, scale=sc, correctA=cA)
+                assert w.built_fast() == bool(fast), (name, fast)
+                assert_same_weighted(w, rg.matrix_d(name, em, dims=odims, scale=sc, correctA=cA), "coupler %s fast=%d" % (name, fast))
+            # a shared dimE that numbers the classes in some OTHER order (and holds keys this mask never touches): the
+            # rows' columns are no longer ascending in visiting order -> the per-row selection branch of the fast path
+            E_keys = dimE.to_sparse()
+            extra = np.setdiff1d(np.arange(nE), E_keys)[:7]
+            perm = np.random.default_rng(5).permutation(np.concatenate([E_keys, extra]))
+            for name, rowset, orow in (("IvE", dimI, oI), ("XvE", dimX, oX)):
+                dE2, oE2 = icebin_amd.SparseSet(nE, perm), orc.SparseSet(nE, init=perm)
+                w = rm.matrix_d(name, (rowset, dE2), scale=True, correctA=True)
+                assert w.built_fast() == bool(fast)
+                assert_same_weighted(w, rg.matrix_d(name, em, dims=(orow, oE2), scale=True, correctA=True), "permuted dimE %s fast=%d" % (name, fast))
+            # ... and one that lacks a key: the fast path hands over to the general pipeline, which appends it
+            dE3, oE3 = icebin_amd.SparseSet(nE, E_keys[:-3]), orc.SparseSet(nE, init=E_keys[:-3])
+            w = rm.matrix_d("IvE", (dimI, dE3), scale=True, correctA=True)
+            assert not w.built_fast() and dE3.dense_extent() == len(E_keys)
+            assert_same_weighted(w, rg.matrix_d("IvE", em, dims=(oI, oE3), scale=True, correctA=True), "incomplete dimE")
+    finally:
+        icebin_amd.set_tuning("assemble_fast", 1)
+
+
 def test_config1_real_mask_bit_exact(elev_mask_g20):
     # BASELINE config 1: 20 km Greenland, the reference's own PISM mask fixture, all six matrices
     g = syn.make_grids("g20")
