@@ -68,6 +68,8 @@ _SIGS = {
     "ibh_regrid_matrices_destroy": (C.c_int, [C.c_void_p]),
     "ibh_regrid_matrices_matrix_d": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                               C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ibh_regrid_matrices_matrix_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "ibh_regrid_matrices_matrix": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "ibh_weighted_from_coo": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

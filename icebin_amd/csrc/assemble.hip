@@ -18,8 +18,12 @@
 // CSR structure, dims, wM, Mw and M are bit-identical to the oracle.
 #include "assemble.h"
 #include "prims.h"
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
+#include <functional>
 #include <mutex>
+#include <thread>
 
 namespace ibh {
 
@@ -96,13 +100,13 @@ __device__ __forceinline__ void stage_hc(RgView &rg, double *s_hc) {
         rg.hc = s_hc;
     }
 }
+// the arithmetic of a cell from its four inputs (callers that stage the loads of several cells themselves use this form)
 template <bool WITH_EP>
-__device__ __forceinline__ XCell load_cell(const RgView &rg, long x) {
+__device__ __forceinline__ XCell make_cell(const RgView &rg, long iA, long iI, double a, double e) {
     XCell c;
-    c.iA = rg.exi[2 * x];
-    c.iI = rg.exi[2 * x + 1];
-    c.a = rg.area[x];
-    const double e = rg.em[c.iI];
+    c.iA = iA;
+    c.iI = iI;
+    c.a = a;
     c.unmasked = !(e != e);                       // !std::isnan, IceRegridder_L0.cpp:121,186,208
     c.inAp = c.unmasked && c.a > 0;               // :208-209
     c.inI = c.unmasked && c.a != 0;               // :186-187 (+ include_zero=false)
@@ -148,6 +152,11 @@ __device__ __forceinline__ XCell load_cell(const RgView &rg, long x) {
         else if (c.nep == 2) c.rsE = c.vE0 + c.vE1;
     }
     return c;
+}
+template <bool WITH_EP>
+__device__ __forceinline__ XCell load_cell(const RgView &rg, long x) {
+    const long iA = rg.exi[2 * x], iI = rg.exi[2 * x + 1];
+    return make_cell<WITH_EP>(rg, iA, iI, rg.area[x], rg.em[iI]);
 }
 
 // entries of `list` at cell c: count and sparse keys of kind `key`
@@ -1166,12 +1175,18 @@ static void smooth_matrix(ibh_weighted *w, const ibh_regrid_matrices *rm, const 
 #include "fastasm.inl"
 
 // ---- RegridMatrices_Dynamic::matrix_d ----------------------------------------------------------
-void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_sparse_set *dim0, ibh_sparse_set *dim1,
-                     int scale, int correctA, const double sigma[3], ibh_weighted **out) {
-    IBH_CHECK(rm && spec_name && out, "null argument");
+static const MatSpec *find_spec(const char *spec_name) {
     const MatSpec *sp = nullptr;
     for (const auto &s : SPECS) if (!strcmp(s.name, spec_name)) sp = &s;
     if (!sp) fail(IBH_ENOKEY, "unknown regrid matrix '%s' (expected one of AvI IvA AvX XvA EvI IvE EvX XvE EvA AvE)", spec_name);
+    return sp;
+}
+// fast_only: build through the plan-based fast path or not at all (returns false, nothing touched) -- the mode of the
+// concurrent builds of a batch, which must not append to a set another build of the same wave is reading
+bool assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_sparse_set *dim0, ibh_sparse_set *dim1,
+                     int scale, int correctA, const double sigma[3], ibh_weighted **out, bool fast_only) {
+    IBH_CHECK(rm && spec_name && out, "null argument");
+    const MatSpec *sp = find_spec(spec_name);
     // RegridParams::smooth() (RegridMatrices.hpp:31): only compute_IvAE smooths (RegridMatrices_Dynamic.cpp:237-248)
     const bool smooth = sigma && sigma[0] != 0 && sp->family == FAM_IVAE;
     if (smooth && sp->row_key != KEY_I)
@@ -1179,7 +1194,8 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     const ibh_regridder *g = rm->rg;
     const bool uses_ep = sp->row_list == LIST_EP || sp->col_list == LIST_EP;
     if (uses_ep && g->nhc == 0) fail(IBH_EINVAL, "IceRegridder_L0::GvEp(): hcdefs is zero-length!");   // IceRegridder_L0.cpp:108-109
-    hipStream_t st = nullptr;
+    // the calling thread's own stream: builds issued by different host threads (assemble_batch) overlap on the GPU
+    hipStream_t st = hipStreamPerThread;
     Arena &A = arena();
     A.reset();
 
@@ -1205,7 +1221,11 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     if (!smooth && !bands_wanted && fast_build(rm, sp, dims, scale, correctA, rg, w.get(), st)) {
         w->built_fast = 1;
         *out = w.release();
-        return;
+        return true;
+    }
+    if (fast_only) {
+        for (int k = 0; k < 2; ++k) if (w->owns[k]) { delete dims[k]; w->owns[k] = false; w->dims[k] = nullptr; }
+        return false;
     }
     A.reset();
     // counters read back with ONE sync: [0] first out-of-range exchange cell, [1] new row keys,
@@ -1333,6 +1353,149 @@ void assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
         IBH_HIP(hipStreamSynchronize(st));
     }
     *out = w.release();
+    return true;
+}
+
+// ---- a batch of builds (the coupler's per-timestep set, IceCoupler.cpp:361-468) ----------------------------------
+// Same results as calling matrix_d for the jobs one after the other, in order.  Jobs that share no set they could
+// modify run CONCURRENTLY, each on a host thread of a small persistent pool and that thread's own stream: a 5 km build
+// is ~250 workgroups, an eighth of the chip, so four of them overlap almost perfectly.  A job waits for every earlier
+// job that may still append to one of its sets (EvI numbers dimE before IvE / XvE read it); jobs of one wave that share a
+// pre-populated set run in fast-only mode (the fast path only reads such a set) and anything that needs the general
+// pipeline -- which may append -- is redone sequentially afterwards, together with the later jobs that share its sets.
+namespace {
+class WorkerPool {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::deque<std::function<void()>> queue;
+    int pending = 0;
+    bool stop = false;
+public:
+    explicit WorkerPool(int n) {
+        for (int i = 0; i < n; ++i)
+            threads.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [this] { return stop || !queue.empty(); });
+                        if (stop && queue.empty()) return;
+                        job = std::move(queue.front());
+                        queue.pop_front();
+                    }
+                    job();
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        --pending;
+                    }
+                    done_cv.notify_all();
+                }
+            });
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : threads) t.detach();      // process exit: the HIP runtime may already be gone, do not join into it
+    }
+    void submit(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(mu); queue.push_back(std::move(f)); ++pending; }
+        cv.notify_one();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [this] { return pending == 0; });
+    }
+};
+WorkerPool &pool() { static WorkerPool *p = new WorkerPool(3); return *p; }
+}  // namespace
+
+void assemble_batch(const ibh_regrid_matrices *rm, int n, const char *const *specs, ibh_sparse_set *const *dim0,
+                    ibh_sparse_set *const *dim1, const int32_t *scale, const int32_t *correctA, const double sigma[3],
+                    ibh_weighted **out) {
+    IBH_CHECK(rm && n >= 0 && (n == 0 || (specs && scale && correctA && out)), "bad arguments");
+    struct Job { const MatSpec *sp; ibh_sparse_set *d[2]; int wave; bool done; int code; std::string err; };
+    std::vector<Job> jobs((size_t)n);
+    for (int j = 0; j < n; ++j) {
+        IBH_CHECK(specs[j] != nullptr, "null matrix name in batch");
+        jobs[(size_t)j] = Job{find_spec(specs[j]), {dim0 ? dim0[j] : nullptr, dim1 ? dim1[j] : nullptr}, 0, false, IBH_OK, std::string()};
+        IBH_CHECK(jobs[(size_t)j].d[0] == nullptr || jobs[(size_t)j].d[0] != jobs[(size_t)j].d[1], "dims[0] and dims[1] must be distinct sets");
+        out[j] = nullptr;
+    }
+    const ibh_regridder *g = rm->rg;
+    auto extent_of = [&](int key) -> int64_t {
+        return key == KEY_A ? g->nA : key == KEY_E ? g->nA * (int64_t)g->nhc : key == KEY_I ? g->nI : g->nX;
+    };
+    auto readonly = [&](const Job &jb, int k) {          // a set no build ever changes: the identity over its whole extent
+        const ibh_sparse_set *s = jb.d[k];
+        return s && s->identity && s->n == extent_of(k == 0 ? jb.sp->row_key : jb.sp->col_key);
+    };
+    // wave of a job: one after the PRODUCER of each of its sets -- the first job of the batch that uses a set which is
+    // still empty numbers it; the later users of that set only read it (fast path) and do not wait for each other
+    for (int j = 0; j < n; ++j)
+        for (int a = 0; a < 2; ++a) {
+            const ibh_sparse_set *s = jobs[(size_t)j].d[a];
+            if (!s || s->n != 0 || readonly(jobs[(size_t)j], a)) continue;
+            for (int i = 0; i < j; ++i)
+                if (jobs[(size_t)i].d[0] == s || jobs[(size_t)i].d[1] == s) {      // i is the producer (the first user)
+                    jobs[(size_t)j].wave = std::max(jobs[(size_t)j].wave, jobs[(size_t)i].wave + 1);
+                    break;
+                }
+        }
+    int dev = 0;
+    IBH_HIP(hipGetDevice(&dev));
+    int nwaves = 0;
+    for (auto &jb : jobs) nwaves = std::max(nwaves, jb.wave + 1);
+    auto run = [&](int j, bool fast_only) {
+        Job &jb = jobs[(size_t)j];
+        try {
+            jb.done = assemble_matrix(rm, specs[j], jb.d[0], jb.d[1], scale[j], correctA[j], sigma, &out[j], fast_only);
+        } catch (const Error &e) { jb.code = e.code; jb.err = e.msg; }
+        catch (const std::exception &e) { jb.code = IBH_EINVAL; jb.err = e.what(); }
+    };
+    auto shares = [&](int i, int j) {
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                if (jobs[(size_t)i].d[a] && jobs[(size_t)i].d[a] == jobs[(size_t)j].d[b] && !readonly(jobs[(size_t)i], a)) return true;
+        return false;
+    };
+    for (int wv = 0; wv < nwaves; ++wv) {
+        std::vector<int> members;
+        for (int j = 0; j < n; ++j) if (jobs[(size_t)j].wave == wv) members.push_back(j);
+        // members that share a (by now pre-populated) set with another member: fast-only; the others are free to use either path
+        std::vector<char> fo(members.size(), 0);
+        for (size_t a = 0; a < members.size(); ++a)
+            for (size_t b = 0; b < members.size(); ++b)
+                if (a != b && shares(members[a], members[b])) fo[a] = 1;
+        for (int j : members) { ibh_sparse_set *d[2] = {jobs[(size_t)j].d[0], jobs[(size_t)j].d[1]}; fast_prewarm(rm, jobs[(size_t)j].sp, d, hipStreamPerThread); }
+        for (size_t a = 1; a < members.size(); ++a) {
+            const int j = members[a];
+            const bool f = fo[a] != 0;
+            pool().submit([&, j, f, dev] { (void)hipSetDevice(dev); run(j, f); });
+        }
+        if (!members.empty()) run(members[0], fo[0] != 0);
+        pool().wait();
+        // anything the fast path declined is redone by the general pipeline, in order; a later member that shares a set
+        // with it saw the set before that build could append to it and is redone too
+        std::vector<int> redone;
+        for (size_t a = 0; a < members.size(); ++a) {
+            const int j = members[a];
+            Job &jb = jobs[(size_t)j];
+            if (jb.code != IBH_OK) continue;
+            bool redo = !jb.done;
+            for (int b : redone) redo = redo || shares(b, j);
+            if (!redo) continue;
+            if (out[j]) { delete out[j]; out[j] = nullptr; }
+            redone.push_back(j);
+            run(j, false);
+        }
+    }
+    for (int j = 0; j < n; ++j)
+        if (jobs[(size_t)j].code != IBH_OK) {
+            const Job jb = jobs[(size_t)j];
+            for (int q = 0; q < n; ++q) { delete out[q]; out[q] = nullptr; }
+            throw Error(jb.code, jb.err);
+        }
 }
 
 // ---- ibh_weighted_from_coo: Eigen setFromTriplets on device -----------------------------------

@@ -364,6 +364,15 @@ int ibh_regrid_matrices_matrix_d(const ibh_regrid_matrices *rm, const char *spec
         assemble_matrix(rm, spec, dim0, dim1, scale, correctA, sigma, out);
     });
 }
+int ibh_regrid_matrices_matrix_batch(const ibh_regrid_matrices *rm, int32_t n, const char *const *specs,
+                                     ibh_sparse_set *const *dim0, ibh_sparse_set *const *dim1, const int32_t *scale,
+                                     const int32_t *correctA, const double sigma[3], ibh_weighted **out) {
+    return guarded([&] {
+        IBH_CHECK(rm && out, "null argument");
+        check_rm_device(rm);
+        assemble_batch(rm, n, specs, dim0, dim1, scale, correctA, sigma, out);
+    });
+}
 int ibh_regrid_matrices_matrix(const ibh_regrid_matrices *rm, const char *spec, ibh_weighted **out) {
     return guarded([&] {
         IBH_CHECK(rm && spec && out, "null argument");

@@ -31,6 +31,7 @@ constexpr int FA_ILMAX = 8;         // exchange cells per ice cell
 constexpr int FA_DUPMAX = 4;        // consecutive cells with the same (iA, iI)
 constexpr int FA_OLDMAX = 512;      // straddling entries of one range ranked in LDS
 constexpr int FA_T = 256;
+constexpr int FA_CPT = 4;          // exchange cells per thread and pass of the range kernel
 enum { FA_ERR_OLDOVER = 1, FA_ERR_MISSING = 2 };
 
 struct PlanView {
@@ -378,74 +379,108 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
     __syncthreads();
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const bool g_is_row = EMIT;
-    for (long cb = x0; cb < x1; cb += FA_T) {
-        const long x = cb + tid;
-        const bool head = x < x1 && !(merge && (pl.isdup[x] & 1));
-        GEnt ge;
-        ge.n = 0;
-        long iI = 0;
-        if (head) {
-            const XCell c = load_cell<WITH_EP>(rg, x);
-            iI = c.iI;
-            if (!(WITH_EP && c.range_error)) fa_group<WITH_EP>(rg, pl, s, g_is_row, merge != 0, c, x, ge);
-        }
-        const bool isnew = head && fa_pnew(p, pl, iI, x0);
-        const int did = ge.n ? fa_pdense(p, pl, iI, x) : 0;
-        if (EMIT) {
-            // dims of a P set numbered by this build: the first-seen cell of every key records dense -> sparse
-            if (x < x1 && p.fresh && p.pflag[x]) p.to_sparse[p.poff[x]] = p.key == KEY_I ? (long)rg.exi[2 * x + 1] : x;
-            // Mw of an ice cell that lives in this range only (and of every exchange cell): its <= 2 entries, in
-            // ascending row order, from zero (spsparse sum()).  Ice cells that straddle ranges: k_fa_pelem<SUMS>.
-            if (ge.n > 0 && (p.key == KEY_X || (pl.isdup[x] & 2))) {
-                double sum = 0.0;
-                if (ge.n == 1) sum = sum + ge.t0;
-                else if (s_rank[ge.cls0] < s_rank[ge.cls1]) { sum = sum + ge.t0; sum = sum + ge.t1; }
-                else { sum = sum + ge.t1; sum = sum + ge.t0; }
-                o.Mw[did] = sum;
-            }
-        }
-        // Rank of a new entry inside its class segment = entries of the same class at smaller x.  A cell holds a
-        // class in at most one of its two slots, so the lanes of a wave are matched on both slots at once
-        // (wave ballots, rs_scatter's scheme); every lane takes part in the ballots.
-        for (int i = tid; i < (FA_T / 64) * FA_NC; i += FA_T) (&s_wcnt[0][0])[i] = 0;
-        __syncthreads();
-        const bool has0 = ge.n > 0, has1 = ge.n > 1;
-        const int c0 = has0 ? ge.cls0 : 0, c1 = has1 ? ge.cls1 : 0;
-        const unsigned long long v0 = __ballot(has0 && isnew), v1 = __ballot(has1 && isnew);
-        unsigned long long pa0 = v0, pb0 = v1, pa1 = v0, pb1 = v1;      // pXj: lanes whose slot X holds the class of MY slot j
-        for (int b = 0; b < 6; ++b) {
-            const unsigned long long m0 = __ballot((c0 >> b) & 1), m1 = __ballot((c1 >> b) & 1);
-            const bool b0 = (c0 >> b) & 1, b1 = (c1 >> b) & 1;
-            pa0 &= b0 ? m0 : ~m0; pb0 &= b0 ? m1 : ~m1;
-            pa1 &= b1 ? m0 : ~m0; pb1 &= b1 ? m1 : ~m1;
-        }
-        const unsigned long long u0 = pa0 | pb0, u1 = pa1 | pb1;
-        const uint32_t in0 = (uint32_t)__popcll(u0 & lt), in1 = (uint32_t)__popcll(u1 & lt);
-        if (has0 && isnew && in0 == 0) s_wcnt[wave][c0] = (uint32_t)__popcll(u0);
-        if (has1 && isnew && in1 == 0) s_wcnt[wave][c1] = (uint32_t)__popcll(u1);
-        __syncthreads();
+    // FA_CPT cells per thread and pass: their loads are issued in three staged rounds (exchange cell -> mask and
+    // first-seen position of its ice cell -> dense id) before anything is consumed, so a pass pays the dependent
+    // round trips once instead of once per 256 cells; the ranking then walks the FA_CPT sub-chunks in x order.
+    for (long cb = x0; cb < x1; cb += (long)FA_T * FA_CPT) {
+        int iAv[FA_CPT], iIv[FA_CPT], ifv[FA_CPT], didv[FA_CPT];
+        double av[FA_CPT], ev[FA_CPT];
+        unsigned fl[FA_CPT], pfv[FA_CPT], pov[FA_CPT];
+        GEnt gev[FA_CPT];
+        bool newv[FA_CPT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j >= ge.n) break;
-            const int cls = ge.cls(j);
-            if (isnew) {
-                uint32_t before = s_run[cls];
-                for (int w = 0; w < wave; ++w) before += s_wcnt[w][cls];
-                const uint32_t pos = eb + s_start[s_rank[cls]] + s_nold[cls] + before + (j ? in1 : in0);
-                if (EMIT) o.colind[pos] = did;
-                o.val[pos] = ge.t(j);
-            } else {                                       // straddler: ranked after the stream
-                const uint32_t q = atomicAdd(&s_no, 1u);
-                if (q < (uint32_t)FA_OLDMAX) { o_cls[q] = cls; o_did[q] = did; o_t[q] = ge.t(j); }
+        for (int u = 0; u < FA_CPT; ++u) {
+            const long x = cb + (long)u * FA_T + tid;
+            const long xx = x < x1 ? x : x1 - 1;
+            iAv[u] = rg.exi[2 * xx]; iIv[u] = rg.exi[2 * xx + 1]; av[u] = rg.area[xx]; fl[u] = pl.isdup[xx];
+            pfv[u] = 0; pov[u] = 0;
+            if (p.fresh && (EMIT || p.key == KEY_X)) { pfv[u] = p.pflag[xx]; pov[u] = p.poff[xx]; }
+        }
+#pragma unroll
+        for (int u = 0; u < FA_CPT; ++u) {
+            ev[u] = rg.em[iIv[u]];
+            ifv[u] = (p.key == KEY_I && p.fresh) ? pl.ifirst[iIv[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < FA_CPT; ++u) {
+            const long x = cb + (long)u * FA_T + tid;
+            if (p.key == KEY_I) didv[u] = p.fresh ? (int)p.poff[ifv[u] < 0 ? 0 : ifv[u]] : iIv[u];
+            else didv[u] = p.fresh ? (int)pov[u] : (int)(x < x1 ? x : x1 - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < FA_CPT; ++u) {
+            const long x = cb + (long)u * FA_T + tid;
+            const bool head = x < x1 && !(merge && (fl[u] & 1));
+            GEnt &ge = gev[u];
+            ge.n = 0; ge.cls0 = ge.cls1 = 0; ge.t0 = ge.t1 = 0.0; ge.gkey0 = ge.gkey1 = 0;
+            if (head) {
+                const XCell c = make_cell<WITH_EP>(rg, iAv[u], iIv[u], av[u], ev[u]);
+                if (!(WITH_EP && c.range_error)) fa_group<WITH_EP>(rg, pl, s, g_is_row, merge != 0, c, x, ge);
+            }
+            newv[u] = head && (p.key != KEY_I || !p.fresh || ifv[u] >= x0);
+            if (EMIT) {
+                // dims of a P set numbered by this build: the first-seen cell of every key records dense -> sparse
+                if (x < x1 && pfv[u]) p.to_sparse[pov[u]] = p.key == KEY_I ? (long)iIv[u] : x;
+                // Mw of an ice cell that lives in this range only (and of every exchange cell): its <= 2 entries, in
+                // ascending row order, from zero (spsparse sum()).  Ice cells that straddle ranges: k_fa_pelem<SUMS>.
+                if (ge.n > 0 && (p.key == KEY_X || (fl[u] & 2))) {
+                    double sum = 0.0;
+                    if (ge.n == 1) sum = sum + ge.t0;
+                    else if (s_rank[ge.cls0] < s_rank[ge.cls1]) { sum = sum + ge.t0; sum = sum + ge.t1; }
+                    else { sum = sum + ge.t1; sum = sum + ge.t0; }
+                    o.Mw[didv[u]] = sum;
+                }
             }
         }
-        __syncthreads();
-        if (tid < FA_NC) {
-            uint32_t a = 0;
-            for (int w = 0; w < FA_T / 64; ++w) a += s_wcnt[w][tid];
-            s_run[tid] += a;
+#pragma unroll
+        for (int u = 0; u < FA_CPT; ++u) {
+            if (cb + (long)u * FA_T >= x1) break;          // uniform: this sub-chunk lies past the range
+            const GEnt &ge = gev[u];
+            const bool isnew = newv[u];
+            const int did = didv[u];
+            // Rank of a new entry inside its class segment = entries of the same class at smaller x.  A cell holds a
+            // class in at most one of its two slots, so the lanes of a wave are matched on both slots at once
+            // (wave ballots, rs_scatter's scheme); every lane takes part in the ballots.
+            for (int i = tid; i < (FA_T / 64) * FA_NC; i += FA_T) (&s_wcnt[0][0])[i] = 0;
+            __syncthreads();
+            const bool has0 = ge.n > 0, has1 = ge.n > 1;
+            const int c0 = has0 ? ge.cls0 : 0, c1 = has1 ? ge.cls1 : 0;
+            const unsigned long long v0 = __ballot(has0 && isnew), v1 = __ballot(has1 && isnew);
+            unsigned long long pa0 = v0, pb0 = v1, pa1 = v0, pb1 = v1;      // pXj: lanes whose slot X holds the class of MY slot j
+            for (int b = 0; b < 6; ++b) {
+                const unsigned long long m0 = __ballot((c0 >> b) & 1), m1 = __ballot((c1 >> b) & 1);
+                const bool b0 = (c0 >> b) & 1, b1 = (c1 >> b) & 1;
+                pa0 &= b0 ? m0 : ~m0; pb0 &= b0 ? m1 : ~m1;
+                pa1 &= b1 ? m0 : ~m0; pb1 &= b1 ? m1 : ~m1;
+            }
+            const unsigned long long u0 = pa0 | pb0, u1 = pa1 | pb1;
+            const uint32_t in0 = (uint32_t)__popcll(u0 & lt), in1 = (uint32_t)__popcll(u1 & lt);
+            if (has0 && isnew && in0 == 0) s_wcnt[wave][c0] = (uint32_t)__popcll(u0);
+            if (has1 && isnew && in1 == 0) s_wcnt[wave][c1] = (uint32_t)__popcll(u1);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j >= ge.n) break;
+                const int cls = ge.cls(j);
+                if (isnew) {
+                    uint32_t before = s_run[cls];
+                    for (int w = 0; w < wave; ++w) before += s_wcnt[w][cls];
+                    const uint32_t pos = eb + s_start[s_rank[cls]] + s_nold[cls] + before + (j ? in1 : in0);
+                    if (EMIT) o.colind[pos] = did;
+                    o.val[pos] = ge.t(j);
+                } else {                                       // straddler: ranked after the stream
+                    const uint32_t q = atomicAdd(&s_no, 1u);
+                    if (q < (uint32_t)FA_OLDMAX) { o_cls[q] = cls; o_did[q] = did; o_t[q] = ge.t(j); }
+                }
+            }
+            __syncthreads();
+            if (tid < FA_NC) {
+                uint32_t a = 0;
+                for (int w = 0; w < FA_T / 64; ++w) a += s_wcnt[w][tid];
+                s_run[tid] += a;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     const uint32_t no = s_no < (uint32_t)FA_OLDMAX ? s_no : (uint32_t)FA_OLDMAX;
     if (s_no > (uint32_t)FA_OLDMAX && tid == 0) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
@@ -485,6 +520,7 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
             const long iA = rg.exi[2 * x0];
             const long gkey = g.key == KEY_E ? iA * rg.sA + (long)cls * rg.sHC : iA;
             const int gd = fa_gdense(g, r, cls, gkey);
+            if (gd < 0) continue;                               // a key the pre-populated set lacks: the build is discarded (FA_ERR_MISSING)
             if (g.to_sparse) g.to_sparse[gd] = gkey;            // a set numbered by this build: dense -> sparse
             if (EMIT) {                                        // FAM_AEVI rows (RegridMatrices_Dynamic.cpp:100-146)
                 double wM, mul = 1.0;
@@ -644,6 +680,16 @@ __global__ void k_fa_init(uint32_t *cnt) {
     if (threadIdx.x < 8) cnt[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
 }
 
+// Batch builds (assemble_batch): everything a concurrent fast build would otherwise create lazily in shared objects --
+// the sheet's plan, the inverse table of a pre-populated column set -- is created up front on the calling thread.
+static void fast_prewarm(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], hipStream_t st) {
+    const ibh_regridder *gr = rm->rg;
+    if (!get_tuning("assemble_fast", 1) || sp->family == FAM_EVA || !ensure_plan(gr, st)) return;
+    if (sp->family != FAM_IVAE || !dims[1] || dims[1]->n == 0 || dims[1]->identity || sp->col_key != KEY_E) return;
+    (void)set_inverse_table(dims[1], gr->nA * (int64_t)gr->nhc, st);
+    IBH_HIP(hipStreamSynchronize(st));
+}
+
 // returns false when the fast path does not apply (nothing has been touched: the caller runs the general pipeline)
 static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
                        const RgView &rg, ibh_weighted *w, hipStream_t st) {
@@ -697,19 +743,29 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     }
     IBH_HIP(hipGetLastError());
     uint32_t h[8];
-    readback_sync(h, d_cnt, sizeof(h), st);
-    if (h[0] != 0xffffffffu) {                                  // message of linterp_1d_b, IceRegridder_L0.cpp:84-85
-        int32_t ij[2];
-        IBH_HIP(hipMemcpy(ij, gr->ex_indices.p + 2 * (size_t)h[0], sizeof(ij), hipMemcpyDeviceToHost));
-        double e = 0;
-        IBH_HIP(hipMemcpy(&e, rm->elevmaskI.p + ij[1], sizeof(double), hipMemcpyDeviceToHost));
-        fail(IBH_ERANGE, "Elevation %g out of bounds (%g, %g)", e < 0 ? 0.0 : e, gr->hcdefs_h.front(), gr->hcdefs_h.back());
-    }
-    if (h[1]) return false;                                     // a limit of the fast path was hit: general pipeline
-    const uint32_t n_pnew = h[2], n_g = h[3], nnz = h[4];
-    IBH_CHECK(nnz < (1u << 31) && n_pnew < (1u << 31), "matrix too large for int32 indices");
-    const int np_d = p.fresh ? (int)n_pnew : (int)extent_of(pkey);
-    const int ng_d = g_fresh ? (int)n_g : gset->n;
+    auto check_counters = [&]() -> bool {
+        readback_sync(h, d_cnt, sizeof(h), st);
+        if (h[0] != 0xffffffffu) {                              // message of linterp_1d_b, IceRegridder_L0.cpp:84-85
+            int32_t ij[2];
+            IBH_HIP(hipMemcpy(ij, gr->ex_indices.p + 2 * (size_t)h[0], sizeof(ij), hipMemcpyDeviceToHost));
+            double e = 0;
+            IBH_HIP(hipMemcpy(&e, rm->elevmaskI.p + ij[1], sizeof(double), hipMemcpyDeviceToHost));
+            fail(IBH_ERANGE, "Elevation %g out of bounds (%g, %g)", e < 0 ? 0.0 : e, gr->hcdefs_h.front(), gr->hcdefs_h.back());
+        }
+        if (h[1]) return false;                                 // a limit of the fast path was hit: general pipeline
+        IBH_CHECK(h[4] < (1u << 31) && h[2] < (1u << 31), "matrix too large for int32 indices");
+        return true;
+    };
+    // Small grids are bound by launches and synchronisations, not by bytes: their outputs are allocated by upper bounds
+    // (<= 2 entries per exchange cell, <= NC rows per range) so that the counters are read back ONCE, with the final
+    // synchronisation; large grids read them here and allocate exactly.
+    const bool optimistic = nX <= (1l << 20) && get_tuning("assemble_optimistic", 1);
+    if (!optimistic && !check_counters()) return false;
+    const uint32_t n_pnew = optimistic ? (uint32_t)std::min<int64_t>(extent_of(pkey), nX) : h[2];
+    const uint32_t n_g = optimistic ? (uint32_t)nrc : h[3];
+    const uint32_t nnz = optimistic ? (uint32_t)((uses_ep ? 2 : 1) * nX) : h[4];
+    int np_d = p.fresh ? (int)n_pnew : (int)extent_of(pkey);
+    int ng_d = g_fresh ? (int)n_g : gset->n;
     // dims tables of the sets numbered by this build are written straight into the sets' device buffers
     DevBuf<int64_t> ptable, gtable;
     if (p.fresh) { ptable.alloc((size_t)np_d); p.to_sparse = ptable.p; }
@@ -735,6 +791,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     } else {
         // rows = P: count -> scan -> emit per element; Mw (G columns) from the ranges through a scratch copy of the terms
         uint32_t *rowlen = A.get<uint32_t>((size_t)nrow + 1);
+        if (optimistic && p.fresh) IBH_HIP(hipMemsetAsync(rowlen, 0, sizeof(uint32_t) * ((size_t)nrow + 1), st));   // rows beyond the real count
         if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PCOUNT>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
         else hipLaunchKernelGGL((k_fa_pelem<false, FA_PCOUNT>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
         exclusive_scan_u32(rowlen, reinterpret_cast<uint32_t *>(w->rowptr.p), (size_t)nrow, reinterpret_cast<uint32_t *>(w->rowptr.p) + nrow, st);
@@ -747,6 +804,15 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         else hipLaunchKernelGGL((k_fa_range<false, false>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, os, flags);
     }
     IBH_HIP(hipGetLastError());
+    if (optimistic) {                                           // the one read-back of a small build: flags and the real sizes
+        if (!check_counters()) return false;
+        if (p.fresh) np_d = (int)h[2];
+        if (g_fresh) ng_d = (int)h[3];
+        w->nrow = g_is_row ? ng_d : np_d; w->ncol = g_is_row ? np_d : ng_d; w->nnz = h[4];
+        w->rowptr.n = (size_t)w->nrow + 1; w->colind.n = w->val.n = (size_t)w->nnz;
+        w->wM.n = (size_t)w->nrow; w->Mw.n = (size_t)w->ncol;
+        ptable.n = p.fresh ? (size_t)np_d : 0; gtable.n = g_fresh ? (size_t)ng_d : 0;
+    }
     auto commit = [&](ibh_sparse_set *set, int64_t extent, DevBuf<int64_t> &table, int n) {
         set->sparse_extent = extent;
         if (n == 0) return;
@@ -755,8 +821,10 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         set->dev_n = set->n = n;
         set->identity = false;
     };
-    if (p.fresh) commit(pset, extent_of(pkey), ptable, np_d); else pset->sparse_extent = extent_of(pkey);
-    if (g_fresh) commit(gset, gext, gtable, ng_d); else gset->sparse_extent = gext;
+    // (a set that is only read -- identity / pre-populated -- may be shared by builds running concurrently in a batch:
+    // its extent is written only when it changes)
+    if (p.fresh) commit(pset, extent_of(pkey), ptable, np_d); else if (pset->sparse_extent != extent_of(pkey)) pset->sparse_extent = extent_of(pkey);
+    if (g_fresh) commit(gset, gext, gtable, ng_d); else if (gset->sparse_extent != gext) gset->sparse_extent = gext;
     IBH_HIP(hipStreamSynchronize(st));
     return true;
 }

@@ -44,6 +44,22 @@ class RegridMatrices:
         return linear_Weighted(h, keep=(self, dims))
 
 
+    def matrix_batch(self, jobs, sigma=None):
+        """The matrices of one coupling step in one call (IceCoupler.cpp:361-468): jobs is a list of
+        (spec_name, (dim0, dim1), scale, correctA) -- dims as in matrix_d -- and the results are those of the
+        matrix_d calls in that order; independent builds run concurrently inside the library."""
+        n = len(jobs)
+        names = (C.c_char_p * n)(*[j[0].encode() for j in jobs])
+        d0 = (C.c_void_p * n)(*[(j[1][0]._h.value if j[1][0] is not None else None) for j in jobs])
+        d1 = (C.c_void_p * n)(*[(j[1][1]._h.value if j[1][1] is not None else None) for j in jobs])
+        sc = (C.c_int32 * n)(*[int(j[2]) for j in jobs])
+        ca = (C.c_int32 * n)(*[int(j[3]) for j in jobs])
+        out = (C.c_void_p * n)()
+        sig = None if sigma is None else np.asarray(sigma, np.float64)
+        check(lib().ibh_regrid_matrices_matrix_batch(self._h, n, names, d0, d1, sc, ca, ptr(sig), out))
+        return [linear_Weighted(C.c_void_p(out[k]), keep=(self, jobs[k][1])) for k in range(n)]
+
+
 class _Sheet:
     def __init__(self, handle, nI, arrays, interp_style="Z_INTERP", centroid=None):
         self.h, self.nI, self.arrays = handle, nI, arrays

@@ -157,6 +157,15 @@ int ibh_regrid_matrices_matrix_d(const ibh_regrid_matrices *rm, const char *spec
                                  ibh_sparse_set *dim0, ibh_sparse_set *dim1,
                                  int scale, int correctA, const double sigma[3],
                                  ibh_weighted **out);
+/* The matrices of one coupling step in ONE call (IceCoupler.cpp:361-468 builds EvI, AvI, IvE, XvE per step with a
+ * shared dimE and identity dimI / dimX): the results -- matrices and dims -- are those of n ibh_regrid_matrices_matrix_d
+ * calls in the order given (sigma[3], or NULL for no smoothing, applies to all); builds that cannot influence each
+ * other run concurrently on the library's worker threads and their own streams, a build that reads a set an earlier
+ * one numbers waits for it.  On error nothing is returned (out[] all NULL) and the first failing job's status is. */
+int ibh_regrid_matrices_matrix_batch(const ibh_regrid_matrices *rm, int32_t n, const char *const *specs,
+                                     ibh_sparse_set *const *dim0, ibh_sparse_set *const *dim1,
+                                     const int32_t *scale, const int32_t *correctA, const double sigma[3],
+                                     ibh_weighted **out /* [n] */);
 /* RegridMatrices::matrix(spec) (RegridMatrices.hpp:60-61): own dims, params of rm. */
 int ibh_regrid_matrices_matrix(const ibh_regrid_matrices *rm, const char *spec, ibh_weighted **out);
 

@@ -112,6 +112,46 @@ def test_fast_and_general_assembly_paths_agree_with_the_oracle(config):
         icebin_amd.set_tuning("assemble_fast", 1)
 
 
+@pytest.mark.parametrize("fast", [1, 0])
+def test_matrix_batch_equals_sequential_builds(fast):
+    # ibh_regrid_matrices_matrix_batch: the coupler's per-step set (IceCoupler.cpp:361-468) in one call; independent builds
+    # run concurrently on the library's worker threads.  Results (matrices AND dims) are those of matrix_d calls in order.
+    g, em, mm, rg = setup("g20")
+    nI, nX, nE = g["nI"], len(g["ex_area"]), g["nA"] * len(g["hcdefs"])
+    try:
+        icebin_amd.set_tuning("assemble_fast", fast)
+        rm = mm.regrid_matrices("greenland", em)
+        for rep in range(3):            # repeated steps reuse the worker threads and their workspaces
+            dimI, dimX, dimE, dimA = (icebin_amd.SparseSet.identity(nI), icebin_amd.SparseSet.identity(nX), icebin_amd.SparseSet(nE),
+                                      icebin_amd.SparseSet(g["nA"]))
+            jobs = [("EvI", (dimE, dimI), False, False), ("AvI", (dimA, dimI), False, True), ("IvE", (dimI, dimE), True, True),
+                    ("XvE", (dimX, dimE), False, True), ("EvA", (dimE, dimA), True, True), ("IvA", (None, None), True, False)]
+            ws = rm.matrix_batch(jobs)
+            oI, oX, oE, oA = (orc.SparseSet(nI, init=np.arange(nI)), orc.SparseSet(nX, init=np.arange(nX)), orc.SparseSet(nE),
+                              orc.SparseSet(g["nA"]))
+            odims = [(oE, oI), (oA, oI), (oI, oE), (oX, oE), (oE, oA), (None, None)]
+            for (name, _, sc, cA), od, w in zip(jobs, odims, ws):
+                assert_same_weighted(w, rg.matrix_d(name, em, dims=od, scale=sc, correctA=cA), "batch %s fast=%d" % (name, fast))
+                if fast:
+                    assert w.built_fast() == (name != "EvA")
+            assert np.array_equal(dimE.to_sparse(), ws[0].dim(0)) and np.array_equal(dimA.to_sparse(), ws[1].dim(0))
+        # a shared set that lacks a key: the concurrent fast-only attempt declines, the job is redone by the general pipeline
+        # (which appends), and the later job that shares the set is redone after it -- sequential semantics
+        E_keys = ws[0].dim(0)
+        dE3, oE3 = icebin_amd.SparseSet(nE, E_keys[:-3]), orc.SparseSet(nE, init=E_keys[:-3])
+        dI2, dX2 = icebin_amd.SparseSet.identity(nI), icebin_amd.SparseSet.identity(nX)
+        w1, w2 = rm.matrix_batch([("IvE", (dI2, dE3), True, True), ("XvE", (dX2, dE3), False, True)])
+        assert_same_weighted(w1, rg.matrix_d("IvE", em, dims=(orc.SparseSet(nI, init=np.arange(nI)), oE3), scale=True, correctA=True), "redo IvE")
+        assert_same_weighted(w2, rg.matrix_d("XvE", em, dims=(orc.SparseSet(nX, init=np.arange(nX)), oE3), scale=False, correctA=True), "redo XvE")
+        assert dE3.dense_extent() == len(E_keys)
+        # an error in one job: nothing is returned, the message is the job's
+        with pytest.raises(icebin_amd.IcebinHipError, match="unknown regrid matrix 'BvA'"):
+            rm.matrix_batch([("AvI", (None, None), True, True), ("BvA", (None, None), True, True)])
+        assert rm.matrix_batch([]) == []
+    finally:
+        icebin_amd.set_tuning("assemble_fast", 1)
+
+
 def test_config1_real_mask_bit_exact(elev_mask_g20):
     # BASELINE config 1: 20 km Greenland, the reference's own PISM mask fixture, all six matrices
     g = syn.make_grids("g20")
