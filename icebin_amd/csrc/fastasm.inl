@@ -247,20 +247,58 @@ __global__ __launch_bounds__(FA_T) void k_fa_count(RgView rg, PlanView pl, MatSp
     const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
     if (threadIdx.x < FA_NC) { s_first[threadIdx.x] = 0xffffffffu; s_cn[threadIdx.x] = 0; s_co[threadIdx.x] = 0; }
     __syncthreads();
-    for (long x = x0 + threadIdx.x; x < x1; x += FA_T) {
-        const XCell c = load_cell<WITH_EP>(rg, x);
-        if (p.fresh) p.pflag[x] = fa_pflag_of<WITH_EP>(rg, pl, p, c, x);
-        if (WITH_EP && c.range_error) { atomicMin(err_x, (uint32_t)x); continue; }
-        long k0, k1;
-        const int n = list_entries(c, x, g.list, g.key, k0, k1);        // first-seen positions of the G keys: every cell counts
-        if (n > 0) atomicMin(&s_first[fa_class(rg, g.key, k0)], (uint32_t)(2 * x));
-        if (n > 1) atomicMin(&s_first[fa_class(rg, g.key, k1)], (uint32_t)(2 * x + 1));
-        if (merge && (pl.isdup[x] & 1)) continue;
-        GEnt ge;
-        fa_group<WITH_EP>(rg, pl, s, g_is_row != 0, merge != 0, c, x, ge);
-        const bool isnew = fa_pnew(p, pl, c.iI, x0);
-        if (ge.n > 0) atomicAdd(isnew ? &s_cn[ge.cls0] : &s_co[ge.cls0], 1u);
-        if (ge.n > 1) atomicAdd(isnew ? &s_cn[ge.cls1] : &s_co[ge.cls1], 1u);
+    // FA_CPT cells per thread and pass with their loads staged (exchange cell, then mask / first-seen position of the ice
+    // cell) before anything is consumed: a range of ~10^3 cells is one pass, i.e. two dependent round trips in all
+    const int lane = threadIdx.x & 63;
+    for (long cb = x0; cb < x1; cb += (long)FA_T * FA_CPT) {
+        int iAv[FA_CPT], iIv[FA_CPT], ifv[FA_CPT];
+        double av[FA_CPT], ev[FA_CPT];
+        unsigned fl[FA_CPT];
+#pragma unroll
+        for (int u = 0; u < FA_CPT; ++u) {
+            const long x = cb + (long)u * FA_T + threadIdx.x;
+            const long xx = x < x1 ? x : x1 - 1;
+            iAv[u] = rg.exi[2 * xx]; iIv[u] = rg.exi[2 * xx + 1]; av[u] = rg.area[xx]; fl[u] = pl.isdup[xx];
+        }
+#pragma unroll
+        for (int u = 0; u < FA_CPT; ++u) {
+            ev[u] = rg.em[iIv[u]];
+            ifv[u] = p.key == KEY_I ? pl.ifirst[iIv[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < FA_CPT; ++u) {
+            const long x = cb + (long)u * FA_T + threadIdx.x;
+            const bool in = x < x1;
+            uint32_t cn0 = 0, co0 = 0;                        // one-class ranges: this lane's new / old entries
+            if (in) {
+                const XCell c = make_cell<WITH_EP>(rg, iAv[u], iIv[u], av[u], ev[u]);
+                if (p.fresh) p.pflag[x] = p.key == KEY_I ? ((ifv[u] == (int32_t)x && c.unmasked) ? 1u : 0u) : fa_pflag_of<WITH_EP>(rg, pl, p, c, x);
+                if (WITH_EP && c.range_error) atomicMin(err_x, (uint32_t)x);
+                else {
+                    long k0, k1;
+                    const int n = list_entries(c, x, g.list, g.key, k0, k1);        // first-seen positions of the G keys: every cell counts
+                    if (g.NC == 1) { if (n > 0) atomicMin(&s_first[0], (uint32_t)(2 * x)); }     // (one address: cheap; first hit wins quickly)
+                    else {
+                        if (n > 0) atomicMin(&s_first[fa_class(rg, g.key, k0)], (uint32_t)(2 * x));
+                        if (n > 1) atomicMin(&s_first[fa_class(rg, g.key, k1)], (uint32_t)(2 * x + 1));
+                    }
+                    if (!(merge && (fl[u] & 1))) {
+                        GEnt ge;
+                        fa_group<WITH_EP>(rg, pl, s, g_is_row != 0, merge != 0, c, x, ge);
+                        const bool isnew = p.key != KEY_I || !p.fresh || ifv[u] >= x0;
+                        if (g.NC == 1) { cn0 = (ge.n > 0 && isnew) ? 1u : 0u; co0 = (ge.n > 0 && !isnew) ? 1u : 0u; }
+                        else {
+                            if (ge.n > 0) atomicAdd(isnew ? &s_cn[ge.cls0] : &s_co[ge.cls0], 1u);
+                            if (ge.n > 1) atomicAdd(isnew ? &s_cn[ge.cls1] : &s_co[ge.cls1], 1u);
+                        }
+                    }
+                }
+            }
+            if (g.NC == 1) {                                  // one counter pair: a ballot per wave instead of an atomic per lane
+                const unsigned long long bn = __ballot(cn0 != 0), bo = __ballot(co0 != 0);
+                if (lane == 0) { if (bn) atomicAdd(&s_cn[0], (uint32_t)__popcll(bn)); if (bo) atomicAdd(&s_co[0], (uint32_t)__popcll(bo)); }
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x < FA_NC && (int)threadIdx.x < g.NC) {
@@ -351,7 +389,7 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
     __shared__ int s_rank[FA_NC];
     __shared__ uint32_t s_start[FA_NC + 1], s_seg[FA_NC], s_nold[FA_NC], s_run[FA_NC], s_wcnt[FA_T / 64][FA_NC];
     __shared__ double s_mul[FA_NC];
-    __shared__ uint32_t s_no;
+    __shared__ uint32_t s_no, s_w1[2][FA_T / 64];
     __shared__ int o_cls[FA_OLDMAX], o_did[FA_OLDMAX];
     __shared__ double o_t[FA_OLDMAX];
     stage_hc<WITH_EP>(rg, s_hc);
@@ -438,6 +476,29 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
             const GEnt &ge = gev[u];
             const bool isnew = newv[u];
             const int did = didv[u];
+            if (g.NC == 1) {
+                // one class per range (A rows / A columns): the rank is a running count -- one ballot, two barriers
+                const int par = u & 1;
+                const bool hn = ge.n > 0 && isnew;
+                const unsigned long long m = __ballot(hn);
+                if (lane == 0) s_w1[par][wave] = (uint32_t)__popcll(m);
+                __syncthreads();
+                if (ge.n > 0) {
+                    if (isnew) {
+                        uint32_t before = s_run[0];
+                        for (int w = 0; w < wave; ++w) before += s_w1[par][w];
+                        const uint32_t pos = eb + s_nold[0] + before + (uint32_t)__popcll(m & lt);
+                        if (EMIT) o.colind[pos] = did;
+                        o.val[pos] = ge.t0;
+                    } else {
+                        const uint32_t q = atomicAdd(&s_no, 1u);
+                        if (q < (uint32_t)FA_OLDMAX) { o_cls[q] = 0; o_did[q] = did; o_t[q] = ge.t0; }
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) s_run[0] += s_w1[par][0] + s_w1[par][1] + s_w1[par][2] + s_w1[par][3];
+                continue;
+            }
             // Rank of a new entry inside its class segment = entries of the same class at smaller x.  A cell holds a
             // class in at most one of its two slots, so the lanes of a wave are matched on both slots at once
             // (wave ballots, rs_scatter's scheme); every lane takes part in the ballots.
