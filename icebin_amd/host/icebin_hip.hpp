@@ -199,6 +199,17 @@ public:
         check(ibh_weighted_apply_transformed_device(h_, dA_b, nvar_in, lda, T.data(), b.data(), (int32_t)b.size(),
                                                     dB_b, ldb, fill, stream));
     }
+    /** Several field batches through one launch (ibh_weighted_apply_many_device): dA_b[q] -> dB_b[q], all nvar x lda / ldb. */
+    void apply_many_device(std::vector<const double *> const &dA_b, int nvar, long lda, std::vector<double *> const &dB_b,
+                           long ldb, double fill, bool force_conservation, void *stream) const {
+        if (dA_b.size() != dB_b.size()) throw Exception(IBH_EINVAL, "apply_many_device: batch lists differ in length");
+        check(ibh_weighted_apply_many_device(h_, (int32_t)dA_b.size(), dA_b.data(), nvar, lda, dB_b.data(), ldb, fill,
+                                             force_conservation ? 1 : 0, stream));
+    }
+    /** The legacy COO product with its fill / ignore-NaN contract (coo_matvec, pylib/icebin_cython.cpp:158-192) on device arrays. */
+    void matvec_device(const double *dxx, int nvar, long ldx, double *dyy, long ldy, bool ignore_nan, void *stream) const {
+        check(ibh_weighted_matvec_device(h_, dxx, nvar, ldx, dyy, ldy, ignore_nan ? 1 : 0, stream));
+    }
     /** Device-resident variant: dA_b (nvar x lda) and dB_b (nvar x ldb) are HBM pointers; enqueues on stream. */
     void apply_device(const double *dA_b, int nvar, long lda, double *dB_b, long ldb, double fill,
                       bool force_conservation, void *stream) const {
@@ -281,6 +292,30 @@ public:
                                            dims[1] ? dims[1]->handle() : nullptr, params.scale, params.correctA,
                                            params.sigma.data(), &w));
         return std::unique_ptr<linear::Weighted_Eigen>(new linear::Weighted_Eigen(w));
+    }
+    /** The matrices of one coupling step in one call (IceCoupler.cpp:361-468 builds EvI, AvI, IvE, XvE every step): the
+        results of matrix_d(specs[k], dims[k], params[k]) in order; independent builds run concurrently in the library. */
+    std::vector<std::unique_ptr<linear::Weighted_Eigen>> matrix_batch(std::vector<std::string> const &specs,
+                                                                       std::vector<std::array<SparseSetT *, 2>> const &dims,
+                                                                       std::vector<RegridParams> const &params) const {
+        const size_t n = specs.size();
+        if (dims.size() != n || params.size() != n) throw Exception(IBH_EINVAL, "matrix_batch: argument lists differ in length");
+        std::vector<const char *> names(n);
+        std::vector<ibh_sparse_set *> d0(n), d1(n);
+        std::vector<int32_t> sc(n), ca(n);
+        const double *sigma = nullptr;
+        for (size_t k = 0; k < n; ++k) {
+            names[k] = specs[k].c_str();
+            d0[k] = dims[k][0] ? dims[k][0]->handle() : nullptr;
+            d1[k] = dims[k][1] ? dims[k][1]->handle() : nullptr;
+            sc[k] = params[k].scale; ca[k] = params[k].correctA;
+            if (params[k].smooth()) sigma = params[k].sigma.data();      // one sigma per batch
+        }
+        std::vector<ibh_weighted *> w(n, nullptr);
+        check(ibh_regrid_matrices_matrix_batch(h_, (int32_t)n, names.data(), d0.data(), d1.data(), sc.data(), ca.data(), sigma, w.data()));
+        std::vector<std::unique_ptr<linear::Weighted_Eigen>> out;
+        for (size_t k = 0; k < n; ++k) out.emplace_back(new linear::Weighted_Eigen(w[k]));
+        return out;
     }
     /** Produces its own dims (RegridMatrices_Dynamic.cpp:425-437). */
     std::unique_ptr<linear::Weighted> matrix(std::string const &spec_name) const override {
@@ -381,6 +416,44 @@ public:
         return out;
     }
 };
+
+// ---- e1ve0.hpp / e1ve0.cpp:55-106 ----------------------------------------------------------------
+namespace e1ve0 {
+/** compute_E1vE0c(XuE1s, XuE0s, nE, areaX): the correction matrix between last step's and this step's elevation grids,
+    one XuE matrix per ice sheet; returned over the sparse E space (rows iE1, columns iE0), where the reference returns
+    the same tuples as a spsparse::TupleList (areaX is unused there too). */
+inline std::unique_ptr<linear::Weighted_Eigen> compute_E1vE0c(std::vector<linear::Weighted_Eigen const *> const &XuE1s,
+                                                               std::vector<linear::Weighted_Eigen const *> const &XuE0s,
+                                                               unsigned long nE) {
+    if (XuE1s.size() != XuE0s.size() || XuE1s.empty()) throw Exception(IBH_EINVAL, "compute_E1vE0c: need one XuE1 and one XuE0 per ice sheet");
+    std::vector<const ibh_weighted *> a, b;
+    for (auto *w : XuE1s) a.push_back(w->handle());
+    for (auto *w : XuE0s) b.push_back(w->handle());
+    ibh_weighted *out = nullptr;
+    check(ibh_e1ve0_compute((int32_t)a.size(), a.data(), b.data(), (int64_t)nE, &out));
+    return std::unique_ptr<linear::Weighted_Eigen>(new linear::Weighted_Eigen(out));
+}
+}   // namespace e1ve0
+
+// ---- gridgen/GridGen_Exchange.cpp:175-284 ----------------------------------------------------------
+/** make_exchange_grid for a rectilinear XY ice grid under convex projected GCM-cell polygons (ibh_exgrid_generate). */
+inline ExchangeGrid make_exchange_grid(std::vector<double> const &xedges, std::vector<double> const &yedges, bool x_fastest,
+                                       std::vector<int> const &polyptr, std::vector<double> const &vx, std::vector<double> const &vy,
+                                       std::vector<long> const &iA) {
+    std::vector<int64_t> ia(iA.begin(), iA.end());
+    ibh_exgrid_desc d{};
+    d.nx = (int32_t)xedges.size() - 1; d.ny = (int32_t)yedges.size() - 1; d.xedges = xedges.data(); d.yedges = yedges.data();
+    d.x_fastest = x_fastest; d.npoly = (int32_t)ia.size(); d.polyptr = polyptr.data(); d.vx = vx.data(); d.vy = vy.data(); d.iA = ia.data();
+    ibh_exgrid *h = nullptr;
+    check(ibh_exgrid_generate(&d, &h));
+    ExchangeGrid ex;
+    int64_t n = 0;
+    int rc = ibh_exgrid_size(h, &n);
+    if (rc == IBH_OK) { ex.indices.resize((size_t)(2 * n)); ex.overlaps.resize((size_t)n); rc = ibh_exgrid_get(h, ex.indices.data(), ex.overlaps.data()); }
+    ibh_exgrid_destroy(h);
+    check(rc);
+    return ex;
+}
 
 // ---- pylib/icebin_cython.hpp:70-87 -----------------------------------------------------------
 namespace cython {

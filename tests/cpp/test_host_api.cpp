@@ -126,6 +126,37 @@ int main() {
         REQUIRE((long)trip.size() == OvI->nnz() && trip.front().row == 0 && std::isfinite(trip.front().value));
     }
 
+    // one coupling step's matrices in one call (IceCoupler.cpp:361-468), then E1vE0 against an unchanged mask (e1ve0.cpp:55-106)
+    {
+        SparseSetT dI(SparseSetT::identity(nx * ny)), dX(SparseSetT::identity((long)exgrid.overlaps.size())), dE((long)gcm.nE()), dA;
+        auto step = rmO->matrix_batch({"EvI", "AvI", "IvE", "XvE"},
+                                      {{{&dE, &dI}}, {{&dA, &dI}}, {{&dI, &dE}}, {{&dX, &dE}}},
+                                      {RegridParams(false, false, {{0., 0., 0.}}), RegridParams(false, true, {{0., 0., 0.}}),
+                                       RegridParams(true, true, {{0., 0., 0.}}), RegridParams(false, true, {{0., 0., 0.}})});
+        REQUIRE(step.size() == 4 && step[0]->shape_d()[0] == dE.dense_extent() && step[2]->shape_d()[1] == dE.dense_extent());
+        REQUIRE(step[1]->shape_d()[0] == dA.dense_extent() && dA.dense_extent() == 6);
+        auto one = rmO->matrix_d("XvE", {{&dX, &dE}}, RegridParams(false, true, {{0., 0., 0.}}));
+        REQUIRE(one->nnz() == step[3]->nnz());
+        auto E1vE0 = e1ve0::compute_E1vE0c({step[3].get()}, {one.get()}, gcm.nE());
+        REQUIRE(E1vE0->shape()[0] == (long)gcm.nE() && E1vE0->nnz() > 0);
+        for (auto const &t : E1vE0->M.triplets()) REQUIRE(t.value == 0.0);          // E1 == E0: no correction
+        // the exchange grid regenerated on the device (gridgen/GridGen_Exchange.cpp:175-284) equals the hand-built one
+        std::vector<double> xe, ye, vx, vy; std::vector<int> pp{0}; std::vector<long> ia;
+        for (int k = 0; k <= nx; ++k) xe.push_back(k);
+        for (int k = 0; k <= ny; ++k) ye.push_back(k);
+        for (int ay = 0; ay < 2; ++ay) for (int ax = 0; ax < 3; ++ax) {
+            double x0 = ax * Wx, x1 = (ax + 1) * Wx, y0 = ay * Wy, y1 = (ay + 1) * Wy;
+            vx.insert(vx.end(), {x0, x1, x1, x0}); vy.insert(vy.end(), {y0, y0, y1, y1});
+            pp.push_back((int)vx.size()); ia.push_back((j0 + ay) * im + (i0 + ax));
+        }
+        ExchangeGrid gen = make_exchange_grid(xe, ye, false, pp, vx, vy, ia);
+        REQUIRE(gen.overlaps.size() == exgrid.overlaps.size());
+        double tot = 0, tot0 = 0;
+        for (double v : gen.overlaps) tot += v;
+        for (double v : exgrid.overlaps) tot0 += v;
+        REQUIRE(std::fabs(tot - tot0) < 1e-12 * tot0);
+    }
+
     // errors surface as exceptions (error.hpp:28-32)
     bool threw = false;
     try { rm->matrix("BvA"); } catch (Exception const &e) { threw = e.code == IBH_ENOKEY; }
