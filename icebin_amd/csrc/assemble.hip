@@ -1172,6 +1172,40 @@ static void smooth_matrix(ibh_weighted *w, const ibh_regrid_matrices *rm, const 
     w->conservative = 0;            // conservative = !smooth, RegridMatrices_Dynamic.cpp:167
 }
 
+// The same structure for a matrix that already exists (either assembly path; spmm.hip calls this when an E-row matrix is
+// applied again and again): per-column slots from the CSR, then build_bands.  One synchronisation (the band count).
+__global__ void k_expand_rows(const int32_t *__restrict__ rowptr, int nrow, int32_t *__restrict__ row) {
+    const int r = blockIdx.x;                         // one workgroup per row: rows of E matrices hold 10^1..10^4 entries
+    for (int k = rowptr[r] + threadIdx.x; k < rowptr[r + 1]; k += blockDim.x) row[k] = r;
+}
+void build_bands_from_csr(const ibh_weighted *cw, hipStream_t st) {
+    ibh_weighted *w = const_cast<ibh_weighted *>(cw);
+    if (!w->band_eligible || w->band_n > 0 || w->nnz == 0 || w->nrow == 0 || w->ncol >= (1 << 28)) return;
+    const ibh_sparse_set *rset = w->dims[0];
+    if (!rset || rset->identity || rset->dev_n < w->nrow) return;         // the row keys must be on the device
+    Arena &A = arena();
+    A.reset();
+    const int T = 256, nrow = w->nrow, ncol = w->ncol;
+    const long nnz = w->nnz;
+    RgView rg{};
+    rg.sA = w->band_sA; rg.sHC = w->band_sHC;
+    int32_t *row = A.get<int32_t>((size_t)nnz);
+    hipLaunchKernelGGL(k_expand_rows, dim3(nrow), dim3(T), 0, st, w->rowptr.p, nrow, row);
+    uint32_t *colptr = A.get<uint32_t>((size_t)ncol + 1);
+    uint32_t *cntc = A.get<uint32_t>(2 * (size_t)ncol + 1), *fillc = cntc + ncol;
+    int32_t *lrow = A.get<int32_t>((size_t)nnz);
+    uint32_t *lidx = A.get<uint32_t>((size_t)nnz);
+    IBH_HIP(hipMemsetAsync(cntc, 0, sizeof(uint32_t) * (2 * (size_t)ncol + 1), st));
+    hipLaunchKernelGGL(k_col_count, dim3(ceil_div(nnz, T)), dim3(T), 0, st, w->colind.p, nnz, cntc);
+    exclusive_scan_u32(cntc, colptr, (size_t)ncol, colptr + ncol, st);
+    hipLaunchKernelGGL(k_col_scatter, dim3(ceil_div(nnz, T)), dim3(T), 0, st, row, w->colind.p, nnz, colptr, fillc, lrow, lidx);
+    uint32_t *d_nb = A.get<uint32_t>(1);
+    build_bands(w, rg, rset->dev.p, row, colptr, lrow, lidx, d_nb, st);
+    uint32_t nb = 0;
+    readback_sync(&nb, d_nb, sizeof(uint32_t), st);
+    w->band_n = nb;
+}
+
 #include "fastasm.inl"
 
 // ---- RegridMatrices_Dynamic::matrix_d ----------------------------------------------------------
@@ -1211,6 +1245,9 @@ bool assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     }
     w->conservative = 1;              // :63, :167 (no smoothing), :258
     w->scaled = scale;                // :421
+    if (sp->row_key == KEY_E && (sp->col_key == KEY_I || sp->col_key == KEY_X)) {       // EvI, EvX: bands may be built later (ensure_bands)
+        w->band_eligible = 1; w->band_sA = g->hc_stride_A; w->band_sHC = g->hc_stride_HC;
+    }
 
     auto extent_of = [&](int key) -> int64_t {
         return key == KEY_A ? g->nA : key == KEY_E ? g->nA * (int64_t)g->nhc : key == KEY_I ? g->nI : g->nX;

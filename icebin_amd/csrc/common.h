@@ -207,9 +207,15 @@ struct ibh_weighted {
     mutable ibh::DevBuf<double> xt;     // shortrow: transposed copy of the (small) input fields
     // rowdual (EvI, EvX): the CSR filtered to one entry per (GCM cell, ice cell) carrying the weights of
     // BOTH elevation classes the cell lies between (assemble.hip build_bands); band r = row r
-    int64_t band_n = 0;                 // number of band entries, 0: not built
-    ibh::DevBuf<int32_t> band_ptr, band_col, band_rb1;   // [nrow+1]; [band_n] column | bit30 lower exists | bit31 upper exists; [nrow]
-    ibh::DevBuf<double> band_v0, band_v1;                // [band_n] lower-class / upper-class weight
+    mutable int64_t band_n = 0;         // number of band entries, 0: not built
+    mutable ibh::DevBuf<int32_t> band_ptr, band_col, band_rb1;   // [nrow+1]; [band_n] column | bit30 lower exists | bit31 upper exists; [nrow]
+    mutable ibh::DevBuf<double> band_v0, band_v1;                // [band_n] lower-class / upper-class weight
+    // E-row matrices over ice / exchange columns can get the band structure later, from their CSR (ensure_bands):
+    // how the row keys decode into (GCM cell, class), and how many applies the matrix has seen
+    int band_eligible = 0;
+    int64_t band_sA = 0, band_sHC = 0;
+    mutable int band_tried = 0;
+    mutable int64_t napply = 0;
     mutable ibh::DevBuf<double> band_part;               // per-apply partial sums [2][nvar][nrow padded]
     mutable bool have_rowsum1 = false;
     mutable ibh::DevBuf<int32_t> rowperm;                // rows by descending length (batched rowblock launches)
@@ -233,6 +239,8 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
 void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA, int nvar, int64_t lda,
                       double *const *dB, int64_t ldb, double fill, int force_conservation, hipStream_t stream);
 void weighted_reserve(const ibh_weighted *w, int nvar);
+// assemble.hip: the band structure of an E-row matrix from its CSR (same result as building it with the matrix)
+void build_bands_from_csr(const ibh_weighted *w, hipStream_t st);
 void matvec_legacy_launch(const ibh_weighted *w, const double *dx, int nvar, int64_t ldx, double *dy, int64_t ldy,
                           int ignore_nan, hipStream_t stream);
 void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_in, int64_t lda, const double *T,

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
     const BatchPtrs bp, int nbatch, int qi, long ldx, int ncol, long ldy, int nrow, int nf, int nfc,
     int xcd_mode, const double *__restrict__ wM, double fill,
     const double *__restrict__ vals2 = nullptr, double *__restrict__ Y2 = nullptr,
-    const int *__restrict__ rowperm = nullptr)
+    const int *__restrict__ rowperm = nullptr, long y2_stride = 0)
 {
     static_assert(!DUAL || WK == 1, "bands are not split across waves");
     constexpr int RB_THREADS = NW * 64;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
             if (lane == 0) {
 #pragma unroll
                 for (int j = 0; j < FPW; ++j)
-                    if (f0 + j < nf) { Y[(long)(f0 + j) * ldy + r] = acc[j]; Y2[(long)(f0 + j) * ldy + r] = acc2[j]; }
+                    if (f0 + j < nf) { Y[(long)(f0 + j) * ldy + r] = acc[j]; Y2[(long)q * y2_stride + (long)(f0 + j) * ldy + r] = acc2[j]; }
             }
             continue;
         }
@@ -611,7 +611,7 @@ static void launch_rowblock(const ibh_weighted *w, const BatchPtrs &bp, int nbat
 #define IBH_RB(U)                                                                                        \
     hipExtLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U, NW>), grid, dim3(NW * 64), 0, stream, ev0, ev1, 0,  \
                           w->rowptr.p, w->colind.p, w->val.p, bp, nbatch, qi, lda, w->ncol, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill, \
-                          (const double *)nullptr, (double *)nullptr, (const int *)rowperm)
+                          (const double *)nullptr, (double *)nullptr, (const int *)rowperm, 0l)
     if (unroll == 1) IBH_RB(1);
     else if (unroll == 2) IBH_RB(2);
     else if (unroll == 8) IBH_RB(8);
@@ -621,24 +621,24 @@ static void launch_rowblock(const ibh_weighted *w, const BatchPtrs &bp, int nbat
 }
 
 // B[f, r] = lower-class sum of band r + upper-class sum of the band below it (rb1[r], -1: none)
-__global__ void dual_combine_kernel(const double *__restrict__ P0, const double *__restrict__ P1, long ldp,
+__global__ void dual_combine_kernel(const double *__restrict__ P0, const double *__restrict__ P1, long ldp, long pstride,
                                     const int *__restrict__ rb1, const double *__restrict__ wM, double fill,
-                                    double *__restrict__ Y, long ldy, int nrow, int nf) {
+                                    const BatchPtrs bp, long ldy, int nrow, int nf) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = blockIdx.y;
+    const int f = blockIdx.y, q = blockIdx.z;
     if (r >= nrow) return;
     const int b = rb1[r];
-    double t = P0[(long)f * ldp + r];
-    if (b >= 0) t = t + P1[(long)f * ldp + b];
-    Y[(long)f * ldy + r] = wM[r] == 0.0 ? fill : t;
+    double t = P0[(long)q * pstride + (long)f * ldp + r];
+    if (b >= 0) t = t + P1[(long)q * pstride + (long)f * ldp + b];
+    bp.y[q][(long)f * ldy + r] = wM[r] == 0.0 ? fill : t;
 }
 
-static size_t band_part_count(const ibh_weighted *w, int nvar) {
+static size_t band_part_count(const ibh_weighted *w, int nvar, int nbatch) {
     const long ldp = ((long)w->nrow + 63) & ~63l;
-    return 2 * (size_t)nvar * (size_t)ldp;
+    return 2 * (size_t)nbatch * (size_t)nvar * (size_t)ldp;
 }
 template <int FPW>
-static void launch_rowdual(const ibh_weighted *w, const double *dA, int nvar, long lda, double *dB, long ldb,
+static void launch_rowdual(const ibh_weighted *w, const BatchPtrs &bp, int nbatch, int nvar, long lda, long ldb,
                            double fill, hipStream_t stream)
 {
     constexpr int NW = 4, FB = FPW * NW;
@@ -648,20 +648,22 @@ static void launch_rowdual(const ibh_weighted *w, const double *dA, int nvar, lo
     IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
     IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
     const long ldp = ((long)w->nrow + 63) & ~63l;
-    grow_scratch(w->band_part, band_part_count(w, nvar), stream, "band");
-    double *P0 = w->band_part.p, *P1 = P0 + (size_t)nvar * (size_t)ldp;
+    const long pstride = (long)nvar * ldp;                       // one batch's lower (or upper) partial sums
+    grow_scratch(w->band_part, band_part_count(w, nvar, nbatch), stream, "band");
+    double *P0 = w->band_part.p, *P1 = P0 + (size_t)nbatch * (size_t)pstride;
     const double mean = w->nrow ? (double)w->band_n / (double)w->nrow / 64.0 : 1.0;
     const int unroll = mean > 4.0 ? 8 : mean > 2.0 ? 4 : mean > 1.0 ? 2 : 1;
-    BatchPtrs bp{};
-    bp.x[0] = dA; bp.y[0] = P0;
+    BatchPtrs bq{};
+    for (int q = 0; q < nbatch; ++q) { bq.x[q] = bp.x[q]; bq.y[q] = P0 + (size_t)q * (size_t)pstride; }
+    const dim3 grid((unsigned)nb, (unsigned)nbatch);
 #define IBH_RD(U)                                                                                                  \
-    hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, 1, U, NW, true>), dim3((unsigned)nb), dim3(NW * 64), 0, stream,   \
-                       w->band_ptr.p, w->band_col.p, w->band_v0.p, bp, 1, 1, lda, w->ncol, ldp, w->nrow, nvar, nfc, xcd_mode, \
-                       w->wM.p, fill, w->band_v1.p, P1)
+    hipLaunchKernelGGL((spmm_rowblock_kernel<FPW, 1, U, NW, true>), grid, dim3(NW * 64), 0, stream,                 \
+                       w->band_ptr.p, w->band_col.p, w->band_v0.p, bq, nbatch, 1, lda, w->ncol, ldp, w->nrow, nvar, nfc, xcd_mode, \
+                       w->wM.p, fill, w->band_v1.p, P1, (const int *)nullptr, pstride)
     if (unroll == 1) IBH_RD(1); else if (unroll == 2) IBH_RD(2); else if (unroll == 8) IBH_RD(8); else IBH_RD(4);
 #undef IBH_RD
-    hipLaunchKernelGGL(dual_combine_kernel, dim3((unsigned)ceil_div(w->nrow, 256), (unsigned)nvar), dim3(256), 0, stream,
-                       P0, P1, ldp, w->band_rb1.p, w->wM.p, fill, dB, ldb, w->nrow, nvar);
+    hipLaunchKernelGGL(dual_combine_kernel, dim3((unsigned)ceil_div(w->nrow, 256), (unsigned)nvar, (unsigned)nbatch), dim3(256), 0, stream,
+                       P0, P1, ldp, pstride, w->band_rb1.p, w->wM.p, fill, bp, ldb, w->nrow, nvar);
     IBH_HIP(hipGetLastError());
 }
 
@@ -700,7 +702,7 @@ static ShortrowPlan shortrow_plan(const ibh_weighted *w, int nvar) {
 void weighted_reserve(const ibh_weighted *w, int nvar) {
     if (nvar <= 0) return;
     const int kernel = pick_kernel(w, nvar);
-    if (kernel == 3 || w->band_n > 0) grow_scratch(w->band_part, band_part_count(w, nvar), nullptr, "band");
+    if (kernel == 3 || w->band_n > 0) grow_scratch(w->band_part, band_part_count(w, nvar, 1), nullptr, "band");
     if (kernel == 2 || w->kernel_override == 0) {
         const ShortrowPlan p = shortrow_plan(w, nvar);
         if (p.use_xt && pick_kernel(w, nvar) == 2) grow_scratch(w->xt, (size_t)w->ncol * (size_t)p.ldt, nullptr, "transposed-input");
@@ -717,11 +719,9 @@ static void launch_one(const ibh_weighted *w, int kernel, const BatchPtrs &bp, i
     if (kernel == 3) {
         const long pairs = (long)w->nrow * nvar;
         const int fpw = get_tuning("rowdual_fpw", pairs >= 4 * 8192 ? 4 : pairs >= 2 * 8192 ? 2 : 1);
-        for (int q = 0; q < nbatch; ++q) {
-            if (fpw >= 4) launch_rowdual<4>(w, bp.x[q], nvar, (long)lda, bp.y[q], (long)ldb, fill, stream);
-            else if (fpw == 2) launch_rowdual<2>(w, bp.x[q], nvar, (long)lda, bp.y[q], (long)ldb, fill, stream);
-            else launch_rowdual<1>(w, bp.x[q], nvar, (long)lda, bp.y[q], (long)ldb, fill, stream);
-        }
+        if (fpw >= 4) launch_rowdual<4>(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream);
+        else if (fpw == 2) launch_rowdual<2>(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream);
+        else launch_rowdual<1>(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream);
     } else if (kernel == 1) {
         int fpw = get_tuning(nbatch > 1 ? "rowblock_many_fpw" : "rowblock_fpw", 0), wk = get_tuning("rowblock_wk", 0);
         if (fpw == 0 || wk == 0) {
@@ -796,6 +796,17 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
     if (nvar <= 0 || w->nrow == 0 || nbatch <= 0) return;
     IBH_CHECK(lda >= w->ncol && ldb >= w->nrow, "apply: leading dimensions (%ld, %ld) smaller than (%d, %d)",
               (long)lda, (long)ldb, w->ncol, w->nrow);
+    // An E-row matrix that is applied again gets its band structure now (every ice cell carries the weights of BOTH
+    // classes it lies between and is read once instead of twice): pays for a matrix that meets many field batches, not
+    // for the coupler's one build : one apply, hence on the second apply and only for bandwidth-sized work (measured, 64
+    // fields: 1 km EvI 292 -> 255 us; at 5 km the extra combine pass costs more than the halved traffic saves, 18.5 -> 21.9).
+    if (w->band_eligible && !w->band_tried && w->band_n == 0 && w->napply >= 1 && w->kernel_override == 0 && nvar >= 4 &&
+        (double)w->nnz * nvar >= (double)get_tuning("rowdual_min_work", 128 << 20) && get_tuning("rowdual_auto", 1)) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
+        if (cs == hipStreamCaptureStatusNone) { w->band_tried = 1; build_bands_from_csr(w, stream); }
+    }
+    ++w->napply;
     const int kernel = pick_kernel(w, nvar);
     w->last_kernel = kernel;
     const bool correct = !w->conservative && force_conservation;

@@ -1260,6 +1260,47 @@ def test_rowdual_bands_on_grid_variants(variant):
         set_tuning("assemble_bands", 0)
 
 
+@pytest.mark.parametrize("variant", ["sorted", "shuffled"])
+def test_lazy_bands_on_repeated_applies_and_batched_rowdual(variant):
+    # an E-row matrix that is applied again gets its band structure from its own CSR (either assembly path) and the
+    # rowdual kernel takes over; batched launches serve it too, bitwise like separate rowdual applies
+    import torch
+    from icebin_amd.linear import set_tuning
+    g = syn.make_grids("g20", **(dict(order="shuffled") if variant == "shuffled" else {}))
+    em = syn.dome_elevmask(g)
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    set_tuning("rowdual_min_work", 1)
+    try:
+        rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+        for name in ("EvI", "EvX"):
+            w, o = rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True)
+            assert w.built_fast() == (variant == "sorted")
+            xs = [torch.from_numpy(syn.fields(6, w.ncol_d, seed=40 + q)).cuda() for q in range(5)]
+            xs[1][2, ::5] = float("nan")
+            y0 = w.apply_device(xs[0], fill=-1.0, force_conservation=False)
+            torch.cuda.synchronize()
+            assert w.last_kernel() == "rowblock"                     # first apply: no bands yet
+            y1 = w.apply_device(xs[0], fill=-1.0, force_conservation=False)
+            torch.cuda.synchronize()
+            assert w.last_kernel() == "rowdual"                      # second apply: bands built from the CSR
+            ref = o.apply(xs[0].cpu().numpy(), fill=-1.0, force_conservation=False)
+            assert rel_linf(y0.cpu().numpy(), ref) <= FIELD_RTOL and rel_linf(y1.cpu().numpy(), ref) <= FIELD_RTOL
+            sep = [w.apply_device(x, fill=-1.0, force_conservation=False).clone() for x in xs]
+            outs = w.apply_many_device(xs, fill=-1.0, force_conservation=False)
+            torch.cuda.synchronize()
+            assert w.last_kernel() == "rowdual"
+            for a, b, x in zip(outs, sep, xs):
+                assert np.array_equal(a.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
+                assert rel_linf(a.cpu().numpy(), o.apply(x.cpu().numpy(), fill=-1.0, force_conservation=False)) <= FIELD_RTOL
+        # matrices of other shapes never grow bands
+        w = rm.matrix("AvI")
+        x = torch.from_numpy(syn.fields(6, w.ncol_d)).cuda()
+        w.apply_device(x); w.apply_device(x)
+        assert w.last_kernel() == "rowblock"
+    finally:
+        set_tuning("rowdual_min_work", 128 << 20)
+
+
 @pytest.mark.parametrize("seed", list(range(10)))
 def test_random_exchange_grids_bit_exact(seed):
     """Randomised differential test of the whole assembly against the oracle: arbitrary (iA, iI) pairs
