@@ -121,6 +121,8 @@ def main():
     X = [x0 if b == 0 else x0 + 1e-3 * b for b in range(nbuf)]
     depth = max(1, min(32, args.queue_depth))
     ldy = (nrow + 63) // 64 * 64 if nrow >= 4096 else nrow       # 512-byte planes for the I-row matrices (whole-line stores)
+    if 8 * nf * ldy > (64 << 20):
+        depth = min(depth, 4)                                    # results of ~1 GB each (I-row matrices at 1 km): a short queue is plenty
     Y = [torch.zeros((nf, ldy), dtype=torch.float64, device=dev) for _ in range(2 * depth)]
 
     L = _capi.lib()
@@ -282,7 +284,7 @@ def main():
         if use_dist:
             y = sharded.result(0, 0).cpu().numpy()
         else:
-            y = torch.stack(Y)[:min(2 * depth, args.steps), :, :nrow].cpu().numpy() if args.steps > 0 else None
+            y = torch.stack(Y[:min(2 * depth, args.steps, 4)])[:, :, :nrow].cpu().numpy() if args.steps > 0 else None
         result["finite_output"] = bool(y is not None and np.isfinite(y).all())
         print(json.dumps(result), flush=True)
     if use_dist:
