@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libicebin_hip.so")
 SOURCES = ["capi.hip", "spmm.hip", "prims.hip", "assemble.hip", "gridgen.hip"]
-HEADERS = ["common.h", "prims.h", "assemble.h", "fastasm.inl", os.path.join("..", "..", "include", "icebin_hip.h")]
+HEADERS = ["common.h", "prims.h", "assemble.h", "fastasm.inl", "sweep_kernel.inl", os.path.join("..", "..", "include", "icebin_hip.h")]
 # -ffp-contract=off: the bookkeeping kernels must round every multiply and add separately
 # (bit-exact weights); the SpMM kernels ask for FMA explicitly with fma().
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result"]

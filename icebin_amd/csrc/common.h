@@ -217,6 +217,15 @@ struct ibh_weighted {
     mutable int band_tried = 0;
     mutable int64_t napply = 0;
     mutable ibh::DevBuf<double> band_part;               // per-apply partial sums [2][nvar][nrow padded]
+    // colsweep (EvI, EvX; sweep_kernel.inl): the rows in groups (one GCM cell), the entries of a group in column order in
+    // blocks of 64 columns, built lazily from the CSR (assemble.hip build_sweep_from_csr)
+    mutable int sweep_tried = 0;
+    mutable int32_t sweep_ntask = 0, sweep_nblk = 0, sweep_nprow = 0, sweep_nslot = 0;   // ntask == 0: not built
+    mutable ibh::DevBuf<int32_t> sweep_task_b0, sweep_task_p0, sweep_task_ns, sweep_blk_cnt, sweep_col;
+    mutable ibh::DevBuf<uint32_t> sweep_meta;
+    mutable ibh::DevBuf<double> sweep_v0, sweep_v1;
+    mutable ibh::DevBuf<int32_t> sweep_row_t0, sweep_row_nt, sweep_row_slot;              // [nrow] tasks of the row's group, its slot
+    mutable ibh::DevBuf<double> sweep_part;              // per-apply partial sums [nbatch][nprow][fields padded to 64]
     mutable bool have_rowsum1 = false;
     mutable ibh::DevBuf<int32_t> rowperm;                // rows by descending length (batched rowblock launches)
     mutable bool have_rowperm = false;
@@ -241,6 +250,8 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
 void weighted_reserve(const ibh_weighted *w, int nvar);
 // assemble.hip: the band structure of an E-row matrix from its CSR (same result as building it with the matrix)
 void build_bands_from_csr(const ibh_weighted *w, hipStream_t st);
+// assemble.hip: the column-sweep structure of an E-row matrix from its CSR (sweep_kernel.inl); false: not representable
+bool build_sweep_from_csr(const ibh_weighted *w, hipStream_t st);
 void matvec_legacy_launch(const ibh_weighted *w, const double *dx, int nvar, int64_t ldx, double *dy, int64_t ldy,
                           int ignore_nan, hipStream_t stream);
 void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_in, int64_t lda, const double *T,

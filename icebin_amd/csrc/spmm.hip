@@ -25,6 +25,7 @@
 //    Y stores -- is fully coalesced (512 B per wave-store, non-temporal); the
 //    small X (nf x nA_d) is served from L2.
 #include "common.h"
+#include "sweep_kernel.inl"
 #include <hip/hip_ext.h>
 #include <mutex>
 
@@ -667,15 +668,74 @@ static void launch_rowdual(const ibh_weighted *w, const BatchPtrs &bp, int nbatc
     IBH_HIP(hipGetLastError());
 }
 
-// which kernel serves (w, nvar): 1 rowblock, 2 shortrow, 3 rowdual
+// ---- colsweep (sweep_kernel.inl): E-row matrices, >= 32 fields ------------------------------------------------
+// Y[f, r] = the partial sums of row r's group, task by task in task order (slot = r's position in its group); rows
+// whose group has no entries are 0, rows with wM == 0 hold `fill` (mask_result, IceCoupler.cpp:186-201).
+__global__ __launch_bounds__(256) void sweep_combine_kernel(const double *__restrict__ P, long pstride, long ldp,
+                                                            const int *__restrict__ row_t0, const int *__restrict__ row_nt,
+                                                            const int *__restrict__ row_slot, const int *__restrict__ task_p0,
+                                                            const double *__restrict__ wM, double fill, const BatchPtrs bp, long ldy,
+                                                            int nrow, int nf)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int q = blockIdx.z;
+    if (r >= nrow || f >= nf) return;
+    const int t0 = row_t0[r], nt = row_nt[r], s = row_slot[r];
+    const double *p = P + (long)q * pstride + f;
+    double tot = 0.0;
+    if (nt > 0) tot = p[(long)(task_p0[t0] + s) * ldp];
+    for (int t = t0 + 1; t < t0 + nt; ++t) tot += p[(long)(task_p0[t] + s) * ldp];
+    bp.y[q][(long)f * ldy + r] = wM[r] == 0.0 ? fill : tot;
+}
+static size_t sweep_part_count(const ibh_weighted *w, int nvar, int nbatch) {
+    return (size_t)nbatch * (size_t)w->sweep_nprow * (size_t)(ceil_div(nvar, 64) * 64);
+}
+static void launch_sweep(const ibh_weighted *w, const BatchPtrs &bp, int nbatch, int nvar, long lda, long ldb, double fill,
+                         hipStream_t stream)
+{
+    const int nfb = ceil_div(nvar, 64);
+    const long ldp = (long)nfb * 64, pstride = (long)w->sweep_nprow * ldp;
+    grow_scratch(w->sweep_part, sweep_part_count(w, nvar, nbatch), stream, "column-sweep");
+    SweepView sv{w->sweep_task_b0.p, w->sweep_task_p0.p, w->sweep_task_ns.p, w->sweep_blk_cnt.p, w->sweep_col.p,
+                 w->sweep_meta.p, w->sweep_v0.p, w->sweep_v1.p};
+    SweepBatch sb{};
+    for (int q = 0; q < nbatch; ++q) { sb.x[q] = bp.x[q]; sb.p[q] = w->sweep_part.p + (size_t)q * (size_t)pstride; }
+    const size_t lds = sweep_lds_bytes(w->sweep_nslot);
+    const bool full = nvar % 64 == 0;
+    if (lds > 64 * 1024) {                               // beyond the default dynamic-LDS limit: raise it once per device and variant
+        static std::mutex mu;
+        static bool raised[64][2] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        const int dev = w->device & 63;
+        if (!raised[dev][full]) {
+            if (full) IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_sweep_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            else IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_sweep_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised[dev][full] = true;
+        }
+    }
+    const dim3 grid((unsigned)w->sweep_ntask, (unsigned)nfb, (unsigned)nbatch);
+    hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+    if (full) hipExtLaunchKernelGGL((spmm_sweep_kernel<true, 0>), grid, dim3(SWEEP_NW * 64), lds, stream, ev0, ev1, 0, sv, sb, lda, nvar, w->sweep_nslot, ldp);
+    else hipExtLaunchKernelGGL((spmm_sweep_kernel<false, 0>), grid, dim3(SWEEP_NW * 64), lds, stream, ev0, ev1, 0, sv, sb, lda, nvar, w->sweep_nslot, ldp);
+    hipLaunchKernelGGL(sweep_combine_kernel, dim3((unsigned)ceil_div(w->nrow, 4), (unsigned)nfb, (unsigned)nbatch), dim3(256), 0, stream,
+                       w->sweep_part.p, pstride, ldp, w->sweep_row_t0.p, w->sweep_row_nt.p, w->sweep_row_slot.p, w->sweep_task_p0.p, w->wM.p, fill,
+                       bp, ldb, w->nrow, nvar);
+    IBH_HIP(hipGetLastError());
+}
+
+// which kernel serves (w, nvar): 1 rowblock, 2 shortrow, 3 rowdual, 4 colsweep
 static int pick_kernel(const ibh_weighted *w, int nvar) {
     int kernel = w->kernel_override;
     if (kernel == 0) {
         const double mean = w->nrow ? (double)w->nnz / (double)w->nrow : 0.0;
         kernel = mean >= (double)get_tuning("rowblock_min_mean_nnz", 6) ? 1 : 2;
     }
+    if (kernel == 1 && w->kernel_override == 0 && w->sweep_ntask > 0 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1)) kernel = 4;
     if (kernel == 1 && w->kernel_override == 0 && w->band_n > 0 && nvar >= 4 && get_tuning("rowdual_auto", 1)) kernel = 3;
     if (kernel == 3 && w->band_n == 0) kernel = 1;            // no bands were built for this matrix
+    if (kernel == 4 && w->sweep_ntask == 0) kernel = 1;       // no column-sweep structure
     return kernel;
 }
 struct ShortrowPlan { int fper, g, use_xt, ldt; bool one_entry, big; };
@@ -703,6 +763,7 @@ void weighted_reserve(const ibh_weighted *w, int nvar) {
     if (nvar <= 0) return;
     const int kernel = pick_kernel(w, nvar);
     if (kernel == 3 || w->band_n > 0) grow_scratch(w->band_part, band_part_count(w, nvar, 1), nullptr, "band");
+    if (w->sweep_ntask > 0) grow_scratch(w->sweep_part, sweep_part_count(w, nvar, 1), nullptr, "column-sweep");
     if (kernel == 2 || w->kernel_override == 0) {
         const ShortrowPlan p = shortrow_plan(w, nvar);
         if (p.use_xt && pick_kernel(w, nvar) == 2) grow_scratch(w->xt, (size_t)w->ncol * (size_t)p.ldt, nullptr, "transposed-input");
@@ -716,7 +777,9 @@ void weighted_reserve(const ibh_weighted *w, int nvar) {
 static void launch_one(const ibh_weighted *w, int kernel, const BatchPtrs &bp, int nbatch, int nvar, int64_t lda,
                        int64_t ldb, double fill, hipStream_t stream)
 {
-    if (kernel == 3) {
+    if (kernel == 4) {
+        launch_sweep(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream);
+    } else if (kernel == 3) {
         const long pairs = (long)w->nrow * nvar;
         const int fpw = get_tuning("rowdual_fpw", pairs >= 4 * 8192 ? 4 : pairs >= 2 * 8192 ? 2 : 1);
         if (fpw >= 4) launch_rowdual<4>(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream);
@@ -800,7 +863,16 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
     // classes it lies between and is read once instead of twice): pays for a matrix that meets many field batches, not
     // for the coupler's one build : one apply, hence on the second apply and only for bandwidth-sized work (measured, 64
     // fields: 1 km EvI 292 -> 255 us; at 5 km the extra combine pass costs more than the halved traffic saves, 18.5 -> 21.9).
-    if (w->band_eligible && !w->band_tried && w->band_n == 0 && w->napply >= 1 && w->kernel_override == 0 && nvar >= 4 &&
+    // ... or, with >= 32 fields, the column-sweep structure (sweep_kernel.inl): every X element read once, in whole lines.
+    if (w->band_eligible && !w->sweep_tried && w->sweep_ntask == 0 &&
+        (w->kernel_override == 4 ||
+         (w->kernel_override == 0 && w->napply >= 1 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
+          (double)w->nnz * nvar >= (double)get_tuning("sweep_min_work", 8 << 20)))) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
+        if (cs == hipStreamCaptureStatusNone) { w->sweep_tried = 1; build_sweep_from_csr(w, stream); }
+    }
+    if (w->band_eligible && !w->band_tried && w->band_n == 0 && w->sweep_ntask == 0 && w->napply >= 1 && w->kernel_override == 0 && nvar >= 4 &&
         (double)w->nnz * nvar >= (double)get_tuning("rowdual_min_work", 128 << 20) && get_tuning("rowdual_auto", 1)) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));

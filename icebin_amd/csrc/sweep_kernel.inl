@@ -1,0 +1,191 @@
+// sweep_kernel.inl -- K1d: column-sweep apply for matrices whose rows come in small groups over a shared
+// column range (EvI / EvX: the elevation classes of one GCM cell over that cell's ice cells).
+//
+// Row by row such a matrix reads every X element once per class row it feeds (measured at 1 km: 2.0 GB
+// fetched for 1.03 GB algorithmic); the band structure (rowdual) still wastes 64-byte lines (1.39 x).  Here
+// the columns of a group are swept ONCE, in ascending order, in blocks of 64 of the group's columns (the group's own
+// range is contiguous: consecutive columns; the few cells it shares with a neighbouring GCM cell lie elsewhere and are
+// packed together):
+//   load     the four waves of a workgroup bring the block's X tile (64 fields x 64 columns) in with plain loads, lane =
+//            column -- one instruction = one field plane x 512 contiguous bytes for consecutive columns, whatever the
+//            alignment of the planes (odd leading dimensions) -- and park it in LDS;
+//   consume  transposed: the LANES ARE THE FIELDS, wave w takes columns [16w, 16w+16) of the block.  Which
+//            rows a column feeds is then WAVE-UNIFORM (scalar metadata, broadcast weights), so the accumulators
+//            need no cross-lane reduction at all: one live pair of rows in two registers, spilled to a
+//            per-wave LDS table acc[slot][lane] when the sweep moves on to another pair (neighbouring ice
+//            cells lie between the same two classes for long runs).
+// A task = a run of blocks of one group; it leaves one partial sum per (row of the group, field), and
+// sweep_combine_kernel adds the partials of a row in task order.  Fixed order throughout -> bitwise
+// reproducible; entries are predicated by existence, never multiplied by a padded zero (0*NaN must not
+// leak into a row).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#ifndef IBH_MAX_BATCH
+#define IBH_MAX_BATCH 32
+#endif
+
+namespace ibh {
+
+constexpr int SWEEP_CB = 64;             // columns per block
+constexpr int SWEEP_NW = 4;              // waves per workgroup
+constexpr int SWEEP_TS = SWEEP_CB + 1;   // padded tile row
+// One ITEM per column slot of a block (block b = items [64 b, 64 b + blk_cnt[b])): the column, and the <= 2 entries the
+// column has in this group: meta = slot0 | slot1 << 8 | has0 << 16 | has1 << 17 (0: empty slot), v0, v1 the two values.
+constexpr unsigned SWEEP_HAS0 = 1u << 16, SWEEP_HAS1 = 1u << 17;
+struct SweepView {
+    const int *task_b0;        // [ntask+1] first block of the task
+    const int *task_p0;        // [ntask]   first partial-sum row of the task
+    const int *task_ns;        // [ntask]   rows ("slots") of the task's group
+    const int *blk_cnt;        // [nblk]    items in the block (64 but for the last block of a group)
+    const int *it_col;         // [nblk*64]
+    const unsigned *it_meta;   // [nblk*64]
+    const double *it_v0, *it_v1;
+};
+struct SweepBatch {
+    const double *x[IBH_MAX_BATCH];
+    double *p[IBH_MAX_BATCH];  // partial sums [nprow][ldp]
+};
+
+inline size_t sweep_lds_bytes(int nslot) { return ((size_t)64 * SWEEP_TS + (size_t)SWEEP_NW * nslot * 64 + 2 * SWEEP_CB) * 8; }
+
+__device__ __forceinline__ int sweep_xcd_contiguous(int b, int nb) {
+    const int q = nb >> 3, rem = nb & 7;
+    const int x = b & 7, slot = b >> 3;
+    const int base = x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q;
+    return base + slot;
+}
+
+typedef const unsigned __attribute__((address_space(4))) *sweep_cu32;
+typedef double sweep_double2 __attribute__((ext_vector_type(2)));
+
+// FULL: all 64 fields of the field block exist.  MODE (diagnostics, scratch/sweep_bench.hip): 0 the kernel; 1 tile traffic only;
+// 2 the kernel with s_memtime stamps around its phases (per wave sums to sb.p[1])
+template <bool FULL, int MODE = 0>
+__global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepView sv, const SweepBatch sb, long ldx, int nf,
+                                                                   int nslot_max, long ldp)
+{
+    constexpr int NW = SWEEP_NW, TS = SWEEP_TS, FPW = 64 / NW, CPW = SWEEP_CB / NW;   // planes loaded / columns consumed per wave
+    extern __shared__ double s_mem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *tile = s_mem;                                           // [64 fields][TS]
+    double *acc = s_mem + 64 * TS + wave * (nslot_max * 64);        // [slots][64 fields] per wave
+    const int t = sweep_xcd_contiguous(blockIdx.x, gridDim.x);
+    const int fb = blockIdx.y, q = blockIdx.z;
+    const double *__restrict__ X = sb.x[q];
+    const int b0 = sv.task_b0[t], b1 = sv.task_b0[t + 1];
+    const int ns = min(sv.task_ns[t], nslot_max);
+    for (int s = 0; s < ns; ++s) acc[s * 64 + lane] = 0.0;
+    const int fmine = fb * 64 + wave * FPW;                         // first plane this wave loads
+    const int fld = fb * 64 + lane;                                 // the field this lane accumulates
+    const int nfw = min(FPW, nf - fmine);                           // planes of this wave that exist
+
+    int cur = -1;                         // meta word of the live pair
+    double a0 = 0.0, a1 = 0.0;
+    auto spill = [&]() {
+        if (cur >= 0) {
+            acc[(cur & 255) * 64 + lane] += a0;
+            if (cur & (int)SWEEP_HAS1) acc[((cur >> 8) & 255) * 64 + lane] += a1;
+        }
+    };
+    // One register tile: the loads of block k+1 (X tile and the weights of the wave's 16 columns, lanes 0..15) are in flight
+    // while block k is consumed.  What the consumer needs per column must not cost a VALU -> SGPR transfer (v_readlane:
+    // measured, five of them per column made the consume phase as long as the memory latency it is supposed to hide) nor a
+    // load inside the consume phase (a serial round trip per block):
+    //   * the 16 metadata words come through ONE scalar load, issued after the previous block has been consumed -- it
+    //     lands while the wave waits for the tile;
+    //   * the weights are parked in LDS next to the tile and read back with wave-uniform addresses (a broadcast).
+    // Block sizes travel 64 at a time, one per lane (a descriptor load inside the block loop would be a dependent round
+    // trip in front of every tile load).
+    unsigned long tA = 0, tB = 0, tC = 0, tD = 0, dA = 0, dB = 0, dC = 0, dD = 0, dn = 0;    // MODE 2: phase clocks
+    double xr[FPW], v0 = 0.0, v1 = 0.0;
+    sweep_double2 *wq = reinterpret_cast<sweep_double2 *>(s_mem + 64 * TS + NW * nslot_max * 64) + wave * CPW;    // [CPW] (w0, w1) per wave
+    const int jb = wave * CPW;                              // this wave consumes columns [jb, jb + CPW) of a block
+    for (int kc = b0; kc < b1; kc += 64) {
+        const int nbk = min(64, b1 - kc);
+        const int ni = sv.blk_cnt[kc + min(lane, nbk - 1)];
+        unsigned mk[CPW];
+        // the column list of a block is fetched one block ahead of its tile loads (two ahead of its consumption)
+        auto columns = [&](int k) {
+            const int kk = min(k, nbk - 1);
+            return sv.it_col[(long)(kc + kk) * SWEEP_CB + min(lane, __builtin_amdgcn_readlane(ni, kk) - 1)];   // lanes past the last item repeat it
+        };
+        int cnx = columns(0);
+        auto issue = [&](int k) {
+            // Unconditional loads (exact vmcnt bookkeeping); planes past nf repeat the last plane.
+            const double *xp = X + cnx;
+            cnx = columns(k + 1);
+#pragma unroll
+            for (int i = 0; i < FPW; ++i) xr[i] = xp[(long)(FULL ? fmine + i : min(fmine + i, nf - 1)) * ldx];
+            const long it = (long)(kc + k) * SWEEP_CB + jb + (lane & (CPW - 1));
+            v0 = sv.it_v0[it]; v1 = sv.it_v1[it];
+        };
+        auto meta = [&](int k) {
+            sweep_cu32 mp = (sweep_cu32)(sv.it_meta + (long)(kc + k) * SWEEP_CB + jb);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) mk[j] = mp[j];
+        };
+        issue(0);
+        meta(0);
+        for (int k = 0; k < nbk; ++k) {
+            if (MODE == 2) tA = __builtin_amdgcn_s_memtime();
+            const bool mine = jb < __builtin_amdgcn_readlane(ni, k);         // some of this wave's column slots hold items
+#pragma unroll
+            for (int i = 0; i < FPW; ++i) tile[(wave * FPW + i) * TS + lane] = xr[i];
+            { sweep_double2 w; w.x = v0; w.y = v1; wq[lane & (CPW - 1)] = w; }
+            __syncthreads();
+            if (MODE == 2) { tB = __builtin_amdgcn_s_memtime(); dA += tB - tA; }
+            if (k + 1 < nbk) issue(k + 1);
+            if (MODE == 2) { tC = __builtin_amdgcn_s_memtime(); dB += tC - tB; }
+            if (mine) {
+                double x[CPW];
+#pragma unroll
+                for (int j = 0; j < CPW; ++j) x[j] = tile[lane * TS + jb + j];
+                if (MODE == 1) {
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j) a0 += x[j];
+                    cur = (int)SWEEP_HAS0;
+                } else {
+                    sweep_double2 w[CPW];                   // all weight pairs up front: one LDS round trip, not one per column
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j) w[j] = wq[j];
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j) {
+                        if (__builtin_expect((int)mk[j] != cur, 0)) {       // not the live pair of rows
+                            if (mk[j] == 0) continue;                       // empty slot
+                            spill();                                        // the sweep moves on to another pair
+                            cur = (int)mk[j]; a0 = 0.0; a1 = 0.0;
+                        }
+                        // a column with one entry carries w1 = 0 and no HAS1: a1 then collects garbage (0*NaN) that spill()
+                        // never adds
+                        a0 = fma(w[j].x, x[j], a0);
+                        a1 = fma(w[j].y, x[j], a1);
+                    }
+                }
+            }
+            if (MODE == 2) { tD = __builtin_amdgcn_s_memtime(); dC += tD - tC; }
+            if (k + 1 < nbk) meta(k + 1);
+            __syncthreads();
+            if (MODE == 2) { dD += __builtin_amdgcn_s_memtime() - tD; ++dn; }
+        }
+    }
+    spill();
+    if (MODE == 2 && lane == 0 && sb.p[1]) {
+        unsigned long *dbg = reinterpret_cast<unsigned long *>(sb.p[1]) + ((long)t * NW + wave) * 8;
+        dbg[0] = dA; dbg[1] = dB; dbg[2] = dC; dbg[3] = dD; dbg[4] = dn;
+    }
+    double *__restrict__ P = sb.p[q];
+    const int p0 = sv.task_p0[t];
+    __syncthreads();
+    // the task's partial sums: the waves' tables added in wave order, slots dealt round-robin to the waves
+    const double *acc0 = s_mem + 64 * TS;
+    for (int s = wave; s < ns; s += NW) {
+        double tot = acc0[s * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) tot += acc0[w * (nslot_max * 64) + s * 64 + lane];
+        if (fld < nf) P[(long)(p0 + s) * ldp + fld] = tot;
+    }
+}
+
+}  // namespace ibh

@@ -1,4 +1,5 @@
-"""EvI apply: row-by-row (rowblock) against the band structure (rowdual), single launches and batched, us per 64-field apply."""
+"""EvI apply: row-by-row (rowblock) against the band structure (rowdual) and the column sweep (colsweep), single launches and
+batched, us per 64-field apply.  usage: evi_apply.py config [matrix [sweep_tb]]"""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,9 +9,12 @@ cfg = sys.argv[1]; name = sys.argv[2] if len(sys.argv) > 2 else "EvI"; nf = 64
 g = syn.make_grids(cfg); em = syn.dome_elevmask(g)
 rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em, scale=True, correctA=True)
 L = _capi.lib(); st = torch.cuda.current_stream(); cs = C.c_void_p(st.cuda_stream)
-for mode in ("rowblock", "rowdual"):
+for mode in ("rowblock", "rowdual", "colsweep"):
     icebin_amd.set_tuning("rowdual_auto", 1 if mode == "rowdual" else 0)
+    icebin_amd.set_tuning("sweep_auto", 1 if mode == "colsweep" else 0)
     icebin_amd.set_tuning("rowdual_min_work", 1)
+    icebin_amd.set_tuning("sweep_min_work", 1)
+    if len(sys.argv) > 3: icebin_amd.set_tuning("sweep_tb", int(sys.argv[3]))
     W = rm.matrix(name)
     nrow, ncol, nnz = W.nrow_d, W.ncol_d, W.nnz
     B = 12 * nnz + 4 * (nrow + 1) + 8 * nf * (ncol + nrow)

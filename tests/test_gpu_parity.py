@@ -1301,6 +1301,89 @@ def test_lazy_bands_on_repeated_applies_and_batched_rowdual(variant):
         set_tuning("rowdual_min_work", 128 << 20)
 
 
+@pytest.mark.parametrize("variant", ["sorted", "shuffled", "elev_class", "x_fastest"])
+def test_colsweep_on_grid_variants(variant):
+    """The column-sweep apply (sweep_kernel.inl: lanes = fields, every X element read once) of the E-row matrices against
+    the oracle: full and partial field blocks (64, 40, 130, 7 fields), NaN-carrying fields, fill, both interpolation
+    styles, both ice index orders, shuffled exchange cells (general assembly path)."""
+    kw = dict(sorted={}, shuffled=dict(order="shuffled"), elev_class={}, x_fastest=dict(x_fastest=True))[variant]
+    g = syn.make_grids("g20", **kw)
+    if variant == "elev_class":
+        g["interp_style"] = 1
+    em = syn.dome_elevmask(g)
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    for name in ("EvI", "EvX"):
+        w, o = rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True)
+        w.set_kernel("colsweep")
+        for nvar in (64, 40, 130, 7):
+            x = syn.fields(nvar, w.ncol_d, seed=7 + nvar)
+            x[nvar // 2, ::7] = np.nan              # NaN in a field must stay in the rows that use those cells
+            y = w.apply(x, fill=-1.0, force_conservation=False)
+            assert w.last_kernel() == "colsweep", (name, nvar)
+            assert rel_linf(y, o.apply(x, fill=-1.0, force_conservation=False)) <= FIELD_RTOL, (name, nvar)
+    # other shapes have no column-sweep structure: the request falls back
+    w = rm.matrix("AvI")
+    w.set_kernel("colsweep")
+    w.apply(syn.fields(64, w.ncol_d), force_conservation=False)
+    assert w.last_kernel() == "rowblock"
+
+
+def test_colsweep_lazy_build_batched_and_shared_dims():
+    # with >= 32 fields an E-row matrix that is applied again gets the column-sweep structure from its CSR; batched launches
+    # are bitwise separate applies (also inside a hipGraph once the structure exists); a shared dimE in a permuted order
+    # (rows of one GCM cell no longer consecutive: small groups) stays correct
+    import torch
+    from icebin_amd.linear import set_tuning
+    g, em, mm, rg = setup("g20")
+    set_tuning("sweep_min_work", 1)
+    try:
+        rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+        w, o = rm.matrix("EvI"), rg.matrix_d("EvI", em, scale=True, correctA=True)
+        xs = [torch.from_numpy(syn.fields(64, w.ncol_d, seed=60 + q)).cuda() for q in range(5)]
+        xs[1][2, ::5] = float("nan")
+        y0 = w.apply_device(xs[0], fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert w.last_kernel() == "rowblock"                     # first apply: nothing built yet
+        y1 = w.apply_device(xs[0], fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert w.last_kernel() == "colsweep"                     # second apply: structure built from the CSR
+        ref = o.apply(xs[0].cpu().numpy(), fill=-1.0, force_conservation=False)
+        assert rel_linf(y0.cpu().numpy(), ref) <= FIELD_RTOL and rel_linf(y1.cpu().numpy(), ref) <= FIELD_RTOL
+        sep = [w.apply_device(x, fill=-1.0, force_conservation=False).clone() for x in xs]
+        outs = w.apply_many_device(xs, fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert w.last_kernel() == "colsweep"
+        for a, b, x in zip(outs, sep, xs):
+            assert np.array_equal(a.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
+            assert rel_linf(a.cpu().numpy(), o.apply(x.cpu().numpy(), fill=-1.0, force_conservation=False)) <= FIELD_RTOL
+        # stream capture (scratch is sized: the batch above was larger)
+        out = torch.empty_like(sep[0])
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            w.apply_device(xs[2], out=out, fill=-1.0, force_conservation=False)
+        out.zero_()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), sep[2].cpu().numpy().view(np.uint64))
+        # fewer than 32 fields keep the row-by-row kernels
+        w.apply_device(xs[0][:8].contiguous(), force_conservation=False)
+        assert w.last_kernel() in ("rowblock", "rowdual")
+        # shared dimE in a scrambled order
+        perm = np.random.default_rng(5).permutation(o.dims[0])
+        dimE, odimE = icebin_amd.SparseSet(g["nA"] * 40, perm), orc.SparseSet(g["nA"] * 40, init=perm)
+        w2 = rm.matrix_d("EvI", (dimE, None), scale=True, correctA=True)
+        o2 = rg.matrix_d("EvI", em, (odimE, None), scale=True, correctA=True)
+        assert_same_weighted(w2, o2, "EvI scrambled dimE")
+        w2.set_kernel("colsweep")
+        x = syn.fields(64, w2.ncol_d)
+        y = w2.apply(x, fill=-1.0, force_conservation=False)
+        assert w2.last_kernel() == "colsweep"
+        assert rel_linf(y, o2.apply(x, fill=-1.0, force_conservation=False)) <= FIELD_RTOL
+    finally:
+        set_tuning("sweep_min_work", 8 << 20)
+
+
 @pytest.mark.parametrize("seed", list(range(10)))
 def test_random_exchange_grids_bit_exact(seed):
     """Randomised differential test of the whole assembly against the oracle: arbitrary (iA, iI) pairs
