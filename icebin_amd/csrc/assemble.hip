@@ -1207,218 +1207,187 @@ void build_bands_from_csr(const ibh_weighted *cw, hipStream_t st) {
     w->band_n = nb;
 }
 
-// ---- column-sweep structure (sweep_kernel.inl) of an E-row matrix, from its CSR --------------------------------
-// Rows are grouped into runs of consecutive rows of one GCM cell (<= SWEEP_MAX_SLOTS rows: a longer run is cut -- any
-// partition into runs of consecutive rows is valid, the GCM cell is what makes the groups' columns one compact range).
-// The entries are then ordered by (group, column) -- a stable radix sort, so the <= 2 entries a column has in a group stay
-// in row order -- cut into blocks of 64 of the group's columns, and a group's blocks into tasks of `sweep_tb` blocks.  One
-// item per column: the column, the slots of its entries in the group and exact copies of M's values.  Two host
-// synchronisations (sizes); runs once per matrix, lazily (spmm.hip).
+// ---- column-sweep structure (sweep_kernel.inl) of a matrix with short columns, from its CSR --------------------------
+// ALL columns are swept once, in ascending order.  The entries are ordered by column (stable radix sort: a column's
+// entries stay in row order) and paired up: one ITEM = a column + <= 2 of its entries (an ice cell of an E-row matrix has
+// the two classes of its GCM cell: one item; a cell that straddles two GCM cells has four entries: two items).  64 items
+// make a block, `tb` blocks a task.  A task keeps partial sums for the rows its columns touch: its local row table =
+// the distinct rows of its entries in ascending order ("slots", <= SWEEP_MAX_SLOTS, else tb is halved), found by sorting
+// the (task, row) pairs; the rows of the partial-sum array are exactly those distinct pairs.  The combine lists (which
+// partial rows make up row r, in task order) come from one more sort by row.  Exact copies of M's values throughout.
+// Host synchronisations for sizes; runs once per matrix, lazily (spmm.hip).
 constexpr int SWEEP_MAX_SLOTS = 32;
-__global__ void k_sw_heads(RgView rg, const int64_t *__restrict__ row_s, int nrow, uint32_t *__restrict__ head) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrow) return;
-    long a, hc, ap, hp;
-    e_decode(rg, row_s ? row_s[r] : (int64_t)r, a, hc);      // no table: an identity set
-    int run = 0;                                    // rows of the same GCM cell directly before r
-    for (int q = r - 1; q >= 0 && run < 4096; --q, ++run) {
-        e_decode(rg, row_s ? row_s[q] : (int64_t)q, ap, hp);
-        if (ap != a) break;
-    }
-    head[r] = run % SWEEP_MAX_SLOTS == 0 ? 1u : 0u;
-}
-__global__ void k_sw_groups(const uint32_t *__restrict__ head, const uint32_t *__restrict__ hscan, int nrow, int32_t *__restrict__ grp,
-                            int32_t *__restrict__ gstart, const uint32_t *__restrict__ d_ngroup) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > nrow) return;
-    if (r == nrow) { gstart[*d_ngroup] = nrow; return; }
-    const int g = (int)(hscan[r] + head[r]) - 1;
-    grp[r] = g;
-    if (head[r]) gstart[g] = r;
-}
-__global__ void k_sw_keys(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind, int nrow, const int32_t *__restrict__ grp,
-                          uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, int32_t *__restrict__ erow) {
+__global__ void k_sw_expand(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind, int nrow, uint64_t *__restrict__ keys,
+                            uint32_t *__restrict__ idx, int32_t *__restrict__ erow) {
     const int r = blockIdx.x;                       // one workgroup per row
-    const uint64_t g = (uint64_t)(uint32_t)grp[r] << 32;
-    for (int k = rowptr[r] + threadIdx.x; k < rowptr[r + 1]; k += blockDim.x) { keys[k] = g | (uint32_t)colind[k]; idx[k] = (uint32_t)k; erow[k] = r; }
+    for (int k = rowptr[r] + threadIdx.x; k < rowptr[r + 1]; k += blockDim.x) { keys[k] = (uint64_t)(uint32_t)colind[k]; idx[k] = (uint32_t)k; erow[k] = r; }
 }
-// first entries of a (group, column): the items; counted per group
-__global__ void k_sw_firsts(const uint64_t *__restrict__ keys, long n, uint32_t *__restrict__ fc, uint32_t *__restrict__ ng) {
+// per sorted entry: is it the first of its column (-> colstart), then: does it open an item (even position in its column)
+__global__ void k_sw_colstart(const uint64_t *__restrict__ keys, long n, int32_t *__restrict__ colstart) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const bool first = i == 0 || keys[i] != keys[i - 1];
-    fc[i] = first ? 1u : 0u;
-    if (first) atomicAdd(&ng[keys[i] >> 32], 1u);
+    if (i == 0 || keys[i] != keys[i - 1]) colstart[(uint32_t)keys[i]] = (int32_t)i;
 }
-__global__ void k_sw_group_blocks(const uint32_t *__restrict__ ng, int ngroup, uint32_t *__restrict__ nbg) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < ngroup) nbg[g] = (ng[g] + 63u) >> 6;
-}
-// item (rank of the column among its group's columns) -> block = blkbase[group] + rank / 64, slot = rank % 64
-__global__ void k_sw_items(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ fc,
-                           const uint32_t *__restrict__ fscan, long n, const int32_t *__restrict__ erow, const int32_t *__restrict__ gstart,
-                           const uint32_t *__restrict__ ng, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ blkbase,
-                           const double *__restrict__ val, int32_t *__restrict__ it_col, uint32_t *__restrict__ meta, double *__restrict__ v0,
-                           double *__restrict__ v1, int32_t *__restrict__ blk_cnt, int32_t *__restrict__ blk_g, uint32_t *__restrict__ d_bad) {
+__global__ void k_sw_itemheads(const uint64_t *__restrict__ keys, long n, const int32_t *__restrict__ colstart, uint32_t *__restrict__ ih) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !fc[i]) return;
-    const uint64_t k = keys[i];
-    const int g = (int)(k >> 32);
-    const uint32_t rk = fscan[i] - g0[g];
-    const int b = (int)(blkbase[g] + (rk >> 6));
-    const long it = (long)b * 64 + (long)(rk & 63u);
-    if ((rk & 63u) == 0) { blk_g[b] = g; blk_cnt[b] = (int32_t)min(64u, ng[g] - rk); }
-    const uint32_t s0 = (uint32_t)(erow[idx[i]] - gstart[g]);
+    if (i >= n) return;
+    ih[i] = ((i - colstart[(uint32_t)keys[i]]) & 1) == 0 ? 1u : 0u;
+}
+// (task, row) of every sorted entry; payload = the entry's sorted position
+__global__ void k_sw_taskrow(const uint32_t *__restrict__ ih, const uint32_t *__restrict__ iscan, const uint32_t *__restrict__ idx, long n,
+                             const int32_t *__restrict__ erow, int items_per_task, uint64_t *__restrict__ tk, uint32_t *__restrict__ tv) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t item = iscan[i] + ih[i] - 1;
+    tk[i] = ((uint64_t)(item / (uint32_t)items_per_task) << 32) | (uint32_t)erow[idx[i]];
+    tv[i] = (uint32_t)i;
+}
+__global__ void k_sw_uniq(const uint64_t *__restrict__ tk, long n, uint32_t *__restrict__ u) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    u[k] = (k == 0 || tk[k] != tk[k - 1]) ? 1u : 0u;
+}
+// task_p0[t] = index of the task's first distinct (task, row) pair; uniq_row / uniq list for the combine
+__global__ void k_sw_taskfirst(const uint64_t *__restrict__ tk, const uint32_t *__restrict__ u, const uint32_t *__restrict__ uscan, long n,
+                               int32_t *__restrict__ task_p0, int32_t *__restrict__ urow) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || !u[k]) return;
+    const uint32_t t = (uint32_t)(tk[k] >> 32);
+    urow[uscan[k]] = (int32_t)(uint32_t)tk[k];
+    if (k == 0 || (uint32_t)(tk[k - 1] >> 32) != t) task_p0[t] = (int32_t)uscan[k];
+}
+__global__ void k_sw_slots(const uint64_t *__restrict__ tk, const uint32_t *__restrict__ tv, const uint32_t *__restrict__ u,
+                           const uint32_t *__restrict__ uscan, long n, const int32_t *__restrict__ task_p0, uint8_t *__restrict__ eslot) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t t = (uint32_t)(tk[k] >> 32);
+    eslot[tv[k]] = (uint8_t)(uscan[k] + u[k] - 1 - (uint32_t)task_p0[t]);
+}
+__global__ void k_sw_task_ns(const int32_t *__restrict__ task_p0, int ntask, int nuniq, int32_t *__restrict__ task_ns, int32_t *__restrict__ task_b0,
+                             int tb, int nblk, uint32_t *__restrict__ d_maxns) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > ntask) return;
+    task_b0[t] = min(t * tb, nblk);
+    if (t == ntask) return;
+    const int ns = (t + 1 < ntask ? task_p0[t + 1] : nuniq) - task_p0[t];
+    task_ns[t] = ns;
+    atomicMax(d_maxns, (uint32_t)ns);
+}
+__global__ void k_sw_items(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ ih,
+                           const uint32_t *__restrict__ iscan, long n, const uint8_t *__restrict__ eslot, const double *__restrict__ val,
+                           int32_t *__restrict__ it_col, uint32_t *__restrict__ meta, double *__restrict__ v0, double *__restrict__ v1) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !ih[i]) return;
+    const long it = (long)iscan[i];
+    const uint32_t s0 = eslot[i];
     uint32_t m = s0 | (s0 << 8) | SWEEP_HAS0;
     double w1 = 0.0;
-    if (i + 1 < n && keys[i + 1] == k) {
-        m = s0 | ((uint32_t)(erow[idx[i + 1]] - gstart[g]) << 8) | SWEEP_HAS0 | SWEEP_HAS1;
+    if (i + 1 < n && keys[i + 1] == keys[i]) {      // the odd entry of the pair
+        m = s0 | ((uint32_t)eslot[i + 1] << 8) | SWEEP_HAS0 | SWEEP_HAS1;
         w1 = val[idx[i + 1]];
-        if (i + 2 < n && keys[i + 2] == k) *d_bad = 1u;      // three entries of one column in one group: not representable
     }
-    it_col[it] = (int32_t)(uint32_t)k; meta[it] = m; v0[it] = val[idx[i]]; v1[it] = w1;
+    it_col[it] = (int32_t)(uint32_t)keys[i]; meta[it] = m; v0[it] = val[idx[i]]; v1[it] = w1;
 }
-// task heads: every tb-th block of a group, counted from the group's first block
-__global__ void k_sw_taskheads_fix(const int32_t *__restrict__ blk_g, int nblk, int tb, uint32_t *__restrict__ th, const int32_t *__restrict__ gfirst) {
+__global__ void k_sw_blkcnt(int nblk, long nitems, int32_t *__restrict__ blk_cnt) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblk) return;
-    th[b] = (b - gfirst[blk_g[b]]) % tb == 0 ? 1u : 0u;
+    if (b < nblk) blk_cnt[b] = (int32_t)min(64l, nitems - 64l * b);
 }
-__global__ void k_sw_gfirst(const int32_t *__restrict__ blk_g, int nblk, int32_t *__restrict__ gfirst) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblk) return;
-    if (b == 0 || blk_g[b - 1] != blk_g[b]) gfirst[blk_g[b]] = b;
-}
-__global__ void k_sw_tasks(const uint32_t *__restrict__ th, const uint32_t *__restrict__ tscan, const int32_t *__restrict__ blk_g, int nblk,
-                           const int32_t *__restrict__ gstart, int32_t *__restrict__ task_b0, uint32_t *__restrict__ task_ns,
-                           int32_t *__restrict__ task_g, const uint32_t *__restrict__ d_ntask) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nblk) return;
-    if (b == nblk) { task_b0[*d_ntask] = nblk; return; }
-    if (!th[b]) return;
-    const int t = (int)tscan[b], g = blk_g[b];
-    task_b0[t] = b; task_g[t] = g; task_ns[t] = (uint32_t)(gstart[g + 1] - gstart[g]);
-}
-__global__ void k_sw_group_tasks(const int32_t *__restrict__ task_g, int ntask, int32_t *__restrict__ gt0, int32_t *__restrict__ gtn) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntask) return;
-    const int g = task_g[t];
-    if (t == 0 || task_g[t - 1] != g) gt0[g] = t;
-    atomicAdd(&gtn[g], 1);
-}
-__global__ void k_sw_rows(const int32_t *__restrict__ grp, const int32_t *__restrict__ gstart, const int32_t *__restrict__ gt0,
-                          const int32_t *__restrict__ gtn, int nrow, int32_t *__restrict__ row_t0, int32_t *__restrict__ row_nt,
-                          int32_t *__restrict__ row_slot) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrow) return;
-    const int g = grp[r];
-    row_t0[r] = gt0[g]; row_nt[r] = gtn[g]; row_slot[r] = r - gstart[g];
+__global__ void k_sw_combkeys(const int32_t *__restrict__ urow, int nuniq, uint64_t *__restrict__ ck, uint32_t *__restrict__ cv) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nuniq) { ck[k] = (uint64_t)(uint32_t)urow[k]; cv[k] = (uint32_t)k; }
 }
 bool build_sweep_from_csr(const ibh_weighted *cw, hipStream_t st) {
     ibh_weighted *w = const_cast<ibh_weighted *>(cw);
-    if (!w->band_eligible || w->sweep_ntask > 0 || w->nnz == 0 || w->nrow == 0 || w->nnz >= (1ll << 31) - 64) return false;
-    const ibh_sparse_set *rset = w->dims[0];
-    if (!rset) return false;
+    if (w->sweep_ntask > 0 || w->nnz == 0 || w->nrow == 0 || w->nnz >= (1ll << 31) - 64) return false;
     Arena &A = arena();
     A.reset();
-    const int T = 256, nrow = w->nrow;
+    const int T = 256, nrow = w->nrow, ncol = w->ncol;
     const long nnz = w->nnz;
-    RgView rg{};
-    rg.sA = w->band_sA; rg.sHC = w->band_sHC;
-    // the row keys (dense -> sparse E index): on the device after a build; a caller-supplied set may only have its host copy
-    const int64_t *row_s = nullptr;
-    if (!rset->identity) {
-        if (rset->dev_n >= nrow) row_s = rset->dev.p;
-        else {
-            rset->ensure_host();
-            int64_t *tmp = A.get<int64_t>((size_t)nrow);
-            IBH_HIP(hipMemcpyAsync(tmp, rset->host.data(), sizeof(int64_t) * (size_t)nrow, hipMemcpyHostToDevice, st));
-            IBH_HIP(hipStreamSynchronize(st));      // pageable source
-            row_s = tmp;
-        }
-    }
-    // groups
-    uint32_t *head = A.get<uint32_t>((size_t)nrow), *hscan = A.get<uint32_t>((size_t)nrow), *d_cnt = A.get<uint32_t>(8);
-    int32_t *grp = A.get<int32_t>((size_t)nrow), *gstart = A.get<int32_t>((size_t)nrow + 1);
+    uint32_t *d_cnt = A.get<uint32_t>(8);
     IBH_HIP(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * 8, st));
-    hipLaunchKernelGGL(k_sw_heads, dim3(ceil_div(nrow, T)), dim3(T), 0, st, rg, row_s, nrow, head);
-    exclusive_scan_u32(head, hscan, (size_t)nrow, d_cnt + 0, st);
-    hipLaunchKernelGGL(k_sw_groups, dim3(ceil_div(nrow + 1, T)), dim3(T), 0, st, head, hscan, nrow, grp, gstart, d_cnt + 0);
-    // entries by (group, column)
+    // entries by column
     uint64_t *keys = A.get<uint64_t>((size_t)nnz), *keys2 = A.get<uint64_t>((size_t)nnz);
     uint32_t *idx = A.get<uint32_t>((size_t)nnz), *idx2 = A.get<uint32_t>((size_t)nnz);
     int32_t *erow = A.get<int32_t>((size_t)nnz);
-    hipLaunchKernelGGL(k_sw_keys, dim3(nrow), dim3(T), 0, st, w->rowptr.p, w->colind.p, nrow, grp, keys, idx, erow);
-    KeyField kf[2] = {{0, bits_for((uint64_t)w->ncol)}, {32, bits_for((uint64_t)nrow)}};      // groups <= rows
-    if (radix_sort_pairs(keys, keys2, idx, idx2, (size_t)nnz, kf, 2, st)) { std::swap(keys, keys2); std::swap(idx, idx2); }
-    uint32_t *fc = A.get<uint32_t>((size_t)nnz), *fscan = A.get<uint32_t>((size_t)nnz);
-    // group sizes are needed on the device before the group count is known on the host: tables by row (groups <= rows)
-    uint32_t *ng = A.get<uint32_t>((size_t)nrow + 1), *g0 = A.get<uint32_t>((size_t)nrow + 1);
-    uint32_t *nbg = A.get<uint32_t>((size_t)nrow + 1), *blkbase = A.get<uint32_t>((size_t)nrow + 1);
-    IBH_HIP(hipMemsetAsync(ng, 0, sizeof(uint32_t) * ((size_t)nrow + 1), st));
-    hipLaunchKernelGGL(k_sw_firsts, dim3(ceil_div(nnz, T)), dim3(T), 0, st, keys, nnz, fc, ng);
-    exclusive_scan_u32(fc, fscan, (size_t)nnz, nullptr, st);
-    exclusive_scan_u32(ng, g0, (size_t)nrow, nullptr, st);
-    hipLaunchKernelGGL(k_sw_group_blocks, dim3(ceil_div(nrow, T)), dim3(T), 0, st, ng, nrow, nbg);
-    exclusive_scan_u32(nbg, blkbase, (size_t)nrow, d_cnt + 1, st);
+    hipLaunchKernelGGL(k_sw_expand, dim3(nrow), dim3(T), 0, st, w->rowptr.p, w->colind.p, nrow, keys, idx, erow);
+    KeyField kf{0, bits_for((uint64_t)ncol)};
+    if (kf.nbits > 0 && radix_sort_pairs(keys, keys2, idx, idx2, (size_t)nnz, &kf, 1, st)) { std::swap(keys, keys2); std::swap(idx, idx2); }
+    // items: the entries of a column in pairs
+    int32_t *colstart = A.get<int32_t>((size_t)ncol);
+    uint32_t *ih = A.get<uint32_t>((size_t)nnz), *iscan = A.get<uint32_t>((size_t)nnz);
+    hipLaunchKernelGGL(k_sw_colstart, dim3(ceil_div(nnz, T)), dim3(T), 0, st, keys, nnz, colstart);
+    hipLaunchKernelGGL(k_sw_itemheads, dim3(ceil_div(nnz, T)), dim3(T), 0, st, keys, nnz, colstart, ih);
+    exclusive_scan_u32(ih, iscan, (size_t)nnz, d_cnt + 0, st);
     uint32_t h[8];
     readback_sync(h, d_cnt, sizeof(h), st);
-    const int ngroup = (int)h[0];
-    const long nblk = (long)h[1];
-    if (nblk * 64 >= (1ll << 31) || nblk <= 0) return false;
-    // blocks and items
+    const long nitems = (long)h[0];
+    const int nblk = (int)((nitems + 63) / 64);
+    if (nitems <= 0 || (long)nblk * 64 >= (1ll << 31)) return false;
+    // tasks and their local row tables; tb halves until every task touches <= SWEEP_MAX_SLOTS rows
+    int tb = get_tuning("sweep_tb", 0);
+    if (tb <= 0) {                                  // the largest power of two <= 16 that leaves >= 1024 tasks (two per CU and round: measured at
+        tb = 16;                                    // 1 km, 64 fields: tb 2 / 4 / 6 / 8 -> 276 / 234 / 230 / 214 us; beyond 8 the row tables outgrow the LDS)
+        while (tb > 1 && nblk / tb < 1024) tb /= 2;
+    }
+    uint64_t *tk = A.get<uint64_t>((size_t)nnz), *tk2 = A.get<uint64_t>((size_t)nnz);
+    uint32_t *tv = A.get<uint32_t>((size_t)nnz), *tv2 = A.get<uint32_t>((size_t)nnz);
+    uint32_t *u = A.get<uint32_t>((size_t)nnz), *uscan = A.get<uint32_t>((size_t)nnz);
+    int32_t *urow = A.get<int32_t>((size_t)nnz);
+    uint8_t *eslot = A.get<uint8_t>((size_t)nnz);
+    int ntask = 0, nuniq = 0, maxns = 0;
+    for (;; tb /= 2) {
+        if (tb < 1) return false;                   // 64 items touch more rows than the kernel's table holds
+        ntask = ceil_div(nblk, tb);
+        uint64_t *a = tk, *b2 = tk2;
+        uint32_t *av = tv, *bv = tv2;
+        hipLaunchKernelGGL(k_sw_taskrow, dim3(ceil_div(nnz, T)), dim3(T), 0, st, ih, iscan, idx, nnz, erow, 64 * tb, a, av);
+        KeyField tf[2] = {{0, bits_for((uint64_t)nrow)}, {32, bits_for((uint64_t)ntask)}};
+        if (radix_sort_pairs(a, b2, av, bv, (size_t)nnz, tf, 2, st)) { std::swap(a, b2); std::swap(av, bv); }
+        hipLaunchKernelGGL(k_sw_uniq, dim3(ceil_div(nnz, T)), dim3(T), 0, st, a, nnz, u);
+        exclusive_scan_u32(u, uscan, (size_t)nnz, d_cnt + 1, st);
+        w->sweep_task_b0.alloc((size_t)ntask + 1); w->sweep_task_p0.alloc((size_t)ntask + 1); w->sweep_task_ns.alloc((size_t)ntask + 1);
+        hipLaunchKernelGGL(k_sw_taskfirst, dim3(ceil_div(nnz, T)), dim3(T), 0, st, a, u, uscan, nnz, w->sweep_task_p0.p, urow);
+        readback_sync(h, d_cnt, sizeof(h), st);
+        nuniq = (int)h[1];
+        IBH_HIP(hipMemsetAsync(d_cnt + 2, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_sw_task_ns, dim3(ceil_div(ntask + 1, T)), dim3(T), 0, st, w->sweep_task_p0.p, ntask, nuniq, w->sweep_task_ns.p,
+                           w->sweep_task_b0.p, tb, nblk, d_cnt + 2);
+        readback_sync(h, d_cnt, sizeof(h), st);
+        maxns = (int)h[2];
+        // LDS per workgroup = tile (33 KB) + 4 waves x maxns x 512 B: <= 22 slots keep two workgroups on a CU, <= 9 three
+        const int soft = get_tuning("sweep_soft_slots", 22);
+        if (getenv("IBH_SWEEP_DEBUG")) fprintf(stderr, "sweep: nitems %ld nblk %d tb %d ntask %d nuniq %d maxns %d\n", nitems, nblk, tb, ntask, nuniq, maxns);
+        if (maxns <= SWEEP_MAX_SLOTS && (maxns <= soft || tb == 1)) {
+            hipLaunchKernelGGL(k_sw_slots, dim3(ceil_div(nnz, T)), dim3(T), 0, st, a, av, u, uscan, nnz, w->sweep_task_p0.p, eslot);
+            break;
+        }
+    }
+    // items
     w->sweep_blk_cnt.alloc((size_t)nblk); w->sweep_col.alloc((size_t)nblk * 64);
     w->sweep_meta.alloc((size_t)nblk * 64); w->sweep_v0.alloc((size_t)nblk * 64); w->sweep_v1.alloc((size_t)nblk * 64);
-    int32_t *blk_g = A.get<int32_t>((size_t)nblk);
     IBH_HIP(hipMemsetAsync(w->sweep_col.p, 0, sizeof(int32_t) * (size_t)nblk * 64, st));
     IBH_HIP(hipMemsetAsync(w->sweep_meta.p, 0, sizeof(uint32_t) * (size_t)nblk * 64, st));
     IBH_HIP(hipMemsetAsync(w->sweep_v0.p, 0, sizeof(double) * (size_t)nblk * 64, st));
     IBH_HIP(hipMemsetAsync(w->sweep_v1.p, 0, sizeof(double) * (size_t)nblk * 64, st));
-    hipLaunchKernelGGL(k_sw_items, dim3(ceil_div(nnz, T)), dim3(T), 0, st, keys, idx, fc, fscan, nnz, erow, gstart, ng, g0, blkbase, w->val.p,
-                       w->sweep_col.p, w->sweep_meta.p, w->sweep_v0.p, w->sweep_v1.p, w->sweep_blk_cnt.p, blk_g, d_cnt + 2);
-    // tasks
-    int tb = get_tuning("sweep_tb", 0);
-    if (tb <= 0) {                                  // enough tasks for ~6 rounds of the chip's 768 resident workgroups, <= 16 blocks each
-        tb = (int)(nblk / (6 * 768));
-        tb = tb < 1 ? 1 : tb > 16 ? 16 : tb;
-    }
-    int32_t *gfirst = A.get<int32_t>((size_t)ngroup + 1);
-    uint32_t *th = A.get<uint32_t>((size_t)nblk), *tscan = A.get<uint32_t>((size_t)nblk);
-    hipLaunchKernelGGL(k_sw_gfirst, dim3(ceil_div(nblk, T)), dim3(T), 0, st, blk_g, (int)nblk, gfirst);
-    hipLaunchKernelGGL(k_sw_taskheads_fix, dim3(ceil_div(nblk, T)), dim3(T), 0, st, blk_g, (int)nblk, tb, th, gfirst);
-    exclusive_scan_u32(th, tscan, (size_t)nblk, d_cnt + 3, st);
-    w->sweep_task_b0.alloc((size_t)nblk + 1); w->sweep_task_p0.alloc((size_t)nblk + 1); w->sweep_task_ns.alloc((size_t)nblk + 1);   // ntask <= nblk
-    int32_t *task_g = A.get<int32_t>((size_t)nblk + 1);
-    IBH_HIP(hipMemsetAsync(w->sweep_task_ns.p, 0, sizeof(int32_t) * ((size_t)nblk + 1), st));
-    hipLaunchKernelGGL(k_sw_tasks, dim3(ceil_div(nblk + 1, T)), dim3(T), 0, st, th, tscan, blk_g, (int)nblk, gstart, w->sweep_task_b0.p,
-                       reinterpret_cast<uint32_t *>(w->sweep_task_ns.p), task_g, d_cnt + 3);
-    readback_sync(h, d_cnt, sizeof(h), st);
-    const int ntask = (int)h[3];
-    if (h[2] != 0 || ntask <= 0) {                  // some column has three entries in one group
-        w->sweep_meta.release(); w->sweep_v0.release(); w->sweep_v1.release(); w->sweep_col.release();
-        return false;
-    }
-    exclusive_scan_u32(reinterpret_cast<uint32_t *>(w->sweep_task_ns.p), reinterpret_cast<uint32_t *>(w->sweep_task_p0.p), (size_t)ntask, d_cnt + 4, st);
-    int32_t *gt0 = A.get<int32_t>((size_t)ngroup), *gtn = A.get<int32_t>((size_t)ngroup);
-    IBH_HIP(hipMemsetAsync(gt0, 0, sizeof(int32_t) * (size_t)ngroup, st));
-    IBH_HIP(hipMemsetAsync(gtn, 0, sizeof(int32_t) * (size_t)ngroup, st));
-    hipLaunchKernelGGL(k_sw_group_tasks, dim3(ceil_div(ntask, T)), dim3(T), 0, st, task_g, ntask, gt0, gtn);
-    w->sweep_row_t0.alloc((size_t)nrow); w->sweep_row_nt.alloc((size_t)nrow); w->sweep_row_slot.alloc((size_t)nrow);
-    hipLaunchKernelGGL(k_sw_rows, dim3(ceil_div(nrow, T)), dim3(T), 0, st, grp, gstart, gt0, gtn, nrow, w->sweep_row_t0.p, w->sweep_row_nt.p,
-                       w->sweep_row_slot.p);
+    hipLaunchKernelGGL(k_sw_items, dim3(ceil_div(nnz, T)), dim3(T), 0, st, keys, idx, ih, iscan, nnz, eslot, w->val.p, w->sweep_col.p,
+                       w->sweep_meta.p, w->sweep_v0.p, w->sweep_v1.p);
+    hipLaunchKernelGGL(k_sw_blkcnt, dim3(ceil_div(nblk, T)), dim3(T), 0, st, nblk, nitems, w->sweep_blk_cnt.p);
+    // combine lists: the distinct (task, row) pairs by row, tasks ascending inside a row
+    uint64_t *ck = A.get<uint64_t>((size_t)nuniq), *ck2 = A.get<uint64_t>((size_t)nuniq);
+    uint32_t *cv = A.get<uint32_t>((size_t)nuniq), *cv2 = A.get<uint32_t>((size_t)nuniq);
+    hipLaunchKernelGGL(k_sw_combkeys, dim3(ceil_div(nuniq, T)), dim3(T), 0, st, urow, nuniq, ck, cv);
+    KeyField cf{0, bits_for((uint64_t)nrow)};
+    if (cf.nbits > 0 && radix_sort_pairs(ck, ck2, cv, cv2, (size_t)nuniq, &cf, 1, st)) { std::swap(ck, ck2); std::swap(cv, cv2); }
+    int32_t *srow = A.get<int32_t>((size_t)nuniq);
+    hipLaunchKernelGGL(k_keys_to_i32, dim3(ceil_div(nuniq, T)), dim3(T), 0, st, ck, (long)nuniq, srow);
+    w->sweep_comb_ptr.alloc((size_t)nrow + 1); w->sweep_comb_p.alloc((size_t)nuniq);
+    rowptr_from_rows(srow, (long)nuniq, nrow, w->sweep_comb_ptr.p, st);
+    IBH_HIP(hipMemcpyAsync(w->sweep_comb_p.p, cv, sizeof(uint32_t) * (size_t)nuniq, hipMemcpyDeviceToDevice, st));
     IBH_HIP(hipGetLastError());
-    readback_sync(h, d_cnt, sizeof(h), st);
-    w->sweep_nprow = (int32_t)h[4];
-    w->sweep_nblk = (int32_t)nblk;
-    w->sweep_nslot = SWEEP_MAX_SLOTS;               // refined below: the largest group
-    {
-        // the largest group decides the LDS table of the kernel
-        std::vector<int32_t> ns((size_t)ntask);
-        IBH_HIP(hipMemcpy(ns.data(), w->sweep_task_ns.p, sizeof(int32_t) * (size_t)ntask, hipMemcpyDeviceToHost));
-        int mx = 1;
-        for (int v : ns) mx = std::max(mx, v);
-        w->sweep_nslot = mx;
-    }
+    IBH_HIP(hipStreamSynchronize(st));              // the arena is reused by the next build
+    w->sweep_nprow = nuniq;
+    w->sweep_nblk = nblk;
+    w->sweep_nslot = maxns < 1 ? 1 : maxns;
     w->sweep_ntask = ntask;
     return true;
 }

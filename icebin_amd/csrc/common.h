@@ -217,14 +217,14 @@ struct ibh_weighted {
     mutable int band_tried = 0;
     mutable int64_t napply = 0;
     mutable ibh::DevBuf<double> band_part;               // per-apply partial sums [2][nvar][nrow padded]
-    // colsweep (EvI, EvX; sweep_kernel.inl): the rows in groups (one GCM cell), the entries of a group in column order in
-    // blocks of 64 columns, built lazily from the CSR (assemble.hip build_sweep_from_csr)
+    // colsweep (EvI, EvX; sweep_kernel.inl): the entries in column order, paired per column into items, 64 items a block,
+    // tb blocks a task with its local row table; built lazily from the CSR (assemble.hip build_sweep_from_csr)
     mutable int sweep_tried = 0;
     mutable int32_t sweep_ntask = 0, sweep_nblk = 0, sweep_nprow = 0, sweep_nslot = 0;   // ntask == 0: not built
     mutable ibh::DevBuf<int32_t> sweep_task_b0, sweep_task_p0, sweep_task_ns, sweep_blk_cnt, sweep_col;
     mutable ibh::DevBuf<uint32_t> sweep_meta;
     mutable ibh::DevBuf<double> sweep_v0, sweep_v1;
-    mutable ibh::DevBuf<int32_t> sweep_row_t0, sweep_row_nt, sweep_row_slot;              // [nrow] tasks of the row's group, its slot
+    mutable ibh::DevBuf<int32_t> sweep_comb_ptr, sweep_comb_p;     // [nrow+1], [nprow]: the partial-sum rows that make up row r, in task order
     mutable ibh::DevBuf<double> sweep_part;              // per-apply partial sums [nbatch][nprow][fields padded to 64]
     mutable bool have_rowsum1 = false;
     mutable ibh::DevBuf<int32_t> rowperm;                // rows by descending length (batched rowblock launches)

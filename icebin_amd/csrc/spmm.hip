@@ -669,11 +669,10 @@ static void launch_rowdual(const ibh_weighted *w, const BatchPtrs &bp, int nbatc
 }
 
 // ---- colsweep (sweep_kernel.inl): E-row matrices, >= 32 fields ------------------------------------------------
-// Y[f, r] = the partial sums of row r's group, task by task in task order (slot = r's position in its group); rows
-// whose group has no entries are 0, rows with wM == 0 hold `fill` (mask_result, IceCoupler.cpp:186-201).
+// Y[f, r] = the partial sums of the tasks that touch row r (comb_p[comb_ptr[r] .. comb_ptr[r+1])), in task order; rows no
+// task touches are 0, rows with wM == 0 hold `fill` (mask_result, IceCoupler.cpp:186-201).
 __global__ __launch_bounds__(256) void sweep_combine_kernel(const double *__restrict__ P, long pstride, long ldp,
-                                                            const int *__restrict__ row_t0, const int *__restrict__ row_nt,
-                                                            const int *__restrict__ row_slot, const int *__restrict__ task_p0,
+                                                            const int *__restrict__ comb_ptr, const int *__restrict__ comb_p,
                                                             const double *__restrict__ wM, double fill, const BatchPtrs bp, long ldy,
                                                             int nrow, int nf)
 {
@@ -681,11 +680,11 @@ __global__ __launch_bounds__(256) void sweep_combine_kernel(const double *__rest
     const int f = blockIdx.y * 64 + (threadIdx.x & 63);
     const int q = blockIdx.z;
     if (r >= nrow || f >= nf) return;
-    const int t0 = row_t0[r], nt = row_nt[r], s = row_slot[r];
+    const int k0 = comb_ptr[r], k1 = comb_ptr[r + 1];
     const double *p = P + (long)q * pstride + f;
     double tot = 0.0;
-    if (nt > 0) tot = p[(long)(task_p0[t0] + s) * ldp];
-    for (int t = t0 + 1; t < t0 + nt; ++t) tot += p[(long)(task_p0[t] + s) * ldp];
+    if (k0 < k1) tot = p[(long)comb_p[k0] * ldp];
+    for (int k = k0 + 1; k < k1; ++k) tot += p[(long)comb_p[k] * ldp];
     bp.y[q][(long)f * ldy + r] = wM[r] == 0.0 ? fill : tot;
 }
 static size_t sweep_part_count(const ibh_weighted *w, int nvar, int nbatch) {
@@ -720,7 +719,7 @@ static void launch_sweep(const ibh_weighted *w, const BatchPtrs &bp, int nbatch,
     if (full) hipExtLaunchKernelGGL((spmm_sweep_kernel<true, 0>), grid, dim3(SWEEP_NW * 64), lds, stream, ev0, ev1, 0, sv, sb, lda, nvar, w->sweep_nslot, ldp);
     else hipExtLaunchKernelGGL((spmm_sweep_kernel<false, 0>), grid, dim3(SWEEP_NW * 64), lds, stream, ev0, ev1, 0, sv, sb, lda, nvar, w->sweep_nslot, ldp);
     hipLaunchKernelGGL(sweep_combine_kernel, dim3((unsigned)ceil_div(w->nrow, 4), (unsigned)nfb, (unsigned)nbatch), dim3(256), 0, stream,
-                       w->sweep_part.p, pstride, ldp, w->sweep_row_t0.p, w->sweep_row_nt.p, w->sweep_row_slot.p, w->sweep_task_p0.p, w->wM.p, fill,
+                       w->sweep_part.p, pstride, ldp, w->sweep_comb_ptr.p, w->sweep_comb_p.p, w->wM.p, fill,
                        bp, ldb, w->nrow, nvar);
     IBH_HIP(hipGetLastError());
 }
@@ -728,6 +727,7 @@ static void launch_sweep(const ibh_weighted *w, const BatchPtrs &bp, int nbatch,
 // which kernel serves (w, nvar): 1 rowblock, 2 shortrow, 3 rowdual, 4 colsweep
 static int pick_kernel(const ibh_weighted *w, int nvar) {
     int kernel = w->kernel_override;
+    if (kernel == 4 && w->sweep_ntask == 0) kernel = 0;       // no column-sweep structure: the automatic choice
     if (kernel == 0) {
         const double mean = w->nrow ? (double)w->nnz / (double)w->nrow : 0.0;
         kernel = mean >= (double)get_tuning("rowblock_min_mean_nnz", 6) ? 1 : 2;
@@ -735,7 +735,6 @@ static int pick_kernel(const ibh_weighted *w, int nvar) {
     if (kernel == 1 && w->kernel_override == 0 && w->sweep_ntask > 0 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1)) kernel = 4;
     if (kernel == 1 && w->kernel_override == 0 && w->band_n > 0 && nvar >= 4 && get_tuning("rowdual_auto", 1)) kernel = 3;
     if (kernel == 3 && w->band_n == 0) kernel = 1;            // no bands were built for this matrix
-    if (kernel == 4 && w->sweep_ntask == 0) kernel = 1;       // no column-sweep structure
     return kernel;
 }
 struct ShortrowPlan { int fper, g, use_xt, ldt; bool one_entry, big; };
@@ -864,10 +863,10 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
     // for the coupler's one build : one apply, hence on the second apply and only for bandwidth-sized work (measured, 64
     // fields: 1 km EvI 292 -> 255 us; at 5 km the extra combine pass costs more than the halved traffic saves, 18.5 -> 21.9).
     // ... or, with >= 32 fields, the column-sweep structure (sweep_kernel.inl): every X element read once, in whole lines.
-    if (w->band_eligible && !w->sweep_tried && w->sweep_ntask == 0 &&
+    if (!w->sweep_tried && w->sweep_ntask == 0 &&
         (w->kernel_override == 4 ||
-         (w->kernel_override == 0 && w->napply >= 1 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
-          (double)w->nnz * nvar >= (double)get_tuning("sweep_min_work", 8 << 20)))) {
+         (w->band_eligible && w->kernel_override == 0 && w->napply >= 1 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
+          (double)w->nnz * nvar >= (double)get_tuning("sweep_min_work", 64 << 20)))) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
         if (cs == hipStreamCaptureStatusNone) { w->sweep_tried = 1; build_sweep_from_csr(w, stream); }
