@@ -346,9 +346,11 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 constexpr int SR_THREADS = 256;
 
 // XT[c*ldt + f] = X[f*ldx + c]; pad columns f in [nf, ldt) are zeroed (read for tail fields, never stored)
-__global__ void transpose_fields_kernel(const double *__restrict__ X, long ldx, int nf, int ncol,
-                                        double *__restrict__ XT, int ldt) {
+__global__ void transpose_fields_kernel(const BatchPtrs bp, long ldx, int nf, int ncol,
+                                        double *__restrict__ XT0, int ldt, long xt_stride) {
     __shared__ double tile[16][65];
+    const double *__restrict__ X = bp.x[blockIdx.z];
+    double *__restrict__ XT = XT0 + (long)blockIdx.z * xt_stride;
     const int cb = blockIdx.x * 64, fb = blockIdx.y * 16;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 256 threads: 64 columns x 4
 #pragma unroll
@@ -382,10 +384,14 @@ typedef double sr_double2 __attribute__((ext_vector_type(2)));
 template <bool NT, int G, bool REALIGN, bool XT>
 __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
-    const double *__restrict__ X, long ldx, double *__restrict__ Y, long ldy, int nrow, int nf, int fper,
+    const BatchPtrs bp, const double *__restrict__ XT0, long xt_stride, long ldx, long ldy, int nrow, int nf, int fper,
     const double *__restrict__ wM, double fill)
 {
     __shared__ double s_y[REALIGN ? G : 1][SR_THREADS];
+    // blockIdx.y = field batch of a batched launch (ibh_weighted_apply_many_device): the workgroups of batch q+1 start while
+    // those of batch q still store, so launch ramp and drain are paid once per launch
+    const double *__restrict__ X = XT ? XT0 + (long)blockIdx.y * xt_stride : bp.x[blockIdx.y];
+    double *__restrict__ Y = bp.y[blockIdx.y];
     // 1-D grid, field chunk fastest, contiguous ranges per XCD: the nfy workgroups that walk the same
     // 256 rows (one per field chunk) are neighbours on one XCD, so rowptr/colind/vals/wM of those rows
     // come from HBM once and from that XCD's L2 for the other chunks.
@@ -816,26 +822,41 @@ static void launch_one(const ibh_weighted *w, int kernel, const BatchPtrs &bp, i
     } else {
         const ShortrowPlan p = shortrow_plan(w, nvar);
         const int fper = p.fper, g = p.g;
-        if (p.use_xt) grow_scratch(w->xt, (size_t)w->ncol * (size_t)p.ldt, stream, "transposed-input");
-        for (int q = 0; q < nbatch; ++q) {
-            const double *dA = bp.x[q];
-            double *dB = bp.y[q];
+        const long xt_stride = (long)w->ncol * p.ldt;
+        // GB-sized results: deep launches cost the L2 locality of the row slices (measured at 1 km: 148 us per apply alone,
+        // 181 us sixteen deep); they go out a few batches at a time
+        int qmax = std::max(1, get_tuning("shortrow_many", w->nrow >= (1 << 19) ? 1 : IBH_MAX_BATCH));
+        if (p.use_xt && qmax > 1 && (size_t)xt_stride * sizeof(double) * (size_t)std::min(qmax, nbatch) > w->xt.granted) {
+            // the transposed copies of a deep launch do not fit the scratch the handle owns: grow it -- unless the stream is
+            // being captured (no allocation there): then as many batches per launch as fit
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
+            if (cs != hipStreamCaptureStatusNone) qmax = std::max(1, (int)(w->xt.granted / ((size_t)xt_stride * sizeof(double))));
+        }
+        for (int q0 = 0; q0 < nbatch; q0 += qmax) {
+            const int nq = std::min(qmax, nbatch - q0);
+            BatchPtrs bq{};
+            bool misaligned = (ldb & 7) != 0;
+            for (int q = 0; q < nq; ++q) {
+                bq.x[q] = bp.x[q0 + q]; bq.y[q] = bp.y[q0 + q];
+                misaligned = misaligned || (reinterpret_cast<uintptr_t>(bq.y[q]) & 63) != 0;
+            }
+            if (p.use_xt) grow_scratch(w->xt, (size_t)xt_stride * (size_t)nq, stream, "transposed-input");
             // planes of B that do not start on 64-byte lines are re-aligned through LDS (see the kernel)
             const bool realign = get_tuning("shortrow_realign", -1) >= 0 ? get_tuning("shortrow_realign", -1) != 0
-                               : ((reinterpret_cast<uintptr_t>(dB) & 63) != 0 || (ldb & 7) != 0) && w->nrow >= (1 << 18);   // below: latency-bound, the two extra barriers cost more
+                               : misaligned && w->nrow >= (1 << 18);   // below: latency-bound, the two extra barriers cost more
             const long nblk = (long)ceil_div(w->nrow, realign ? SR_STEP : SR_THREADS) * ceil_div(nvar, fper);
             IBH_CHECK(nblk < (1l << 31), "spmm grid too large (%ld blocks)", nblk);
-            dim3 grid((unsigned)nblk);
-            const double *xin = dA;
+            dim3 grid((unsigned)nblk, (unsigned)nq);
             long xld = (long)lda;
             if (p.use_xt) {
-                hipLaunchKernelGGL(transpose_fields_kernel, dim3((unsigned)ceil_div(w->ncol, 64), (unsigned)(p.ldt / 16)), dim3(256), 0, stream,
-                                   dA, (long)lda, nvar, w->ncol, w->xt.p, p.ldt);
-                xin = w->xt.p; xld = p.ldt;
+                hipLaunchKernelGGL(transpose_fields_kernel, dim3((unsigned)ceil_div(w->ncol, 64), (unsigned)(p.ldt / 16), (unsigned)nq), dim3(256), 0, stream,
+                                   bq, (long)lda, nvar, w->ncol, w->xt.p, p.ldt, xt_stride);
+                xld = p.ldt;
             }
 #define IBH_SR4(NT, GG, RA, XTT)                                                                                \
     hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, RA, XTT>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
-                       w->val.p, xin, xld, dB, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill)
+                       w->val.p, bq, (const double *)w->xt.p, xt_stride, xld, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill)
 #define IBH_SR(NT, GG)                                                                                          \
     do {                                                                                                        \
         if (realign) { if (p.use_xt) IBH_SR4(NT, GG, true, true); else IBH_SR4(NT, GG, true, false); }          \
