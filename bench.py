@@ -72,17 +72,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or args.gpus > 1:
         assert world == args.gpus, "launch with torchrun --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  Rehearsal of the N>1 code path on a box with fewer GPUs than ranks (never a measurement):
+    # ICEBIN_BENCH_BACKEND=gloo lets several ranks share a card (RCCL refuses two ranks on one device)
+    backend = os.environ.get("ICEBIN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also rehearsable at N=1)
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import icebin_amd
     from icebin_amd import _capi
     from icebin_amd import synthetic as syn
     from icebin_amd.distributed import FieldShardedApply, field_shard
-    _capi.check(_capi.lib().ibh_set_device(local_rank))     # handles bind to the device current at creation
+    _capi.check(_capi.lib().ibh_set_device(dev_index))      # handles bind to the device current at creation
     for kv in args.tune:
         k, v = kv.split("=")
         icebin_amd.set_tuning(k, int(v))
@@ -115,7 +122,7 @@ def main():
 
     # ---- field batches resident in HBM -----------------------------------------------------------
     xbytes = 8 * nf * ncol
-    nbuf = 1 if args.warm else max(2, -(-(512 << 20) // xbytes))
+    nbuf = 1 if args.warm else min(64, max(2, -(-(512 << 20) // xbytes)))      # (I-row matrices: X is KB-sized, Y is what streams)
     x_host = syn.fields(nf, ncol, seed=syn.SEED + rank)
     x0 = torch.from_numpy(x_host).to(dev)
     X = [x0 if b == 0 else x0 + 1e-3 * b for b in range(nbuf)]

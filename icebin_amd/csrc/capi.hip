@@ -593,10 +593,10 @@ int ibh_weighted_apply_weight_host(const ibh_weighted *w, int dim, const double 
         const int n = dim == 0 ? w->nrow : w->ncol;
         IBH_CHECK(lda >= n, "leading dimension too small");
         if (nvar == 0) return;
-        DevBuf<double> dA((size_t)nvar * (size_t)n), dout((size_t)nvar);
+        DevBuf<double> dA((size_t)nvar * (size_t)n), dout((size_t)nvar), dpart(weight_dot_scratch(n, nvar));
         IBH_HIP(hipMemcpy2DAsync(dA.p, sizeof(double) * (size_t)n, A_b, sizeof(double) * (size_t)lda,
                                  sizeof(double) * (size_t)n, (size_t)nvar, hipMemcpyHostToDevice, nullptr));
-        weight_dot_launch(dim == 0 ? w->wM.p : w->Mw.p, n, dA.p, nvar, n, dout.p, nullptr);
+        weight_dot_launch(dim == 0 ? w->wM.p : w->Mw.p, n, dA.p, nvar, n, dout.p, dpart.p, nullptr);
         dout.download(out, (size_t)nvar);
     });
 }

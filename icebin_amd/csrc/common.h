@@ -158,7 +158,8 @@ struct ibh_plan {
     ibh::DevBuf<int32_t> ilptr, ilist;   // [nI+1], [nX] exchange cells of every ice cell, ascending
     ibh::DevBuf<int32_t> ifirst;         // [nI] first exchange cell of the ice cell with area != 0, -1: none
     ibh::DevBuf<uint8_t> isdup;          // [nX] bit 0: same (iA, iI) as the cell before; bit 1: every exchange cell of this
-                                         //      cell's ice cell lies in this range (the ice cell straddles no GCM-cell edge)
+                                         //      cell's ice cell lies in this range (the ice cell straddles no GCM-cell edge); bit 2: this
+                                         //      cell is the first-seen exchange cell of its ice cell (ifirst[iI] == x)
     ibh::DevBuf<int32_t> mlist;          // [nmulti] ice cells with exchange cells in more than one range
     int32_t nmulti = 0;
 };
@@ -203,7 +204,7 @@ struct ibh_weighted {
     mutable int last_kernel = 0;
     // apply_transformed: scratch fields + small transform, and M*1 (row sums) for the offset term
     mutable ibh::DevBuf<double> scratch, tbuf, rowsum1;
-    mutable ibh::DevBuf<double> consv;  // force_conservation: the two dot products per variable [2*nvar]
+    mutable ibh::DevBuf<double> consv;  // force_conservation: the two dot products per variable [2*nvar] + chunk sums
     mutable ibh::DevBuf<double> xt;     // shortrow: transposed copy of the (small) input fields
     // rowdual (EvI, EvX): the CSR filtered to one entry per (GCM cell, ice cell) carrying the weights of
     // BOTH elevation classes the cell lies between (assemble.hip build_bands); band r = row r
@@ -256,8 +257,9 @@ void matvec_legacy_launch(const ibh_weighted *w, const double *dx, int nvar, int
                           int ignore_nan, hipStream_t stream);
 void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_in, int64_t lda, const double *T,
                               const double *b, int nvar_out, double *dB, int64_t ldb, double fill, hipStream_t stream);
-void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int64_t lda, double *dout,
+void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int64_t lda, double *dout, double *part,
                        hipStream_t stream);
+size_t weight_dot_scratch(int n, int nvar);
 void set_launch_events(hipEvent_t start, hipEvent_t stop);
 int get_tuning(const char *key, int dflt);
 void set_tuning(const char *key, int value);

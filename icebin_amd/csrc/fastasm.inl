@@ -89,6 +89,7 @@ __global__ void k_plan_ifirst(const int32_t *__restrict__ ilptr, const int32_t *
         one = one && aidx[ilist[k]] == aidx[ilist[b]];
     }
     ifirst[i] = f;
+    if (f >= 0) isdup[f] |= 4;                                     // "this exchange cell is the first-seen one of its ice cell": spares the builds the ifirst gather
     if (one) for (int k = b; k < e; ++k) isdup[ilist[k]] |= 2;     // exchange cells of one ice cell: no two threads share a byte's bits... (own cells only)
     multi[i] = (e > b && !one) ? 1u : 0u;
 }
@@ -167,7 +168,8 @@ struct FaG {
 struct FaP {
     int key, list;              // KEY_I / KEY_X, LIST_I / LIST_AP / LIST_EP
     int fresh;                  // 1: numbered by this build, 0: identity over the whole extent
-    uint32_t *pflag, *poff;     // [nX] first-occurrence flags and their exclusive scan: the dense id of a new key is
+    uint8_t *pflag;             // [nX] first-occurrence flags (bytes: written, scanned and read once per build each)
+    uint32_t *poff;             // [nX] their exclusive scan: the dense id of a new key is
                                 //      poff[its first-seen position] -- for an ice cell poff[ifirst[iI]], no table needed
     int64_t *to_sparse;
 };
@@ -263,7 +265,9 @@ __global__ __launch_bounds__(FA_T) void k_fa_count(RgView rg, PlanView pl, MatSp
 #pragma unroll
         for (int u = 0; u < FA_CPT; ++u) {
             ev[u] = rg.em[iIv[u]];
-            ifv[u] = p.key == KEY_I ? pl.ifirst[iIv[u]] : 0;
+            const long x = cb + (long)u * FA_T + threadIdx.x;
+            // first-seen position of the ice cell: this very cell for ~90 % of them (plan bit 2), a gather for the rest
+            ifv[u] = p.key == KEY_I ? ((fl[u] & 4) ? (int)(x < x1 ? x : x1 - 1) : pl.ifirst[iIv[u]]) : 0;
         }
 #pragma unroll
         for (int u = 0; u < FA_CPT; ++u) {
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(FA_T) void k_fa_count(RgView rg, PlanView pl, MatSp
             uint32_t cn0 = 0, co0 = 0;                        // one-class ranges: this lane's new / old entries
             if (in) {
                 const XCell c = make_cell<WITH_EP>(rg, iAv[u], iIv[u], av[u], ev[u]);
-                if (p.fresh) p.pflag[x] = p.key == KEY_I ? ((ifv[u] == (int32_t)x && c.unmasked) ? 1u : 0u) : fa_pflag_of<WITH_EP>(rg, pl, p, c, x);
+                if (p.fresh) p.pflag[x] = (uint8_t)(p.key == KEY_I ? ((ifv[u] == (int32_t)x && c.unmasked) ? 1u : 0u) : fa_pflag_of<WITH_EP>(rg, pl, p, c, x));
                 if (WITH_EP && c.range_error) atomicMin(err_x, (uint32_t)x);
                 else {
                     long k0, k1;
@@ -437,12 +441,14 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
 #pragma unroll
         for (int u = 0; u < FA_CPT; ++u) {
             ev[u] = rg.em[iIv[u]];
-            ifv[u] = (p.key == KEY_I && p.fresh) ? pl.ifirst[iIv[u]] : 0;
+            const long x = cb + (long)u * FA_T + tid;
+            ifv[u] = (p.key == KEY_I && p.fresh) ? ((fl[u] & 4) ? (int)(x < x1 ? x : x1 - 1) : pl.ifirst[iIv[u]]) : 0;
         }
 #pragma unroll
         for (int u = 0; u < FA_CPT; ++u) {
             const long x = cb + (long)u * FA_T + tid;
-            if (p.key == KEY_I) didv[u] = p.fresh ? (int)p.poff[ifv[u] < 0 ? 0 : ifv[u]] : iIv[u];
+            // dense id of the ice cell = poff[its first-seen position]: already in hand (pov) when that is this cell
+            if (p.key == KEY_I) didv[u] = p.fresh ? ((EMIT && (fl[u] & 4)) ? (int)pov[u] : (int)p.poff[ifv[u] < 0 ? 0 : ifv[u]]) : iIv[u];
             else didv[u] = p.fresh ? (int)pov[u] : (int)(x < x1 ? x : x1 - 1);
         }
 #pragma unroll
@@ -451,9 +457,11 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
             const bool head = x < x1 && !(merge && (fl[u] & 1));
             GEnt &ge = gev[u];
             ge.n = 0; ge.cls0 = ge.cls1 = 0; ge.t0 = ge.t1 = 0.0; ge.gkey0 = ge.gkey1 = 0;
+            bool member = false;                              // EMIT: the P key of this head cell is in the set numbered by this build
             if (head) {
                 const XCell c = make_cell<WITH_EP>(rg, iAv[u], iIv[u], av[u], ev[u]);
                 if (!(WITH_EP && c.range_error)) fa_group<WITH_EP>(rg, pl, s, g_is_row, merge != 0, c, x, ge);
+                member = p.fresh && (p.key == KEY_I ? (c.unmasked && ifv[u] >= 0) : pfv[u] != 0);
             }
             newv[u] = head && (p.key != KEY_I || !p.fresh || ifv[u] >= x0);
             if (EMIT) {
@@ -467,6 +475,8 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
                     else if (s_rank[ge.cls0] < s_rank[ge.cls1]) { sum = sum + ge.t0; sum = sum + ge.t1; }
                     else { sum = sum + ge.t1; sum = sum + ge.t0; }
                     o.Mw[didv[u]] = sum;
+                } else if (ge.n == 0 && member && (p.key == KEY_X || (fl[u] & 2))) {
+                    o.Mw[didv[u]] = 0.0;                      // a member without entries (Mw is not cleared beforehand when the set is fresh)
                 }
             }
         }
@@ -790,10 +800,10 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     // counters read back with one sync: [0] first out-of-range cell, [1] fallback flags, [2] new P keys, [3] G classes, [4] entries
     uint32_t *d_cnt = A.get<uint32_t>(8);
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
-    if (p.fresh) { p.pflag = A.get<uint32_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
+    if (p.fresh) { p.pflag = A.get<uint8_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
     if (uses_ep) hipLaunchKernelGGL(k_fa_count<true>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1);
     else hipLaunchKernelGGL(k_fa_count<false>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1);
-    if (p.fresh) exclusive_scan_u32(p.pflag, p.poff, (size_t)nX, d_cnt + 2, st);
+    if (p.fresh) exclusive_scan_u8(p.pflag, p.poff, (size_t)nX, d_cnt + 2, st);
     if (nAr > 4096) {                                           // many ranges: the device-wide scan; few: one workgroup, one launch
         exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
         exclusive_scan_u32(g.r_nent, g.ebase, (size_t)nAr, g.ebase + nAr, st);
@@ -841,7 +851,9 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     const dim3 gp(ceil_div(np_s, T));
     if (g_is_row) {
         // rows = G: CSR + wM + (most of) Mw from the ranges; members of the P set without entries keep Mw = 0
-        if (ncol) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
+        // (a set numbered by this build: every member's Mw is written by k_fa_range / k_fa_pelem<SUMS>; an identity set has
+        // non-members -- masked cells -- whose Mw stays 0)
+        if (ncol && !p.fresh) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
         if (uses_ep) hipLaunchKernelGGL((k_fa_range<true, true>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, o, flags);
         else hipLaunchKernelGGL((k_fa_range<false, true>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, o, flags);
         if (p.key == KEY_I && P.nmulti) {                     // Mw of the ice cells that straddle ranges (a few %)

@@ -27,6 +27,8 @@ void readback_sync(void *dst, const void *dsrc, size_t bytes, hipStream_t stream
 // out[i] = sum_{j<i} in[j] (u32, wraps at 2^32); in == out allowed.  If total != nullptr the
 // grand total is written there (device pointer).  All work is enqueued on `stream`.
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total, hipStream_t stream);
+// the same over byte-sized counts (flags: a quarter of the read traffic)
+void exclusive_scan_u8(const uint8_t *in, uint32_t *out, size_t n, uint32_t *total, hipStream_t stream);
 
 // Three exclusive scans in one pass over a packed stream: pk[i] bits [0,2) and [2,4) are flag pairs
 // (channel value = number of set flags), bits [4,6) a count 0..3.  totals3: device uint32[3].

@@ -94,7 +94,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave
 // ---- scan ----------------------------------------------------------------------------------
 constexpr int SC_T = 256, SC_I = 8, SC_TILE = SC_T * SC_I;
 
-__global__ __launch_bounds__(SC_T) void scan_tile_sums(const uint32_t *__restrict__ in, size_t n,
+template <class IN>
+__global__ __launch_bounds__(SC_T) void scan_tile_sums(const IN *__restrict__ in, size_t n,
                                                        uint32_t *__restrict__ sums) {
     __shared__ uint32_t s_wave[SC_T / 64];
     const size_t base = (size_t)blockIdx.x * SC_TILE;
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(1024) void scan_sums_inplace(uint32_t *__restrict__
     if (threadIdx.x == 0 && total) *total = carry;
 }
 
-__global__ __launch_bounds__(SC_T) void scan_tile_apply(const uint32_t *in, uint32_t *out, size_t n,
+template <class IN>
+__global__ __launch_bounds__(SC_T) void scan_tile_apply(const IN *in, uint32_t *out, size_t n,
                                                         const uint32_t *__restrict__ offs) {
     __shared__ uint32_t tile[SC_TILE + SC_T];   // +1 pad per 8: thread t owns tile[9t .. 9t+7]
     __shared__ uint32_t s_wave[SC_T / 64];
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(SC_T) void scan_tile_apply(const uint32_t *in, uint
     }
 }
 
-void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total, hipStream_t stream) {
+template <class IN>
+static void exclusive_scan_any(const IN *in, uint32_t *out, size_t n, uint32_t *total, hipStream_t stream) {
     if (n == 0) {
         if (total) IBH_HIP(hipMemsetAsync(total, 0, sizeof(uint32_t), stream));
         return;
@@ -160,10 +163,16 @@ void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *t
     const size_t nb = (n + SC_TILE - 1) / SC_TILE;
     IBH_CHECK(nb < (1ul << 31), "scan too large");
     uint32_t *sums = arena().get<uint32_t>(nb);
-    hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)nb), dim3(SC_T), 0, stream, in, n, sums);
+    hipLaunchKernelGGL(scan_tile_sums<IN>, dim3((unsigned)nb), dim3(SC_T), 0, stream, in, n, sums);
     hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, (int)nb, total);
-    hipLaunchKernelGGL(scan_tile_apply, dim3((unsigned)nb), dim3(SC_T), 0, stream, in, out, n, sums);
+    hipLaunchKernelGGL(scan_tile_apply<IN>, dim3((unsigned)nb), dim3(SC_T), 0, stream, in, out, n, sums);
     IBH_HIP(hipGetLastError());
+}
+void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total, hipStream_t stream) {
+    exclusive_scan_any(in, out, n, total, stream);
+}
+void exclusive_scan_u8(const uint8_t *in, uint32_t *out, size_t n, uint32_t *total, hipStream_t stream) {
+    exclusive_scan_any(in, out, n, total, stream);
 }
 
 // ---- three-channel scan -----------------------------------------------------------------------

@@ -490,15 +490,20 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
 }
 
 // ---- conservation correction (non-conservative matrices only) ------------------------------
-// out[k] = sum_j w[j] * A[k*lda + j] over j with w[j] != 0; one block per variable, fixed order.
-__global__ __launch_bounds__(1024) void weight_dot_kernel(const double *__restrict__ w, int n,
+// out[k] = sum_j w[j] * A[k*lda + j] over j with w[j] != 0, in a fixed order: the vector is cut into <= WD_MAXCHUNK chunks
+// (one workgroup each per variable: a single workgroup per variable reads 10^5..10^7 elements at one CU's bandwidth --
+// measured 35 us of an 85 us corrected apply at 5 km), the chunk sums are added sequentially by the last stage.
+constexpr int WD_MAXCHUNK = 256, WD_MINLEN = 4096;
+static int weight_dot_chunks(int n) { return n <= WD_MINLEN ? 1 : std::min(WD_MAXCHUNK, ceil_div(n, WD_MINLEN)); }
+__global__ __launch_bounds__(1024) void weight_dot_kernel(const double *__restrict__ w, int n, int chunk_len,
                                                           const double *__restrict__ A, long lda,
-                                                          double *__restrict__ out)
+                                                          double *__restrict__ part)
 {
     __shared__ double s[16];
     const double *a = A + (long)blockIdx.x * lda;
+    const int j0 = blockIdx.y * chunk_len, j1 = min(n, j0 + chunk_len);
     double acc = 0.0;
-    for (int j = threadIdx.x; j < n; j += 1024) {
+    for (int j = j0 + threadIdx.x; j < j1; j += 1024) {
         const double wj = w[j];
         if (wj != 0.0) acc = fma(wj, a[j], acc);
     }
@@ -508,8 +513,14 @@ __global__ __launch_bounds__(1024) void weight_dot_kernel(const double *__restri
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int q = 0; q < 16; ++q) t += s[q];
-        out[blockIdx.x] = t;
+        part[(long)blockIdx.x * gridDim.y + blockIdx.y] = t;
     }
+}
+__global__ void weight_dot_final_kernel(const double *__restrict__ part, int nchunk, double *__restrict__ out) {
+    const int k = blockIdx.x;                      // one variable per (single-thread) workgroup: <= WD_MAXCHUNK additions, in chunk order
+    double t = 0.0;
+    for (int c = 0; c < nchunk; ++c) t += part[(long)k * nchunk + c];
+    out[k] = t;
 }
 __global__ void conserve_scale_kernel(double *__restrict__ Y, long ldy, int nrow, const double *__restrict__ wM,
                                       const double *__restrict__ TA, const double *__restrict__ TB)
@@ -520,13 +531,19 @@ __global__ void conserve_scale_kernel(double *__restrict__ Y, long ldy, int nrow
     Y[(long)k * ldy + r] *= TA[k] / TB[k];
 }
 
-void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int64_t lda, double *dout,
+// dout[nvar]; part: scratch of nvar * weight_dot_chunks(n) doubles (nullptr allowed when n <= WD_MINLEN: one chunk goes
+// straight to dout)
+void weight_dot_launch(const double *dw, int n, const double *dA, int nvar, int64_t lda, double *dout, double *part,
                        hipStream_t stream)
 {
     if (nvar <= 0) return;
-    hipLaunchKernelGGL(weight_dot_kernel, dim3(nvar), dim3(1024), 0, stream, dw, n, dA, (long)lda, dout);
+    const int nchunk = part ? weight_dot_chunks(n) : 1;
+    const int len = ceil_div(n, nchunk);
+    hipLaunchKernelGGL(weight_dot_kernel, dim3(nvar, nchunk), dim3(1024), 0, stream, dw, n, len, dA, (long)lda, nchunk == 1 ? dout : part);
+    if (nchunk > 1) hipLaunchKernelGGL(weight_dot_final_kernel, dim3(nvar), dim3(1), 0, stream, part, nchunk, dout);
     IBH_HIP(hipGetLastError());
 }
+size_t weight_dot_scratch(int n, int nvar) { return (size_t)nvar * (size_t)weight_dot_chunks(n); }
 
 // ---- dispatch ------------------------------------------------------------------------------
 void ensure_rowsum1(const ibh_weighted *w, hipStream_t stream);
@@ -735,8 +752,11 @@ static int pick_kernel(const ibh_weighted *w, int nvar) {
     int kernel = w->kernel_override;
     if (kernel == 4 && w->sweep_ntask == 0) kernel = 0;       // no column-sweep structure: the automatic choice
     if (kernel == 0) {
+        // rowblock = one workgroup per (row, field chunk): for FEW LONG rows.  Many rows of 6..63 entries (a smoothed IvE:
+        // 76 k rows of ~16) are thread-per-row work (measured, 5 km smoothed IvE, 16 fields: 220 us as rowblock)
         const double mean = w->nrow ? (double)w->nnz / (double)w->nrow : 0.0;
-        kernel = mean >= (double)get_tuning("rowblock_min_mean_nnz", 6) ? 1 : 2;
+        const bool few_rows = w->nrow <= get_tuning("rowblock_max_short_rows", 16384);
+        kernel = (mean >= 64.0 || (few_rows && mean >= (double)get_tuning("rowblock_min_mean_nnz", 6))) ? 1 : 2;
     }
     if (kernel == 1 && w->kernel_override == 0 && w->sweep_ntask > 0 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1)) kernel = 4;
     if (kernel == 1 && w->kernel_override == 0 && w->band_n > 0 && nvar >= 4 && get_tuning("rowdual_auto", 1)) kernel = 3;
@@ -773,7 +793,7 @@ void weighted_reserve(const ibh_weighted *w, int nvar) {
         const ShortrowPlan p = shortrow_plan(w, nvar);
         if (p.use_xt && pick_kernel(w, nvar) == 2) grow_scratch(w->xt, (size_t)w->ncol * (size_t)p.ldt, nullptr, "transposed-input");
     }
-    grow_scratch(w->consv, 2 * (size_t)nvar, nullptr, "conservation");
+    grow_scratch(w->consv, 2 * (size_t)nvar + weight_dot_scratch(std::max(w->nrow, w->ncol), nvar), nullptr, "conservation");
     // apply_transformed: the small side holds nvar fields
     grow_scratch(w->scratch, (size_t)nvar * (size_t)std::min(w->nrow, w->ncol), nullptr, "transform");
     ensure_rowsum1(w, nullptr);
@@ -902,7 +922,7 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
     const int kernel = pick_kernel(w, nvar);
     w->last_kernel = kernel;
     const bool correct = !w->conservative && force_conservation;
-    if (correct) grow_scratch(w->consv, 2 * (size_t)nvar, stream, "conservation");
+    if (correct) grow_scratch(w->consv, 2 * (size_t)nvar + weight_dot_scratch(std::max(w->nrow, w->ncol), nvar), stream, "conservation");
     for (int b0 = 0; b0 < nbatch; b0 += IBH_MAX_BATCH) {
         const int nb = std::min(IBH_MAX_BATCH, nbatch - b0);
         BatchPtrs bp{};
@@ -916,8 +936,8 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
             // dot products live in handle-owned scratch: stream-ordered, no allocation, no host sync.
             for (int q = 0; q < nb; ++q) {
                 double *T = w->consv.p;
-                weight_dot_launch(w->Mw.p, w->ncol, bp.x[q], nvar, lda, T, stream);
-                weight_dot_launch(w->wM.p, w->nrow, bp.y[q], nvar, ldb, T + nvar, stream);
+                weight_dot_launch(w->Mw.p, w->ncol, bp.x[q], nvar, lda, T, T + 2 * nvar, stream);
+                weight_dot_launch(w->wM.p, w->nrow, bp.y[q], nvar, ldb, T + nvar, T + 2 * nvar, stream);
                 dim3 grid((unsigned)ceil_div(w->nrow, 256), (unsigned)nvar);
                 hipLaunchKernelGGL(conserve_scale_kernel, grid, dim3(256), 0, stream, bp.y[q], (long)ldb, w->nrow, w->wM.p,
                                    T, T + nvar);
