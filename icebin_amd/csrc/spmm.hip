@@ -799,8 +799,25 @@ void weighted_reserve(const ibh_weighted *w, int nvar) {
     ensure_rowsum1(w, nullptr);
 }
 
+static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &bp, int nbatch, int nvar, int64_t lda,
+                            int64_t ldb, double fill, hipStream_t stream);
 static void launch_one(const ibh_weighted *w, int kernel, const BatchPtrs &bp, int nbatch, int nvar, int64_t lda,
                        int64_t ldb, double fill, hipStream_t stream)
+{
+    // launch timing (ibh_set_launch_events): the single-kernel paths attach the events to their dispatch; the paths made of
+    // several launches (transposed input + I-row kernel, bands + combine) record them around the sequence
+    if ((kernel == 2 || kernel == 3) && g_ev_start && g_ev_stop) {
+        hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
+        g_ev_start = g_ev_stop = nullptr;
+        IBH_HIP(hipEventRecord(ev0, stream));
+        launch_one_impl(w, kernel, bp, nbatch, nvar, lda, ldb, fill, stream);
+        IBH_HIP(hipEventRecord(ev1, stream));
+        return;
+    }
+    launch_one_impl(w, kernel, bp, nbatch, nvar, lda, ldb, fill, stream);
+}
+static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &bp, int nbatch, int nvar, int64_t lda,
+                            int64_t ldb, double fill, hipStream_t stream)
 {
     if (kernel == 4) {
         launch_sweep(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream);

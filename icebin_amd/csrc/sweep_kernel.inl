@@ -90,7 +90,9 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
         }
     };
     // One register tile: the loads of block k+1 (X tile and the weights of the wave's 16 columns, lanes 0..15) are in flight
-    // while block k is consumed.  What the consumer needs per column must not cost a VALU -> SGPR transfer (v_readlane:
+    // while block k is consumed (two tiles in flight -- every load unconditional so that the stores of block k wait for the
+    // oldest tile only -- were measured SLOWER, 239 against 228 us at 1 km: the kernel is bound by the address/issue work of
+    // its loads and the extra tail loads and the empty step of odd tasks cost more than the latency they hide).  What the consumer needs per column must not cost a VALU -> SGPR transfer (v_readlane:
     // measured, five of them per column made the consume phase as long as the memory latency it is supposed to hide) nor a
     // load inside the consume phase (a serial round trip per block):
     //   * the 16 metadata words come through ONE scalar load, issued after the previous block has been consumed -- it
