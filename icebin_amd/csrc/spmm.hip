@@ -936,7 +936,9 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
         if (cs == hipStreamCaptureStatusNone) { w->band_tried = 1; build_bands_from_csr(w, stream); }
     }
     ++w->napply;
-    const int kernel = pick_kernel(w, nvar);
+    int kernel = pick_kernel(w, nvar);
+    // the column sweep addresses a wave's 16 field planes through one buffer descriptor (32-bit offsets)
+    if (kernel == 4 && ((uint64_t)16 * (uint64_t)lda * 8 + (uint64_t)w->ncol * 8 >= (1ull << 32))) kernel = w->band_n > 0 ? 3 : 1;
     w->last_kernel = kernel;
     const bool correct = !w->conservative && force_conservation;
     if (correct) grow_scratch(w->consv, 2 * (size_t)nvar + weight_dot_scratch(std::max(w->nrow, w->ncol), nvar), stream, "conservation");

@@ -80,6 +80,12 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
     const int fmine = fb * 64 + wave * FPW;                         // first plane this wave loads
     const int fld = fb * 64 + lane;                                 // the field this lane accumulates
     const int nfw = min(FPW, nf - fmine);                           // planes of this wave that exist
+    (void)nfw;
+    const int pbase = min(fmine, nf - 1);                           // planes past nf repeat the last plane (loaded, never used)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)pbase * ldx), 0, -1 /* 4 GB */, 0x00020000);
+    unsigned poff[FPW];                                             // byte offsets of this wave's planes from its first
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) poff[i] = (unsigned)((long)((FULL ? fmine + i : min(fmine + i, nf - 1)) - pbase) * ldx * 8);
 
     int cur = -1;                         // meta word of the live pair
     double a0 = 0.0, a1 = 0.0;
@@ -116,10 +122,13 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
         int cnx = columns(0);
         auto issue = [&](int k) {
             // Unconditional loads (exact vmcnt bookkeeping); planes past nf repeat the last plane.
-            const double *xp = X + cnx;
+            // buffer loads: the wave's first plane is the descriptor base, the plane is a scalar offset, the column a 32-bit
+            // per-lane byte offset -- no 64-bit VALU address arithmetic per load (the launch checks 16 * ldx * 8 < 2^32)
+            const int boff = cnx << 3;
             cnx = columns(k + 1);
 #pragma unroll
-            for (int i = 0; i < FPW; ++i) xr[i] = xp[(long)(FULL ? fmine + i : min(fmine + i, nf - 1)) * ldx];
+            for (int i = 0; i < FPW; ++i)
+                xr[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, boff, (int)poff[i], 0));
             const long it = (long)(kc + k) * SWEEP_CB + jb + (lane & (CPW - 1));
             v0 = sv.it_v0[it]; v1 = sv.it_v1[it];
         };
