@@ -1263,22 +1263,22 @@ __global__ void k_sw_slots(const uint64_t *__restrict__ tk, const uint32_t *__re
     const uint32_t t = (uint32_t)(tk[k] >> 32);
     eslot[tv[k]] = (uint8_t)(uscan[k] + u[k] - 1 - (uint32_t)task_p0[t]);
 }
-__global__ void k_sw_task_ns(const int32_t *__restrict__ task_p0, int ntask, int nuniq, int32_t *__restrict__ task_ns, int32_t *__restrict__ task_b0,
-                             int tb, int nblk, uint32_t *__restrict__ d_maxns) {
+__global__ void k_sw_task_ns(const int32_t *__restrict__ task_p0, int ntask, int nuniq, int32_t *__restrict__ task_ns,
+                             uint32_t *__restrict__ d_maxns) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > ntask) return;
-    task_b0[t] = min(t * tb, nblk);
-    if (t == ntask) return;
+    if (t >= ntask) return;
     const int ns = (t + 1 < ntask ? task_p0[t + 1] : nuniq) - task_p0[t];
     task_ns[t] = ns;
     atomicMax(d_maxns, (uint32_t)ns);
 }
 __global__ void k_sw_items(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ ih,
                            const uint32_t *__restrict__ iscan, long n, const uint8_t *__restrict__ eslot, const double *__restrict__ val,
-                           int32_t *__restrict__ it_col, uint32_t *__restrict__ meta, double *__restrict__ v0, double *__restrict__ v1) {
+                           int32_t *__restrict__ it_col, uint32_t *__restrict__ meta, double *__restrict__ v0, double *__restrict__ v1,
+                           uint32_t *__restrict__ d_notident) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !ih[i]) return;
     const long it = (long)iscan[i];
+    if ((long)(uint32_t)keys[i] != it) *d_notident = 1u;     // some column has no item, or more than one
     const uint32_t s0 = eslot[i];
     uint32_t m = s0 | (s0 << 8) | SWEEP_HAS0;
     double w1 = 0.0;
@@ -1287,10 +1287,6 @@ __global__ void k_sw_items(const uint64_t *__restrict__ keys, const uint32_t *__
         w1 = val[idx[i + 1]];
     }
     it_col[it] = (int32_t)(uint32_t)keys[i]; meta[it] = m; v0[it] = val[idx[i]]; v1[it] = w1;
-}
-__global__ void k_sw_blkcnt(int nblk, long nitems, int32_t *__restrict__ blk_cnt) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nblk) blk_cnt[b] = (int32_t)min(64l, nitems - 64l * b);
 }
 __global__ void k_sw_combkeys(const int32_t *__restrict__ urow, int nuniq, uint64_t *__restrict__ ck, uint32_t *__restrict__ cv) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1345,13 +1341,12 @@ bool build_sweep_from_csr(const ibh_weighted *cw, hipStream_t st) {
         if (radix_sort_pairs(a, b2, av, bv, (size_t)nnz, tf, 2, st)) { std::swap(a, b2); std::swap(av, bv); }
         hipLaunchKernelGGL(k_sw_uniq, dim3(ceil_div(nnz, T)), dim3(T), 0, st, a, nnz, u);
         exclusive_scan_u32(u, uscan, (size_t)nnz, d_cnt + 1, st);
-        w->sweep_task_b0.alloc((size_t)ntask + 1); w->sweep_task_p0.alloc((size_t)ntask + 1); w->sweep_task_ns.alloc((size_t)ntask + 1);
+        w->sweep_task_p0.alloc((size_t)ntask + 1); w->sweep_task_ns.alloc((size_t)ntask + 1);
         hipLaunchKernelGGL(k_sw_taskfirst, dim3(ceil_div(nnz, T)), dim3(T), 0, st, a, u, uscan, nnz, w->sweep_task_p0.p, urow);
         readback_sync(h, d_cnt, sizeof(h), st);
         nuniq = (int)h[1];
         IBH_HIP(hipMemsetAsync(d_cnt + 2, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_sw_task_ns, dim3(ceil_div(ntask + 1, T)), dim3(T), 0, st, w->sweep_task_p0.p, ntask, nuniq, w->sweep_task_ns.p,
-                           w->sweep_task_b0.p, tb, nblk, d_cnt + 2);
+        hipLaunchKernelGGL(k_sw_task_ns, dim3(ceil_div(ntask, T)), dim3(T), 0, st, w->sweep_task_p0.p, ntask, nuniq, w->sweep_task_ns.p, d_cnt + 2);
         readback_sync(h, d_cnt, sizeof(h), st);
         maxns = (int)h[2];
         // LDS per workgroup = tile (33 KB) + 4 waves x maxns x 512 B: <= 22 slots keep two workgroups on a CU, <= 9 three
@@ -1363,15 +1358,14 @@ bool build_sweep_from_csr(const ibh_weighted *cw, hipStream_t st) {
         }
     }
     // items
-    w->sweep_blk_cnt.alloc((size_t)nblk); w->sweep_col.alloc((size_t)nblk * 64);
+    w->sweep_col.alloc((size_t)nblk * 64);
     w->sweep_meta.alloc((size_t)nblk * 64); w->sweep_v0.alloc((size_t)nblk * 64); w->sweep_v1.alloc((size_t)nblk * 64);
     IBH_HIP(hipMemsetAsync(w->sweep_col.p, 0, sizeof(int32_t) * (size_t)nblk * 64, st));
     IBH_HIP(hipMemsetAsync(w->sweep_meta.p, 0, sizeof(uint32_t) * (size_t)nblk * 64, st));
     IBH_HIP(hipMemsetAsync(w->sweep_v0.p, 0, sizeof(double) * (size_t)nblk * 64, st));
     IBH_HIP(hipMemsetAsync(w->sweep_v1.p, 0, sizeof(double) * (size_t)nblk * 64, st));
     hipLaunchKernelGGL(k_sw_items, dim3(ceil_div(nnz, T)), dim3(T), 0, st, keys, idx, ih, iscan, nnz, eslot, w->val.p, w->sweep_col.p,
-                       w->sweep_meta.p, w->sweep_v0.p, w->sweep_v1.p);
-    hipLaunchKernelGGL(k_sw_blkcnt, dim3(ceil_div(nblk, T)), dim3(T), 0, st, nblk, nitems, w->sweep_blk_cnt.p);
+                       w->sweep_meta.p, w->sweep_v0.p, w->sweep_v1.p, d_cnt + 5);
     // combine lists: the distinct (task, row) pairs by row, tasks ascending inside a row
     uint64_t *ck = A.get<uint64_t>((size_t)nuniq), *ck2 = A.get<uint64_t>((size_t)nuniq);
     uint32_t *cv = A.get<uint32_t>((size_t)nuniq), *cv2 = A.get<uint32_t>((size_t)nuniq);
@@ -1384,7 +1378,10 @@ bool build_sweep_from_csr(const ibh_weighted *cw, hipStream_t st) {
     rowptr_from_rows(srow, (long)nuniq, nrow, w->sweep_comb_ptr.p, st);
     IBH_HIP(hipMemcpyAsync(w->sweep_comb_p.p, cv, sizeof(uint32_t) * (size_t)nuniq, hipMemcpyDeviceToDevice, st));
     IBH_HIP(hipGetLastError());
-    IBH_HIP(hipStreamSynchronize(st));              // the arena is reused by the next build
+    readback_sync(h, d_cnt, sizeof(h), st);         // (the arena is reused by the next build)
+    w->sweep_ident = (h[5] == 0 && nitems == (long)ncol) ? 1 : 0;
+    if (w->sweep_ident) w->sweep_col.release();     // column = item index: the list is never read
+    w->sweep_tb = tb; w->sweep_nitems = (int32_t)nitems;
     w->sweep_nprow = nuniq;
     w->sweep_nblk = nblk;
     w->sweep_nslot = maxns < 1 ? 1 : maxns;

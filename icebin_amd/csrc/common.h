@@ -222,7 +222,8 @@ struct ibh_weighted {
     // tb blocks a task with its local row table; built lazily from the CSR (assemble.hip build_sweep_from_csr)
     mutable int sweep_tried = 0;
     mutable int32_t sweep_ntask = 0, sweep_nblk = 0, sweep_nprow = 0, sweep_nslot = 0;   // ntask == 0: not built
-    mutable ibh::DevBuf<int32_t> sweep_task_b0, sweep_task_p0, sweep_task_ns, sweep_blk_cnt, sweep_col;
+    mutable int32_t sweep_tb = 0, sweep_nitems = 0, sweep_ident = 0;                      // blocks per task, items, column == item index
+    mutable ibh::DevBuf<int32_t> sweep_task_p0, sweep_task_ns, sweep_col;
     mutable ibh::DevBuf<uint32_t> sweep_meta;
     mutable ibh::DevBuf<double> sweep_v0, sweep_v1;
     mutable ibh::DevBuf<int32_t> sweep_comb_ptr, sweep_comb_p;     // [nrow+1], [nprow]: the partial-sum rows that make up row r, in task order

@@ -719,36 +719,40 @@ static void launch_sweep(const ibh_weighted *w, const BatchPtrs &bp, int nbatch,
     const int nfb = ceil_div(nvar, 64);
     const long ldp = (long)nfb * 64, pstride = (long)w->sweep_nprow * ldp;
     grow_scratch(w->sweep_part, sweep_part_count(w, nvar, nbatch), stream, "column-sweep");
-    SweepView sv{w->sweep_task_b0.p, w->sweep_task_p0.p, w->sweep_task_ns.p, w->sweep_blk_cnt.p, w->sweep_col.p,
-                 w->sweep_meta.p, w->sweep_v0.p, w->sweep_v1.p};
+    SweepView sv{w->sweep_task_p0.p, w->sweep_task_ns.p, w->sweep_col.p, w->sweep_meta.p, w->sweep_v0.p, w->sweep_v1.p,
+                 w->sweep_tb, w->sweep_nblk, w->sweep_nitems};
     SweepBatch sb{};
     for (int q = 0; q < nbatch; ++q) { sb.x[q] = bp.x[q]; sb.p[q] = w->sweep_part.p + (size_t)q * (size_t)pstride; }
     const size_t lds = sweep_lds_bytes(w->sweep_nslot);
-    const bool full = nvar % 64 == 0;
+    const bool full = nvar % 64 == 0, ident = w->sweep_ident != 0;
+    const void *fn = full ? (ident ? reinterpret_cast<const void *>(spmm_sweep_kernel<true, true, 0>) : reinterpret_cast<const void *>(spmm_sweep_kernel<true, false, 0>))
+                          : (ident ? reinterpret_cast<const void *>(spmm_sweep_kernel<false, true, 0>) : reinterpret_cast<const void *>(spmm_sweep_kernel<false, false, 0>));
     if (lds > 64 * 1024) {                               // beyond the default dynamic-LDS limit: raise it once per device and variant
         static std::mutex mu;
-        static bool raised[64][2] = {};
+        static bool raised[64][4] = {};
         std::lock_guard<std::mutex> lk(mu);
-        const int dev = w->device & 63;
-        if (!raised[dev][full]) {
-            if (full) IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_sweep_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            else IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_sweep_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised[dev][full] = true;
+        const int dev = w->device & 63, var = (full ? 2 : 0) + (ident ? 1 : 0);
+        if (!raised[dev][var]) {
+            IBH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised[dev][var] = true;
         }
     }
     const dim3 grid((unsigned)w->sweep_ntask, (unsigned)nfb, (unsigned)nbatch);
     hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
-    if (full) hipExtLaunchKernelGGL((spmm_sweep_kernel<true, 0>), grid, dim3(SWEEP_NW * 64), lds, stream, ev0, ev1, 0, sv, sb, lda, nvar, w->sweep_nslot, ldp);
-    else hipExtLaunchKernelGGL((spmm_sweep_kernel<false, 0>), grid, dim3(SWEEP_NW * 64), lds, stream, ev0, ev1, 0, sv, sb, lda, nvar, w->sweep_nslot, ldp);
-    hipLaunchKernelGGL(sweep_combine_kernel, dim3((unsigned)ceil_div(w->nrow, 4), (unsigned)nfb, (unsigned)nbatch), dim3(256), 0, stream,
+    // launch timing: start = the sweep kernel begins, stop = the combine kernel ends (both belong to the apply)
+#define IBH_SW(F, I) hipExtLaunchKernelGGL((spmm_sweep_kernel<F, I, 0>), grid, dim3(SWEEP_NW * 64), lds, stream, ev0, nullptr, 0, sv, sb, lda, nvar, w->sweep_nslot, ldp)
+    if (full) { if (ident) IBH_SW(true, true); else IBH_SW(true, false); }
+    else { if (ident) IBH_SW(false, true); else IBH_SW(false, false); }
+#undef IBH_SW
+    hipExtLaunchKernelGGL(sweep_combine_kernel, dim3((unsigned)ceil_div(w->nrow, 4), (unsigned)nfb, (unsigned)nbatch), dim3(256), 0, stream, nullptr, ev1, 0,
                        w->sweep_part.p, pstride, ldp, w->sweep_comb_ptr.p, w->sweep_comb_p.p, w->wM.p, fill,
                        bp, ldb, w->nrow, nvar);
     IBH_HIP(hipGetLastError());
 }
 
 // which kernel serves (w, nvar): 1 rowblock, 2 shortrow, 3 rowdual, 4 colsweep
-static int pick_kernel(const ibh_weighted *w, int nvar) {
+static int pick_kernel(const ibh_weighted *w, int nvar, int nbatch = 1) {
     int kernel = w->kernel_override;
     if (kernel == 4 && w->sweep_ntask == 0) kernel = 0;       // no column-sweep structure: the automatic choice
     if (kernel == 0) {
@@ -758,7 +762,11 @@ static int pick_kernel(const ibh_weighted *w, int nvar) {
         const bool few_rows = w->nrow <= get_tuning("rowblock_max_short_rows", 16384);
         kernel = (mean >= 64.0 || (few_rows && mean >= (double)get_tuning("rowblock_min_mean_nnz", 6))) ? 1 : 2;
     }
-    if (kernel == 1 && w->kernel_override == 0 && w->sweep_ntask > 0 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1)) kernel = 4;
+    // the column sweep, once its structure exists: always for E-row matrices (every X element read once instead of twice);
+    // for the other long-row matrices (AvI, AvX) in batched launches only (measured at 1 km, 64 fields: 167 against 173 us
+    // per apply 32 deep, but 193 against 183 us one launch per apply -- two kernels and a prologue per task)
+    if (kernel == 1 && w->kernel_override == 0 && w->sweep_ntask > 0 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
+        (w->band_eligible || nbatch >= get_tuning("sweep_min_batch", 4))) kernel = 4;
     if (kernel == 1 && w->kernel_override == 0 && w->band_n > 0 && nvar >= 4 && get_tuning("rowdual_auto", 1)) kernel = 3;
     if (kernel == 3 && w->band_n == 0) kernel = 1;            // no bands were built for this matrix
     return kernel;
@@ -921,9 +929,10 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
     // for the coupler's one build : one apply, hence on the second apply and only for bandwidth-sized work (measured, 64
     // fields: 1 km EvI 292 -> 255 us; at 5 km the extra combine pass costs more than the halved traffic saves, 18.5 -> 21.9).
     // ... or, with >= 32 fields, the column-sweep structure (sweep_kernel.inl): every X element read once, in whole lines.
+    const bool long_rows = w->nrow > 0 && (double)w->nnz / (double)w->nrow >= 64.0 && w->nnz <= 2 * (int64_t)w->ncol;      // AvI, AvX
     if (!w->sweep_tried && w->sweep_ntask == 0 &&
         (w->kernel_override == 4 ||
-         (w->band_eligible && w->kernel_override == 0 && w->napply >= 1 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
+         ((w->band_eligible || (long_rows && nbatch >= get_tuning("sweep_min_batch", 4))) && w->kernel_override == 0 && w->napply >= 1 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
           (double)w->nnz * nvar >= (double)get_tuning("sweep_min_work", 64 << 20)))) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
@@ -936,7 +945,7 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
         if (cs == hipStreamCaptureStatusNone) { w->band_tried = 1; build_bands_from_csr(w, stream); }
     }
     ++w->napply;
-    int kernel = pick_kernel(w, nvar);
+    int kernel = pick_kernel(w, nvar, nbatch);
     // the column sweep addresses a wave's 16 field planes through one buffer descriptor (32-bit offsets)
     if (kernel == 4 && ((uint64_t)16 * (uint64_t)lda * 8 + (uint64_t)w->ncol * 8 >= (1ull << 32))) kernel = w->band_n > 0 ? 3 : 1;
     w->last_kernel = kernel;

@@ -30,17 +30,17 @@ namespace ibh {
 constexpr int SWEEP_CB = 64;             // columns per block
 constexpr int SWEEP_NW = 4;              // waves per workgroup
 constexpr int SWEEP_TS = SWEEP_CB + 1;   // padded tile row
-// One ITEM per column slot of a block (block b = items [64 b, 64 b + blk_cnt[b])): the column, and the <= 2 entries the
-// column has in this group: meta = slot0 | slot1 << 8 | has0 << 16 | has1 << 17 (0: empty slot), v0, v1 the two values.
+// One ITEM per column (a column with more than two entries: several): the column, and <= 2 of its entries:
+// meta = slot0 | slot1 << 8 | has0 << 16 | has1 << 17 (0: empty slot), v0, v1 the two values.  Items are packed: block b =
+// items [64 b, 64 b + 64) (the last block of the matrix may be short), task t = blocks [t tb, t tb + tb): no descriptors.
 constexpr unsigned SWEEP_HAS0 = 1u << 16, SWEEP_HAS1 = 1u << 17;
 struct SweepView {
-    const int *task_b0;        // [ntask+1] first block of the task
     const int *task_p0;        // [ntask]   first partial-sum row of the task
-    const int *task_ns;        // [ntask]   rows ("slots") of the task's group
-    const int *blk_cnt;        // [nblk]    items in the block (64 but for the last block of a group)
-    const int *it_col;         // [nblk*64]
+    const int *task_ns;        // [ntask]   rows ("slots") the task's columns touch
+    const int *it_col;         // [nblk*64] (not read when every column has exactly one item: column = item index)
     const unsigned *it_meta;   // [nblk*64]
     const double *it_v0, *it_v1;
+    int tb, nblk, nitems;
 };
 struct SweepBatch {
     const double *x[IBH_MAX_BATCH];
@@ -61,7 +61,9 @@ typedef double sweep_double2 __attribute__((ext_vector_type(2)));
 
 // FULL: all 64 fields of the field block exist.  MODE (diagnostics, scratch/sweep_bench.hip): 0 the kernel; 1 tile traffic only;
 // 2 the kernel with s_memtime stamps around its phases (per wave sums to sb.p[1])
-template <bool FULL, int MODE = 0>
+// IDENT: every column has exactly one item (AvI, AvX: <= 2 entries per column), so item index = column and the column list
+// is never read -- the first tile loads of a task depend on nothing but the kernel arguments.
+template <bool FULL, bool IDENT, int MODE = 0>
 __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepView sv, const SweepBatch sb, long ldx, int nf,
                                                                    int nslot_max, long ldp)
 {
@@ -74,9 +76,9 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
     const int t = sweep_xcd_contiguous(blockIdx.x, gridDim.x);
     const int fb = blockIdx.y, q = blockIdx.z;
     const double *__restrict__ X = sb.x[q];
-    const int b0 = sv.task_b0[t], b1 = sv.task_b0[t + 1];
-    const int ns = min(sv.task_ns[t], nslot_max);
-    for (int s = 0; s < ns; ++s) acc[s * 64 + lane] = 0.0;
+    const int b0 = t * sv.tb, b1 = min(sv.nblk, b0 + sv.tb);
+    const int p0 = sv.task_p0[t], ns = min(sv.task_ns[t], nslot_max);        // needed at the very end only
+    for (int s = 0; s < nslot_max; ++s) acc[s * 64 + lane] = 0.0;
     const int fmine = fb * 64 + wave * FPW;                         // first plane this wave loads
     const int fld = fb * 64 + lane;                                 // the field this lane accumulates
     const int nfw = min(FPW, nf - fmine);                           // planes of this wave that exist
@@ -110,14 +112,15 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
     double xr[FPW], v0 = 0.0, v1 = 0.0;
     sweep_double2 *wq = reinterpret_cast<sweep_double2 *>(s_mem + 64 * TS + NW * nslot_max * 64) + wave * CPW;    // [CPW] (w0, w1) per wave
     const int jb = wave * CPW;                              // this wave consumes columns [jb, jb + CPW) of a block
-    for (int kc = b0; kc < b1; kc += 64) {
-        const int nbk = min(64, b1 - kc);
-        const int ni = sv.blk_cnt[kc + min(lane, nbk - 1)];
+    {
+        const int kc = b0, nbk = b1 - b0;
         unsigned mk[CPW];
+        auto count = [&](int k) { return min(SWEEP_CB, sv.nitems - (kc + k) * SWEEP_CB); };      // items of block k: 64 but for the matrix' last block
         // the column list of a block is fetched one block ahead of its tile loads (two ahead of its consumption)
         auto columns = [&](int k) {
             const int kk = min(k, nbk - 1);
-            return sv.it_col[(long)(kc + kk) * SWEEP_CB + min(lane, __builtin_amdgcn_readlane(ni, kk) - 1)];   // lanes past the last item repeat it
+            const int it = (kc + kk) * SWEEP_CB + min(lane, count(kk) - 1);       // lanes past the last item repeat it
+            return IDENT ? it : sv.it_col[it];
         };
         int cnx = columns(0);
         auto issue = [&](int k) {
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
         meta(0);
         for (int k = 0; k < nbk; ++k) {
             if (MODE == 2) tA = __builtin_amdgcn_s_memtime();
-            const bool mine = jb < __builtin_amdgcn_readlane(ni, k);         // some of this wave's column slots hold items
+            const bool mine = jb < count(k);                                 // some of this wave's column slots hold items
 #pragma unroll
             for (int i = 0; i < FPW; ++i) tile[(wave * FPW + i) * TS + lane] = xr[i];
             { sweep_double2 w; w.x = v0; w.y = v1; wq[lane & (CPW - 1)] = w; }
@@ -187,7 +190,6 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
         dbg[0] = dA; dbg[1] = dB; dbg[2] = dC; dbg[3] = dD; dbg[4] = dn;
     }
     double *__restrict__ P = sb.p[q];
-    const int p0 = sv.task_p0[t];
     __syncthreads();
     // the task's partial sums: the waves' tables added in wave order, slots dealt round-robin to the waves
     const double *acc0 = s_mem + 64 * TS;

@@ -28,59 +28,48 @@ int main(int argc, char **argv) {
         hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
         int o0 = 0, o1 = 0, o2 = 0;
         const size_t lds = ibh::sweep_lds_bytes(NSL);
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o0, ibh::spmm_sweep_kernel<true, 0>, 256, lds));
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, ibh::spmm_sweep_kernel<true, 1>, 256, lds));
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, ibh::spmm_sweep_kernel<true, 2>, 256, lds));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o0, ibh::spmm_sweep_kernel<true, false, 0>, 256, lds));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, ibh::spmm_sweep_kernel<true, true, 0>, 256, lds));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, ibh::spmm_sweep_kernel<true, true, 1>, 256, lds));
         printf("device: %s CUs %d clock %d kHz LDS/CU %zu LDS/block %zu regs/block %d; lds per WG %zu; occupancy (WGs/CU) MODE0 %d MODE1 %d MODE2 %d\n", pr.name,
                pr.multiProcessorCount, pr.clockRate, pr.maxSharedMemoryPerMultiProcessor, pr.sharedMemPerBlock, pr.regsPerBlock, lds, o0, o1, o2);
     }
-    for (int TB : {16}) for (int MODE : {0, 1, 2}) {
-        std::vector<int> blk_cnt, it_col, task_b0, task_p0, task_ns;
+    for (int TB : {2, 8, 16}) for (int IDENT : {0, 1}) for (int MODE : {0, 1}) {
+        // packed structure: one item per column, 64 items a block, TB blocks a task, NSL slots per task
+        std::vector<int> it_col, task_p0, task_ns;
         std::vector<unsigned> meta; std::vector<double> val0, val1;
-        int prow = 0, ntask_g0 = 0;
-        for (int g = 0; g < ngroup; ++g) {
-            const int c_lo = g * GW, c_hi = std::min(ncol, c_lo + GW);
-            int nb_in_group = 0;
-            for (int c0 = c_lo; c0 < c_hi; c0 += CB) {
-                if (nb_in_group % TB == 0) { task_b0.push_back((int)blk_cnt.size()); task_p0.push_back(prow); task_ns.push_back(NSL); prow += NSL; }
-                ++nb_in_group;
-                if (g == 0) ntask_g0 = (int)task_b0.size();
-                blk_cnt.push_back(std::min(CB, c_hi - c0));
-                for (int c = c0; c < c0 + CB; ++c) {
-                    if (c >= c_hi) { it_col.push_back(0); meta.push_back(0u); val0.push_back(0.0); val1.push_back(0.0); continue; }
-                    const int s = ((c - c_lo) / RUN) % (NSL - 1);
-                    const double t = 0.25 + 0.5 * ((c * 7) % 13) / 13.0;
-                    it_col.push_back(c);
-                    meta.push_back((unsigned)s | ((unsigned)(s + 1) << 8) | ibh::SWEEP_HAS0 | ibh::SWEEP_HAS1);
-                    val0.push_back((1 - t) / GW); val1.push_back(t / GW);
-                }
-            }
+        const int nblk = (ncol + CB - 1) / CB, ntask = (nblk + TB - 1) / TB;
+        for (int c = 0; c < nblk * CB; ++c) {
+            if (c >= ncol) { it_col.push_back(0); meta.push_back(0u); val0.push_back(0.0); val1.push_back(0.0); continue; }
+            const int s = ((c % GW) / RUN) % (NSL - 1);
+            const double t = 0.25 + 0.5 * ((c * 7) % 13) / 13.0;
+            it_col.push_back(c);
+            meta.push_back((unsigned)s | ((unsigned)(s + 1) << 8) | ibh::SWEEP_HAS0 | ibh::SWEEP_HAS1);
+            val0.push_back((1 - t) / GW); val1.push_back(t / GW);
         }
-        const int ntask = (int)task_b0.size(), nblk = (int)blk_cnt.size();
-        task_b0.push_back(nblk);
-        int *d_tb0, *d_tp0, *d_tns, *d_bc0, *d_brg; unsigned *d_meta; double *d_val0, *d_val1, *d_P;
-        CK(hipMalloc(&d_tb0, 4 * (ntask + 1))); CK(hipMalloc(&d_tp0, 4 * ntask)); CK(hipMalloc(&d_tns, 4 * ntask));
-        CK(hipMalloc(&d_bc0, 4 * nblk)); CK(hipMalloc(&d_brg, 4 * it_col.size()));
+        for (int t = 0; t < ntask; ++t) { task_p0.push_back(t * NSL); task_ns.push_back(NSL); }
+        const int prow = ntask * NSL;
+        int *d_tp0, *d_tns, *d_brg; unsigned *d_meta; double *d_val0, *d_val1, *d_P;
+        CK(hipMalloc(&d_tp0, 4 * ntask)); CK(hipMalloc(&d_tns, 4 * ntask));
+        CK(hipMalloc(&d_brg, 4 * it_col.size()));
         CK(hipMalloc(&d_meta, 4 * meta.size())); CK(hipMalloc(&d_val0, 8 * val0.size())); CK(hipMalloc(&d_val1, 8 * val1.size()));
-        CK(hipMemcpy(d_tb0, task_b0.data(), 4 * (ntask + 1), hipMemcpyHostToDevice));
         CK(hipMemcpy(d_tp0, task_p0.data(), 4 * ntask, hipMemcpyHostToDevice));
         CK(hipMemcpy(d_tns, task_ns.data(), 4 * ntask, hipMemcpyHostToDevice));
-        CK(hipMemcpy(d_bc0, blk_cnt.data(), 4 * nblk, hipMemcpyHostToDevice));
         CK(hipMemcpy(d_brg, it_col.data(), 4 * it_col.size(), hipMemcpyHostToDevice));
         CK(hipMemcpy(d_meta, meta.data(), 4 * meta.size(), hipMemcpyHostToDevice));
         CK(hipMemcpy(d_val0, val0.data(), 8 * val0.size(), hipMemcpyHostToDevice));
         CK(hipMemcpy(d_val1, val1.data(), 8 * val1.size(), hipMemcpyHostToDevice));
         CK(hipMalloc(&d_P, 8 * (size_t)prow * 64));
-        double *d_dbg; CK(hipMalloc(&d_dbg, 64 * (size_t)ntask * ibh::SWEEP_NW)); CK(hipMemset(d_dbg, 0, 64 * (size_t)ntask * ibh::SWEEP_NW));
-        ibh::SweepView sv{d_tb0, d_tp0, d_tns, d_bc0, d_brg, d_meta, d_val0, d_val1};
+
+        ibh::SweepView sv{d_tp0, d_tns, d_brg, d_meta, d_val0, d_val1, TB, nblk, ncol};
         ibh::SweepBatch sb{};
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const size_t lds = ibh::sweep_lds_bytes(NSL);
         auto launch = [&](int i) {
             sb.x[0] = d_X + xn * (i % nbuf); sb.p[0] = d_P;
-            if (MODE == 0) hipLaunchKernelGGL((ibh::spmm_sweep_kernel<true, 0>), dim3(ntask, 1, 1), dim3(64 * ibh::SWEEP_NW), lds, 0, sv, sb, ldx, nf, NSL, 64l);
-            else if (MODE == 2) { sb.p[1] = d_dbg; hipLaunchKernelGGL((ibh::spmm_sweep_kernel<true, 2>), dim3(ntask, 1, 1), dim3(64 * ibh::SWEEP_NW), lds, 0, sv, sb, ldx, nf, NSL, 64l); }
-            else hipLaunchKernelGGL((ibh::spmm_sweep_kernel<true, 1>), dim3(ntask, 1, 1), dim3(64 * ibh::SWEEP_NW), lds, 0, sv, sb, ldx, nf, NSL, 64l);
+#define L_(I, M) hipLaunchKernelGGL((ibh::spmm_sweep_kernel<true, I, M>), dim3(ntask, 1, 1), dim3(64 * ibh::SWEEP_NW), lds, 0, sv, sb, ldx, nf, NSL, 64l)
+            if (IDENT) { if (MODE == 0) L_(true, 0); else L_(true, 1); }
+            else { if (MODE == 0) L_(false, 0); else L_(false, 1); }
         };
         for (int i = 0; i < 5; ++i) launch(i);
         CK(hipDeviceSynchronize()); CK(hipGetLastError());
@@ -95,31 +84,17 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(hp.data(), d_P, 8 * hp.size(), hipMemcpyDeviceToHost));
         double maxerr = 0;
         for (int f = 0; f < nf; f += 21) {
-            std::vector<double> ref(NSL, 0.0), got(NSL, 0.0);
-            for (int t = 0; t < ntask_g0; ++t) {
-                for (int s = 0; s < NSL; ++s) got[s] += hp[(size_t)(task_p0[t] + s) * 64 + f];
-                for (int b = task_b0[t]; b < task_b0[t + 1]; ++b)
-                    for (int j = 0; j < CB; ++j) {
-                        const size_t e = (size_t)b * CB + j;
-                        if (!meta[e]) continue;
-                        const double xv = hx[(size_t)f * ldx + it_col[e]];
-                        ref[meta[e] & 255] += val0[e] * xv; ref[(meta[e] >> 8) & 255] += val1[e] * xv;
-                    }
+            std::vector<double> ref(NSL, 0.0);
+            for (int e = 0; e < TB * CB && e < ncol; ++e) {
+                const double xv = hx[(size_t)f * ldx + it_col[e]];
+                ref[meta[e] & 255] += val0[e] * xv; ref[(meta[e] >> 8) & 255] += val1[e] * xv;
             }
-            for (int s = 0; s < NSL; ++s) maxerr = std::max(maxerr, std::fabs(ref[s] - got[s]));
+            for (int s2 = 0; s2 < NSL; ++s2) maxerr = std::max(maxerr, std::fabs(ref[s2] - hp[(size_t)s2 * 64 + f]));
         }
-        printf("ncol %d ldx %ld TB %3d MODE %d: ntask %6d nblk %7d  %8.2f us  %6.2f TB/s  (group-0 check max err %.2e)\n", ncol, ldx, TB, MODE,
+        printf("ncol %d ldx %ld TB %3d IDENT %d MODE %d: ntask %6d nblk %7d  %8.2f us  %6.2f TB/s  (group-0 check max err %.2e)\n", ncol, ldx, TB, IDENT, MODE,
                ntask, nblk, us, (double)nf * ncol * 8 / us / 1e6, maxerr);
-        if (MODE == 2) {
-            std::vector<unsigned long> hd((size_t)ntask * ibh::SWEEP_NW * 8);
-            CK(hipMemcpy(hd.data(), d_dbg, 8 * hd.size(), hipMemcpyDeviceToHost));
-            double sA = 0, sB = 0, sC = 0, sD = 0, sn = 0;
-            for (size_t i = 0; i < hd.size(); i += 8) { sA += hd[i]; sB += hd[i + 1]; sC += hd[i + 2]; sD += hd[i + 3]; sn += hd[i + 4]; }
-            printf("   phases per block per wave (s_memtime ticks): wait+store+barrier %.0f | issue %.0f | consume %.0f | meta+barrier %.0f   (n=%.0f)\n", sA / sn, sB / sn, sC / sn, sD / sn, sn);
-        }
         fflush(stdout);
-        hipFree(d_dbg);
-        hipFree(d_tb0); hipFree(d_tp0); hipFree(d_tns); hipFree(d_bc0); hipFree(d_brg); hipFree(d_meta); hipFree(d_val0); hipFree(d_val1); hipFree(d_P);
+        hipFree(d_tp0); hipFree(d_tns); hipFree(d_brg); hipFree(d_meta); hipFree(d_val0); hipFree(d_val1); hipFree(d_P);
     }
     return 0;
 }
