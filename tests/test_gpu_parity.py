@@ -926,10 +926,16 @@ def test_smoothing_sigma_nonzero(name):
     # RegridMatrices_Dynamic.cpp:237-248 + smoother.cpp: M <- smoothI * M, conservative = false, and the
     # conservation correction of apply().  Structure is exact; entries agree to rounding (device exp()
     # and the neighbour order of the absent RTree are not bit-reproducible: parity unpinned at 1e-13).
+    # Both device forms are checked: the wave-per-row direct build (taken for small grids) and the triplet pipeline.
+    from icebin_amd.linear import set_tuning
     g, em, mm, rg = setup("g20")
     sigma = (60e3, 60e3, 250.0)
-    for scale, correctA in ((True, True), (False, False)):
-        w = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA, sigma=sigma).matrix(name)
+    for (scale, correctA), direct in (((True, True), 1), ((False, False), 0), ((True, True), 0)):
+        set_tuning("smooth_direct", direct)
+        try:
+            w = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA, sigma=sigma).matrix(name)
+        finally:
+            set_tuning("smooth_direct", -1)
         o = rg.matrix_d(name, em, scale=scale, correctA=correctA, sigma=sigma)
         plain = rg.matrix_d(name, em, scale=scale, correctA=correctA)
         assert not w.conservative and not o.conservative and w.scaled == scale
