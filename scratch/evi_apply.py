@@ -9,7 +9,9 @@ cfg = sys.argv[1]; name = sys.argv[2] if len(sys.argv) > 2 else "EvI"; nf = 64
 g = syn.make_grids(cfg); em = syn.dome_elevmask(g)
 rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em, scale=True, correctA=True)
 L = _capi.lib(); st = torch.cuda.current_stream(); cs = C.c_void_p(st.cuda_stream)
-for mode in ("rowblock", "rowdual", "colsweep"):
+modes = os.environ.get("EVI_MODES", "rowblock,rowdual,colsweep").split(",")
+for k, v in [kv.split("=") for kv in os.environ.get("EVI_TUNE", "").split(",") if kv]: icebin_amd.set_tuning(k, int(v))
+for mode in modes:
     icebin_amd.set_tuning("rowdual_auto", 1 if mode == "rowdual" else 0)
     icebin_amd.set_tuning("sweep_auto", 1 if mode == "colsweep" else 0)
     icebin_amd.set_tuning("rowdual_min_work", 1)
