@@ -772,21 +772,26 @@ static int pick_kernel(const ibh_weighted *w, int nvar, int nbatch = 1) {
     return kernel;
 }
 struct ShortrowPlan { int fper, g, use_xt, ldt; bool one_entry, big; };
-static ShortrowPlan shortrow_plan(const ibh_weighted *w, int nvar) {
-    // fields per thread.  Small problems (5 km: 76 k rows) are latency-bound and want many short
-    // threads (4 fields for ~1 entry per row, 8 for 2-3); at 1 km (1.9 M rows) the stores dominate
-    // and 16-32 fields per thread amortise the row's CSR reads (measured, scratch/tune_shortrow.py).
+static ShortrowPlan shortrow_plan(const ibh_weighted *w, int nvar, int nbatch = 1) {
+    // fields per thread.  At 1 km (1.9 M rows) the stores dominate and 16-32 fields per thread amortise the row's CSR reads.
+    // Small problems (5 km: 76 k rows): round-2 sweep with the batched kernel (scratch/one_matrix.py, us per 64-field apply,
+    // one launch / 16 per launch): one entry per row (IvA) 8 fields x transposed input 12.1 / 7.0 (4 fields, field-major:
+    // 13.2 / 9.7); 2-3 entries (IvE) 16 fields 16.5 / 9.9, 32 fields 19.2 / 9.5 -- more fields per thread pay in deep launches.
     ShortrowPlan p;
     p.one_entry = (double)w->nnz <= 1.5 * (double)w->nrow;
     p.big = w->nrow >= (1 << 19);
-    p.fper = get_tuning("shortrow_fper", p.big ? (p.one_entry ? 16 : 32) : (p.one_entry ? 4 : 8));
+    const int small_multi = nbatch >= 4 ? 32 : 16;
+    const int small_one = w->nrow >= 16384 ? 8 : 4;
+    p.fper = get_tuning("shortrow_fper", p.big ? (p.one_entry ? 16 : 32) : (p.one_entry ? small_one : small_multi));
     if (p.fper < 1) p.fper = 1;
-    p.g = get_tuning("shortrow_group", p.big ? (p.one_entry ? 8 : 4) : p.fper >= 8 ? 8 : 4);
-    // transposed input: pays when the lanes of a wave gather different columns (>= 2 entries per row:
-    // 5 km IvE 26.9 -> 18.5 us, 1 km IvE 302 -> 183 us) and at bandwidth-bound sizes (1 km IvA 207 ->
-    // 176 us); a latency-bound one-entry apply (5 km IvA, 14 us) only pays for the extra launch
+    p.g = get_tuning("shortrow_group", p.big ? (p.one_entry ? 8 : 4) : (p.fper >= 8 ? 8 : 4));
+    if (p.g > p.fper) p.g = p.fper;
+    // transposed input: the G fields of an entry are 8*G contiguous bytes per lane (one line per entry instead of one per
+    // field): 5 km IvE 26.9 -> 18.5 us, 1 km IvE 302 -> 183 us, 1 km IvA 207 -> 176 us, 5 km IvA 13.2 -> 12.1 us
     p.use_xt = get_tuning("shortrow_xt", -1);
-    if (p.use_xt < 0) p.use_xt = (!p.one_entry || p.big) ? 1 : 0;
+    // (one-entry matrices: the extra launch costs more than it saves for tiny matrices -- EvA: 4.9 -> 8.9 us -- and for a
+    // single launch of few fields -- 5 km IvA, 16 fields: 7.5 -> 9.3 us)
+    if (p.use_xt < 0) p.use_xt = (!p.one_entry || p.big || (w->nrow >= 16384 && (nbatch >= 4 || nvar >= 32))) ? 1 : 0;
     if (p.fper % p.g != 0 || (p.g & 1)) p.use_xt = 0;
     p.ldt = (nvar + 15) & ~15;
     return p;
@@ -865,7 +870,7 @@ static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &
         else IBH_L(1, 4, 4);
 #undef IBH_L
     } else {
-        const ShortrowPlan p = shortrow_plan(w, nvar);
+        const ShortrowPlan p = shortrow_plan(w, nvar, nbatch);
         const int fper = p.fper, g = p.g;
         const long xt_stride = (long)w->ncol * p.ldt;
         // GB-sized results: deep launches cost the L2 locality of the row slices (measured at 1 km: 148 us per apply alone,
