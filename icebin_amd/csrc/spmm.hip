@@ -618,7 +618,9 @@ static void launch_rowblock(const ibh_weighted *w, const BatchPtrs &bp, int nbat
     int unroll = get_tuning("rowblock_unroll", 0);
     if (unroll == 0) {
         const double mean = w->nrow ? (double)w->nnz / (double)w->nrow / (64.0 * WK) : 1.0;
-        unroll = mean > 4.0 ? 8 : mean > 2.0 ? 4 : mean > 1.0 ? 2 : 1;
+        // (a row is one partly filled batch when the unroll overshoots it: 5 km EvI, 2.1 passes of 64 per row, 26.2 / 18.4 us
+        // with four loads in flight, 23.6 / 16.6 with two)
+        unroll = mean > 6.0 ? 8 : mean > 3.0 ? 4 : mean > 1.5 ? 2 : 1;
     }
     // batches per workgroup: the staged row segment and the prologue are shared by qi batches
     int qi = 1;
