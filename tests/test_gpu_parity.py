@@ -1401,6 +1401,41 @@ def test_colsweep_lazy_build_batched_and_shared_dims():
         set_tuning("sweep_min_work", 64 << 20)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_colsweep_on_random_structures(seed):
+    """The column sweep on request for matrices it was not designed around: random columns with 0..5 entries (empty columns:
+    column != item index; more than two entries: several items per column), rows from a window that drifts along the columns
+    (few rows per 64 items), wM == 0 rows (fill), 33 batches in one call (> 32: two launches), 1..70 fields."""
+    import torch
+    rng = np.random.default_rng(100 + seed)
+    nrow, ncol = 400, 9000 + 37 * seed
+    rows, cols = [], []
+    for c in range(ncol):
+        k = int(rng.integers(0, 6)) if c % 11 else 0          # every 11th column is empty
+        base = c * (nrow - 12) // ncol
+        for r in rng.choice(12, size=k, replace=False):
+            rows.append(base + int(r)); cols.append(c)
+    rows, cols = np.array(rows), np.array(cols)
+    vals = rng.standard_normal(len(rows))
+    wM = rng.random(nrow) + 0.5
+    wM[::17] = 0.0
+    Mw = rng.random(ncol) + 0.5
+    w = icebin_amd.linear_Weighted.from_coo((nrow, ncol), rows, cols, vals, wM, Mw)
+    o = orc.Weighted.from_coo(nrow, ncol, rows, cols, vals, wM, Mw)
+    w.set_kernel("colsweep")
+    for nvar in (64, 70, 1):
+        x = rng.standard_normal((nvar, ncol))
+        x[0, ::13] = np.nan
+        y = w.apply(x, fill=-3.0, force_conservation=False)
+        assert w.last_kernel() == "colsweep"
+        assert rel_linf(y, o.apply(x, fill=-3.0, force_conservation=False)) <= FIELD_RTOL
+    xs = [torch.from_numpy(rng.standard_normal((64, ncol))).cuda() for _ in range(33)]
+    outs = w.apply_many_device(xs, fill=-3.0, force_conservation=False)
+    torch.cuda.synchronize()
+    for q in (0, 31, 32):
+        assert rel_linf(outs[q].cpu().numpy(), o.apply(xs[q].cpu().numpy(), fill=-3.0, force_conservation=False)) <= FIELD_RTOL
+
+
 @pytest.mark.parametrize("seed", list(range(10)))
 def test_random_exchange_grids_bit_exact(seed):
     """Randomised differential test of the whole assembly against the oracle: arbitrary (iA, iI) pairs
