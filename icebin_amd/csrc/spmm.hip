@@ -707,9 +707,21 @@ __global__ __launch_bounds__(256) void sweep_combine_kernel(const double *__rest
     if (r >= nrow || f >= nf) return;
     const int k0 = comb_ptr[r], k1 = comb_ptr[r + 1];
     const double *p = P + (long)q * pstride + f;
+    // eight partial rows in flight (index, then value: two dependent loads each), added in task order
     double tot = 0.0;
-    if (k0 < k1) tot = p[(long)comb_p[k0] * ldp];
-    for (int k = k0 + 1; k < k1; ++k) tot += p[(long)comb_p[k] * ldp];
+    int k = k0;
+    if (k < k1) { tot = p[(long)comb_p[k] * ldp]; ++k; }
+    for (; k + 8 <= k1; k += 8) {
+        int idx[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) idx[u] = comb_p[k + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long)idx[u] * ldp];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot += v[u];
+    }
+    for (; k < k1; ++k) tot += p[(long)comb_p[k] * ldp];
     bp.y[q][(long)f * ldy + r] = wM[r] == 0.0 ? fill : tot;
 }
 static size_t sweep_part_count(const ibh_weighted *w, int nvar, int nbatch) {
