@@ -171,10 +171,9 @@ def main():
     def run(launches, gather=True, kev=None):
         """kev: list that receives one (start, stop) HIP event pair per launch, attached to the SpMM
         kernel's own dispatch (ibh_set_launch_events): the kernel's duration without submission gaps."""
-        for (m, xs, xa, ya) in launches:
+        for li, (m, xs, xa, ya) in enumerate(launches):
             if kev is not None:
-                pair = (new_event(), new_event())
-                kev.append(pair)
+                pair = kev[li]                      # created before the timed region (hipEventCreate is not free)
                 L.ibh_set_launch_events(pair[0], pair[1])
             if use_dist and gather:       # field-sharded SpMM + grouped all-gather, icebin_amd/distributed.py
                 if m <= sharded.G:
@@ -200,7 +199,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    kev = [] if not use_dist else None
+    kev = None          # set below: one pre-created (start, stop) event pair per timed launch (N = 1)
 
     def timed(launches, gather=True):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -217,6 +216,8 @@ def main():
         return dt, e0.elapsed_time(e1)
 
     warm_plan, timed_plan = plan(0, args.warmup), plan(args.warmup, args.steps)
+    if not use_dist:
+        kev = [(new_event(), new_event()) for _ in timed_plan]
     with torch.cuda.stream(compute):
         run(warm_plan)
         sync_all()
