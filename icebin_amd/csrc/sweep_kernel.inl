@@ -153,28 +153,34 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
             if (k + 1 < nbk) issue(k + 1);
             if (MODE == 2) { tC = __builtin_amdgcn_s_memtime(); dB += tC - tB; }
             if (mine) {
-                double x[CPW];
-#pragma unroll
-                for (int j = 0; j < CPW; ++j) x[j] = tile[lane * TS + jb + j];
                 if (MODE == 1) {
+                    double x[CPW];
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j) x[j] = tile[lane * TS + jb + j];
 #pragma unroll
                     for (int j = 0; j < CPW; ++j) a0 += x[j];
                     cur = (int)SWEEP_HAS0;
                 } else {
-                    sweep_double2 w[CPW];                   // all weight pairs up front: one LDS round trip, not one per column
+                    // eight columns at a time: their tile values and weight pairs up front -- one LDS round trip per half, not
+                    // one per column; sixteen at a time cost 48 more VGPRs (152 -> 104) and measured 3 % slower
 #pragma unroll
-                    for (int j = 0; j < CPW; ++j) w[j] = wq[j];
+                    for (int h = 0; h < CPW; h += 8) {
+                        double x[8];
+                        sweep_double2 w[8];
 #pragma unroll
-                    for (int j = 0; j < CPW; ++j) {
-                        if (__builtin_expect((int)mk[j] != cur, 0)) {       // not the live pair of rows
-                            if (mk[j] == 0) continue;                       // empty slot
-                            spill();                                        // the sweep moves on to another pair
-                            cur = (int)mk[j]; a0 = 0.0; a1 = 0.0;
+                        for (int j = 0; j < 8; ++j) { x[j] = tile[lane * TS + jb + h + j]; w[j] = wq[h + j]; }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (__builtin_expect((int)mk[h + j] != cur, 0)) {   // not the live pair of rows
+                                if (mk[h + j] == 0) continue;                   // empty slot
+                                spill();                                        // the sweep moves on to another pair
+                                cur = (int)mk[h + j]; a0 = 0.0; a1 = 0.0;
+                            }
+                            // a column with one entry carries w1 = 0 and no HAS1: a1 then collects garbage (0*NaN) that spill()
+                            // never adds
+                            a0 = fma(w[j].x, x[j], a0);
+                            a1 = fma(w[j].y, x[j], a1);
                         }
-                        // a column with one entry carries w1 = 0 and no HAS1: a1 then collects garbage (0*NaN) that spill()
-                        // never adds
-                        a0 = fma(w[j].x, x[j], a0);
-                        a1 = fma(w[j].y, x[j], a1);
                     }
                 }
             }
