@@ -506,6 +506,30 @@ def test_config5_antarctica_1km_elevation_class_matrices():
     assert np.all(np.abs(back - 1.0) < 1e-11)
 
 
+def test_config5_antarctica_colsweep_agrees_with_rowblock_at_64_fields():
+    # full-size cross-check of the two EvI kernels (8.4 GB of fields; the oracle is out of reach at this size): the column
+    # sweep and the row-by-row kernel evaluate the same sums in different orders -- 1e-12 of each other, same NaN pattern,
+    # constants reproduced (rows of the scaled matrix sum to 1)
+    import torch
+    g = _big_grids("a1h")
+    em = syn.dome_elevmask(g)
+    w = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em, scale=True, correctA=False).matrix("EvI")    # (the synthetic sheet's name)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((64, w.ncol_d), dtype=torch.float64, device="cuda", generator=gen)
+    x[3, ::1000003] = float("nan")
+    x[5].fill_(1.0)
+    w.set_kernel("rowblock")
+    y_row = w.apply_device(x, fill=-1.0, force_conservation=False).cpu().numpy()
+    w.set_kernel("colsweep")
+    y_col = w.apply_device(x, fill=-1.0, force_conservation=False)
+    torch.cuda.synchronize()
+    assert w.last_kernel() == "colsweep"
+    y_col = y_col.cpu().numpy()
+    assert rel_linf(y_col, y_row) <= FIELD_RTOL
+    live = w.wM != 0
+    assert np.all(np.abs(y_col[5][live] - 1.0) < 1e-11)
+
+
 def test_config5_greenland_1km_half_degree_sheet():
     # the other sheet of config 5: Greenland 1 km <-> 1/2 deg
     W = _sheet_properties("g1h", ("AvI", "IvA"), 4204301)
