@@ -693,20 +693,28 @@ static void launch_rowdual(const ibh_weighted *w, const BatchPtrs &bp, int nbatc
     IBH_HIP(hipGetLastError());
 }
 
+// fields per lane group of the sweep: 64 (one batch per wave row) from 33 fields; below, the next power of two >= 8 so that
+// 64 / nfl batches share the lanes
+static int sweep_lg(int nvar) { return nvar > 32 ? 6 : nvar > 16 ? 5 : nvar > 8 ? 4 : 3; }
+// lanes of the sweep that carry a (batch, field) pair for nvar fields in launches of nbatch
+static int sweep_lanes(int nvar, int nbatch) { return nvar > 32 ? 64 : nvar * std::min(nbatch, 64 >> sweep_lg(nvar)); }
 // ---- colsweep (sweep_kernel.inl): E-row matrices, >= 32 fields ------------------------------------------------
 // Y[f, r] = the partial sums of the tasks that touch row r (comb_p[comb_ptr[r] .. comb_ptr[r+1])), in task order; rows no
 // task touches are 0, rows with wM == 0 hold `fill` (mask_result, IceCoupler.cpp:186-201).
 __global__ __launch_bounds__(256) void sweep_combine_kernel(const double *__restrict__ P, long pstride, long ldp,
                                                             const int *__restrict__ comb_ptr, const int *__restrict__ comb_p,
                                                             const double *__restrict__ wM, double fill, const BatchPtrs bp, long ldy,
-                                                            int nrow, int nf)
+                                                            int nrow, int nf, int lg)
 {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int f = blockIdx.y * 64 + (threadIdx.x & 63);
     const int q = blockIdx.z;
     if (r >= nrow || f >= nf) return;
     const int k0 = comb_ptr[r], k1 = comb_ptr[r + 1];
-    const double *p = P + (long)q * pstride + f;
+    // the sweep's lanes are (batch, field) pairs (sweep_kernel.inl): lg = 6 -> one batch per slice, lane = field of the field
+    // block; lg < 6 -> 64 >> lg batches per slice, lane = (batch % G) << lg | field
+    const int G = 64 >> lg;
+    const double *p = lg == 6 ? P + (long)q * pstride + f : P + (long)(q / G) * pstride + ((q % G) << lg) + f;
     // eight partial rows in flight (index, then value: two dependent loads each), added in task order
     double tot = 0.0;
     int k = k0;
@@ -724,21 +732,29 @@ __global__ __launch_bounds__(256) void sweep_combine_kernel(const double *__rest
     for (; k < k1; ++k) tot += p[(long)comb_p[k] * ldp];
     bp.y[q][(long)f * ldy + r] = wM[r] == 0.0 ? fill : tot;
 }
+// fields per lane group of the sweep: 64 (one batch per wave row) from 33 fields; below, the next power of two >= 8 so that
+// 64 / nfl batches share the lanes
 static size_t sweep_part_count(const ibh_weighted *w, int nvar, int nbatch) {
-    return (size_t)nbatch * (size_t)w->sweep_nprow * (size_t)(ceil_div(nvar, 64) * 64);
+    const int lg = sweep_lg(nvar);
+    const size_t slices = lg == 6 ? (size_t)nbatch : (size_t)ceil_div(nbatch, 64 >> lg);
+    const size_t ldp = lg == 6 ? (size_t)ceil_div(nvar, 64) * 64 : 64;
+    return slices * (size_t)w->sweep_nprow * ldp;
 }
 static void launch_sweep(const ibh_weighted *w, const BatchPtrs &bp, int nbatch, int nvar, long lda, long ldb, double fill,
                          hipStream_t stream)
 {
-    const int nfb = ceil_div(nvar, 64);
+    const int lg = sweep_lg(nvar), G = 64 >> lg;
+    const int nfb = lg == 6 ? ceil_div(nvar, 64) : 1, nz = lg == 6 ? nbatch : ceil_div(nbatch, G);
     const long ldp = (long)nfb * 64, pstride = (long)w->sweep_nprow * ldp;
     grow_scratch(w->sweep_part, sweep_part_count(w, nvar, nbatch), stream, "column-sweep");
     SweepView sv{w->sweep_task_p0.p, w->sweep_task_ns.p, w->sweep_col.p, w->sweep_meta.p, w->sweep_v0.p, w->sweep_v1.p,
                  w->sweep_tb, w->sweep_nblk, w->sweep_nitems};
     SweepBatch sb{};
-    for (int q = 0; q < nbatch; ++q) { sb.x[q] = bp.x[q]; sb.p[q] = w->sweep_part.p + (size_t)q * (size_t)pstride; }
+    for (int q = 0; q < nbatch; ++q) sb.x[q] = bp.x[q];
+    for (int zz = 0; zz < nz; ++zz) sb.p[zz] = w->sweep_part.p + (size_t)zz * (size_t)pstride;
     const size_t lds = sweep_lds_bytes(w->sweep_nslot);
-    const bool full = nvar % 64 == 0, ident = w->sweep_ident != 0;
+    const bool full = lg == 6 ? nvar % 64 == 0 : (nvar == (1 << lg) && nbatch % G == 0);
+    const bool ident = w->sweep_ident != 0;
     const void *fn = full ? (ident ? reinterpret_cast<const void *>(spmm_sweep_kernel<true, true, 0>) : reinterpret_cast<const void *>(spmm_sweep_kernel<true, false, 0>))
                           : (ident ? reinterpret_cast<const void *>(spmm_sweep_kernel<false, true, 0>) : reinterpret_cast<const void *>(spmm_sweep_kernel<false, false, 0>));
     if (lds > 64 * 1024) {                               // beyond the default dynamic-LDS limit: raise it once per device and variant
@@ -751,17 +767,17 @@ static void launch_sweep(const ibh_weighted *w, const BatchPtrs &bp, int nbatch,
             raised[dev][var] = true;
         }
     }
-    const dim3 grid((unsigned)w->sweep_ntask, (unsigned)nfb, (unsigned)nbatch);
+    const dim3 grid((unsigned)w->sweep_ntask, (unsigned)nfb, (unsigned)nz);
     hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
     // launch timing: start = the sweep kernel begins, stop = the combine kernel ends (both belong to the apply)
-#define IBH_SW(F, I) hipExtLaunchKernelGGL((spmm_sweep_kernel<F, I, 0>), grid, dim3(SWEEP_NW * 64), lds, stream, ev0, nullptr, 0, sv, sb, lda, nvar, w->sweep_nslot, ldp)
+#define IBH_SW(F, I) hipExtLaunchKernelGGL((spmm_sweep_kernel<F, I, 0>), grid, dim3(SWEEP_NW * 64), lds, stream, ev0, nullptr, 0, sv, sb, lda, nvar, w->sweep_nslot, ldp, lg, nbatch)
     if (full) { if (ident) IBH_SW(true, true); else IBH_SW(true, false); }
     else { if (ident) IBH_SW(false, true); else IBH_SW(false, false); }
 #undef IBH_SW
     hipExtLaunchKernelGGL(sweep_combine_kernel, dim3((unsigned)ceil_div(w->nrow, 4), (unsigned)nfb, (unsigned)nbatch), dim3(256), 0, stream, nullptr, ev1, 0,
                        w->sweep_part.p, pstride, ldp, w->sweep_comb_ptr.p, w->sweep_comb_p.p, w->wM.p, fill,
-                       bp, ldb, w->nrow, nvar);
+                       bp, ldb, w->nrow, nvar, lg);
     IBH_HIP(hipGetLastError());
 }
 
@@ -779,7 +795,7 @@ static int pick_kernel(const ibh_weighted *w, int nvar, int nbatch = 1) {
     // the column sweep, once its structure exists: always for E-row matrices (every X element read once instead of twice);
     // for the other long-row matrices (AvI, AvX) in batched launches only (measured at 1 km, 64 fields: 167 against 173 us
     // per apply 32 deep, but 193 against 183 us one launch per apply -- two kernels and a prologue per task)
-    if (kernel == 1 && w->kernel_override == 0 && w->sweep_ntask > 0 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
+    if (kernel == 1 && w->kernel_override == 0 && w->sweep_ntask > 0 && sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
         (w->band_eligible || nbatch >= get_tuning("sweep_min_batch", 4))) kernel = 4;
     if (kernel == 1 && w->kernel_override == 0 && w->band_n > 0 && nvar >= 4 && get_tuning("rowdual_auto", 1)) kernel = 3;
     if (kernel == 3 && w->band_n == 0) kernel = 1;            // no bands were built for this matrix
@@ -951,8 +967,8 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
     const bool long_rows = w->nrow > 0 && (double)w->nnz / (double)w->nrow >= 64.0 && w->nnz <= 2 * (int64_t)w->ncol;      // AvI, AvX
     if (!w->sweep_tried && w->sweep_ntask == 0 &&
         (w->kernel_override == 4 ||
-         ((w->band_eligible || (long_rows && nbatch >= get_tuning("sweep_min_batch", 4))) && w->kernel_override == 0 && w->napply >= 1 && nvar >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
-          (double)w->nnz * nvar >= (double)get_tuning("sweep_min_work", 64 << 20)))) {
+         ((w->band_eligible || (long_rows && nbatch >= get_tuning("sweep_min_batch", 4))) && w->kernel_override == 0 && w->napply >= 1 && sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
+          (double)w->nnz * sweep_lanes(nvar, nbatch) >= (double)get_tuning("sweep_min_work", 64 << 20)))) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
         if (cs == hipStreamCaptureStatusNone) { w->sweep_tried = 1; build_sweep_from_csr(w, stream); }

@@ -65,7 +65,7 @@ typedef double sweep_double2 __attribute__((ext_vector_type(2)));
 // is never read -- the first tile loads of a task depend on nothing but the kernel arguments.
 template <bool FULL, bool IDENT, int MODE = 0>
 __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepView sv, const SweepBatch sb, long ldx, int nf,
-                                                                   int nslot_max, long ldp)
+                                                                   int nslot_max, long ldp, int lg, int nbatch)
 {
     constexpr int NW = SWEEP_NW, TS = SWEEP_TS, FPW = 64 / NW, CPW = SWEEP_CB / NW;   // planes loaded / columns consumed per wave
     extern __shared__ double s_mem[];
@@ -74,20 +74,32 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
     double *tile = s_mem;                                           // [64 fields][TS]
     double *acc = s_mem + 64 * TS + wave * (nslot_max * 64);        // [slots][64 fields] per wave
     const int t = sweep_xcd_contiguous(blockIdx.x, gridDim.x);
-    const int fb = blockIdx.y, q = blockIdx.z;
-    const double *__restrict__ X = sb.x[q];
+    // The 64 lanes are (batch, field) pairs: nfl = 1 << lg fields of 64 / nfl field batches (lg = 6: the 64 fields of field
+    // block blockIdx.y of ONE batch).  Fewer than 33 fields per batch would leave lanes idle; the batches of a batched launch
+    // sweep the same columns and feed the same rows, so they share a wave: plane p = (batch z*G + (p >> lg), field p & (nfl-1)).
+    const int z = blockIdx.z, nfl = 1 << lg, G = 64 >> lg;
     const int b0 = t * sv.tb, b1 = min(sv.nblk, b0 + sv.tb);
     const int p0 = sv.task_p0[t], ns = min(sv.task_ns[t], nslot_max);        // needed at the very end only
     for (int s = 0; s < nslot_max; ++s) acc[s * 64 + lane] = 0.0;
-    const int fmine = fb * 64 + wave * FPW;                         // first plane this wave loads
-    const int fld = fb * 64 + lane;                                 // the field this lane accumulates
-    const int nfw = min(FPW, nf - fmine);                           // planes of this wave that exist
-    (void)nfw;
-    const int pbase = min(fmine, nf - 1);                           // planes past nf repeat the last plane (loaded, never used)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)pbase * ldx), 0, -1 /* 4 GB */, 0x00020000);
-    unsigned poff[FPW];                                             // byte offsets of this wave's planes from its first
+    auto plane_field = [&](int p) { return lg == 6 ? (int)blockIdx.y * 64 + p : (p & (nfl - 1)); };
+    auto plane_batch = [&](int p) { return lg == 6 ? z : z * G + (p >> lg); };
+    const bool lane_live = plane_field(lane) < nf && plane_batch(lane) < nbatch;     // this lane's (batch, field) exists
+    // this wave loads planes [16 wave, 16 wave + 16): two halves of eight (a half never straddles two batches: nfl >= 8), one
+    // buffer descriptor per half based at the half's first plane; planes that do not exist repeat the last one that does
+    __amdgpu_buffer_rsrc_t rs[2];
+    unsigned poff[FPW];                                             // byte offsets of the planes from their half's first
 #pragma unroll
-    for (int i = 0; i < FPW; ++i) poff[i] = (unsigned)((long)((FULL ? fmine + i : min(fmine + i, nf - 1)) - pbase) * ldx * 8);
+    for (int h = 0; h < 2; ++h) {
+        const int pf = wave * FPW + 8 * h;
+        const int bq = FULL ? plane_batch(pf) : min(plane_batch(pf), nbatch - 1);
+        const int f0 = FULL ? plane_field(pf) : min(plane_field(pf), nf - 1);
+        rs[h] = __builtin_amdgcn_make_buffer_rsrc((void *)(sb.x[bq] + (long)f0 * ldx), 0, -1 /* 4 GB */, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = FULL ? plane_field(pf + i) : min(plane_field(pf + i), nf - 1);
+            poff[8 * h + i] = (unsigned)((long)(f - f0) * ldx * 8);
+        }
+    }
 
     int cur = -1;                         // meta word of the live pair
     double a0 = 0.0, a1 = 0.0;
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
             cnx = columns(k + 1);
 #pragma unroll
             for (int i = 0; i < FPW; ++i)
-                xr[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, boff, (int)poff[i], 0));
+                xr[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs[i >> 3], boff, (int)poff[i], 0));
             const long it = (long)(kc + k) * SWEEP_CB + jb + (lane & (CPW - 1));
             v0 = sv.it_v0[it]; v1 = sv.it_v1[it];
         };
@@ -195,7 +207,8 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
         unsigned long *dbg = reinterpret_cast<unsigned long *>(sb.p[1]) + ((long)t * NW + wave) * 8;
         dbg[0] = dA; dbg[1] = dB; dbg[2] = dC; dbg[3] = dD; dbg[4] = dn;
     }
-    double *__restrict__ P = sb.p[q];
+    double *__restrict__ P = sb.p[z];
+    const int fld = (lg == 6 ? (int)blockIdx.y * 64 : 0) + lane;    // this lane's column of the partial-sum rows
     __syncthreads();
     // the task's partial sums: the waves' tables added in wave order, slots dealt round-robin to the waves
     const double *acc0 = s_mem + 64 * TS;
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(SWEEP_NW * 64) void spmm_sweep_kernel(const SweepVi
         double tot = acc0[s * 64 + lane];
 #pragma unroll
         for (int w = 1; w < NW; ++w) tot += acc0[w * (nslot_max * 64) + s * 64 + lane];
-        if (fld < nf) P[(long)(p0 + s) * ldp + fld] = tot;
+        if (lane_live) P[(long)(p0 + s) * ldp + fld] = tot;
     }
 }
 

@@ -1425,6 +1425,36 @@ def test_colsweep_lazy_build_batched_and_shared_dims():
         set_tuning("sweep_min_work", 64 << 20)
 
 
+@pytest.mark.parametrize("nvar,nbatch", [(16, 4), (16, 5), (8, 9), (12, 8), (24, 3), (32, 2), (5, 33)])
+def test_colsweep_batches_share_lanes(nvar, nbatch):
+    # fewer than 33 fields per batch: the 64 lanes of the sweep are (batch, field) pairs -- 64 / nfl batches of a batched launch
+    # share a wave (they sweep the same columns and feed the same rows); ragged last slices, field counts that are not powers of
+    # two, more than 32 batches; automatic choice: taken on the second apply once enough lanes carry data
+    import torch
+    from icebin_amd.linear import set_tuning
+    g, em, mm, rg = setup("g5")
+    set_tuning("sweep_min_work", 1)
+    try:
+        rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+        w, o = rm.matrix("EvI"), rg.matrix_d("EvI", em, scale=True, correctA=True)
+        xs = [torch.from_numpy(syn.fields(nvar, w.ncol_d, seed=300 + q)).cuda() for q in range(nbatch)]
+        xs[nbatch // 2][nvar - 1, ::9] = float("nan")
+        w.apply_many_device(xs, fill=-2.0, force_conservation=False)         # first apply: nothing built yet
+        outs = w.apply_many_device(xs, fill=-2.0, force_conservation=False)
+        torch.cuda.synchronize()
+        lanes = 64 if nvar > 32 else nvar * min(nbatch, 64 // (8 if nvar <= 8 else 16 if nvar <= 16 else 32))
+        assert w.last_kernel() == ("colsweep" if lanes >= 32 else "rowblock")
+        for q in (0, nbatch // 2, nbatch - 1):
+            assert rel_linf(outs[q].cpu().numpy(), o.apply(xs[q].cpu().numpy(), fill=-2.0, force_conservation=False)) <= FIELD_RTOL
+        w.set_kernel("colsweep")                                             # on request also with few lanes
+        y = w.apply_device(xs[0], fill=-2.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert w.last_kernel() == "colsweep"
+        assert rel_linf(y.cpu().numpy(), o.apply(xs[0].cpu().numpy(), fill=-2.0, force_conservation=False)) <= FIELD_RTOL
+    finally:
+        set_tuning("sweep_min_work", 64 << 20)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_colsweep_on_random_structures(seed):
     """The column sweep on request for matrices it was not designed around: random columns with 0..5 entries (empty columns:
