@@ -1,23 +1,22 @@
-// sweep_kernel.inl -- K1d: column-sweep apply for matrices whose rows come in small groups over a shared
-// column range (EvI / EvX: the elevation classes of one GCM cell over that cell's ice cells).
+// sweep_kernel.inl -- K1d: column-sweep apply for matrices with short columns (EvI / EvX: an ice cell is a column of
+// the two elevation classes it lies between; AvI / AvX: of one GCM cell).
 //
-// Row by row such a matrix reads every X element once per class row it feeds (measured at 1 km: 2.0 GB
-// fetched for 1.03 GB algorithmic); the band structure (rowdual) still wastes 64-byte lines (1.39 x).  Here
-// the columns of a group are swept ONCE, in ascending order, in blocks of 64 of the group's columns (the group's own
-// range is contiguous: consecutive columns; the few cells it shares with a neighbouring GCM cell lie elsewhere and are
-// packed together):
-//   load     the four waves of a workgroup bring the block's X tile (64 fields x 64 columns) in with plain loads, lane =
+// Row by row an E-row matrix reads every X element once per class row it feeds (measured at 1 km: 2.0 GB fetched for
+// 1.03 GB algorithmic); the band structure (rowdual) still wastes 64-byte lines (1.39 x).  Here ALL columns are swept
+// ONCE, in ascending order.  The structure (assemble.hip build_sweep_from_csr): entries ordered by column and paired
+// into ITEMS (a column + <= 2 of its entries), 64 items a block, tb blocks a task; a task's local row table = the distinct
+// rows its columns touch ("slots").  Per block:
+//   load     the four waves of a workgroup bring the block's X tile (64 planes x 64 columns) in with plain loads, lane =
 //            column -- one instruction = one field plane x 512 contiguous bytes for consecutive columns, whatever the
-//            alignment of the planes (odd leading dimensions) -- and park it in LDS;
-//   consume  transposed: the LANES ARE THE FIELDS, wave w takes columns [16w, 16w+16) of the block.  Which
-//            rows a column feeds is then WAVE-UNIFORM (scalar metadata, broadcast weights), so the accumulators
-//            need no cross-lane reduction at all: one live pair of rows in two registers, spilled to a
-//            per-wave LDS table acc[slot][lane] when the sweep moves on to another pair (neighbouring ice
-//            cells lie between the same two classes for long runs).
-// A task = a run of blocks of one group; it leaves one partial sum per (row of the group, field), and
-// sweep_combine_kernel adds the partials of a row in task order.  Fixed order throughout -> bitwise
-// reproducible; entries are predicated by existence, never multiplied by a padded zero (0*NaN must not
-// leak into a row).
+//            alignment of the planes (odd leading dimensions) -- one block ahead, and park it in LDS;
+//   consume  transposed: the LANES ARE THE FIELDS (of one batch, or -- fewer than 33 fields -- of 64/nfl batches of a batched
+//            launch), wave w takes columns [16w, 16w+16) of the block.  Which rows a column feeds is then WAVE-UNIFORM
+//            (scalar metadata, broadcast weights), so the accumulators need no cross-lane reduction at all: one live pair
+//            of rows in two registers, spilled to a per-wave LDS table acc[slot][lane] when the sweep moves on to another
+//            pair (neighbouring ice cells lie between the same two classes for long runs).
+// A task leaves one partial sum per (row it touches, lane); sweep_combine_kernel (spmm.hip) adds the partial rows of a row
+// in task order.  Fixed order throughout -> bitwise reproducible; entries are predicated by existence, never multiplied by
+// a padded zero (0*NaN must not leak into a row).  Design notes and measurements: DESIGN.md K1d.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -59,7 +58,7 @@ __device__ __forceinline__ int sweep_xcd_contiguous(int b, int nb) {
 typedef const unsigned __attribute__((address_space(4))) *sweep_cu32;
 typedef double sweep_double2 __attribute__((ext_vector_type(2)));
 
-// FULL: all 64 fields of the field block exist.  MODE (diagnostics, scratch/sweep_bench.hip): 0 the kernel; 1 tile traffic only;
+// FULL: all 64 planes of the wave row exist (64 | nvar, or nvar == nfl and a whole number of batch groups).  MODE (diagnostics, scratch/sweep_bench.hip): 0 the kernel; 1 tile traffic only;
 // 2 the kernel with s_memtime stamps around its phases (per wave sums to sb.p[1])
 // IDENT: every column has exactly one item (AvI, AvX: <= 2 entries per column), so item index = column and the column list
 // is never read -- the first tile loads of a task depend on nothing but the kernel arguments.

@@ -67,7 +67,7 @@ int main(int argc, char **argv) {
         const size_t lds = ibh::sweep_lds_bytes(NSL);
         auto launch = [&](int i) {
             sb.x[0] = d_X + xn * (i % nbuf); sb.p[0] = d_P;
-#define L_(I, M) hipLaunchKernelGGL((ibh::spmm_sweep_kernel<true, I, M>), dim3(ntask, 1, 1), dim3(64 * ibh::SWEEP_NW), lds, 0, sv, sb, ldx, nf, NSL, 64l)
+#define L_(I, M) hipLaunchKernelGGL((ibh::spmm_sweep_kernel<true, I, M>), dim3(ntask, 1, 1), dim3(64 * ibh::SWEEP_NW), lds, 0, sv, sb, ldx, nf, NSL, 64l, 6, 1)
             if (IDENT) { if (MODE == 0) L_(true, 0); else L_(true, 1); }
             else { if (MODE == 0) L_(false, 0); else L_(false, 1); }
         };
