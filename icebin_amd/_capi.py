@@ -96,6 +96,7 @@ _SIGS = {
     "ibh_coo_matvec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
     "ibh_weighted_reserve": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ibh_weighted_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "ibh_weighted_apply_transformed_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
                                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_double,
                                                        C.c_void_p]),

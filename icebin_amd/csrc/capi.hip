@@ -530,6 +530,13 @@ int ibh_weighted_reserve(const ibh_weighted *w, int32_t nvar) {
         weighted_reserve(w, nvar);
     });
 }
+int ibh_weighted_prepare(const ibh_weighted *w, int32_t nvar, int32_t nbatch) {
+    return guarded([&] {
+        check_weighted_device(w);
+        IBH_CHECK(nvar >= 0 && nbatch >= 0, "bad arguments");
+        weighted_prepare(w, nvar, nbatch);
+    });
+}
 int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nvar, int64_t lda, double *B_b,
                             int64_t ldb, double fill, int force_conservation) {
     return guarded([&] {

@@ -250,6 +250,7 @@ void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda,
 void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA, int nvar, int64_t lda,
                       double *const *dB, int64_t ldb, double fill, int force_conservation, hipStream_t stream);
 void weighted_reserve(const ibh_weighted *w, int nvar);
+void weighted_prepare(const ibh_weighted *w, int nvar, int nbatch);
 // assemble.hip: the band structure of an E-row matrix from its CSR (same result as building it with the matrix)
 void build_bands_from_csr(const ibh_weighted *w, hipStream_t st);
 // assemble.hip: the column-sweep structure of an E-row matrix from its CSR (sweep_kernel.inl); false: not representable

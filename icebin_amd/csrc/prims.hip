@@ -27,26 +27,49 @@ void *Arena::get_bytes(size_t bytes) {
     return nb.p;
 }
 // One arena per (host thread, device): blocks hipMalloc'd on one GPU must never serve a build that
-// runs on another (ibh_set_device switches devices inside one process).
+// runs on another (ibh_set_device switches devices inside one process).  Every thread's set is
+// registered process-wide so that ibh_release_cached_memory() reaches the worker threads' arenas too
+// (assemble_batch: three workers, each with blocks of >= 64 MB and GBs after an Antarctic batch).
 namespace {
+struct ArenaSet;
+struct ArenaRegistry {
+    std::mutex mu;
+    std::vector<ArenaSet *> sets;
+};
+ArenaRegistry &arena_registry() { static ArenaRegistry *r = new ArenaRegistry; return *r; }      // leaked: outlives thread_local teardown
 struct ArenaSet {
     std::map<int, Arena> by_device;
+    ArenaSet() {
+        std::lock_guard<std::mutex> lk(arena_registry().mu);
+        arena_registry().sets.push_back(this);
+    }
+    ~ArenaSet() {
+        std::lock_guard<std::mutex> lk(arena_registry().mu);
+        auto &v = arena_registry().sets;
+        v.erase(std::remove(v.begin(), v.end(), this), v.end());
+    }
 };
 ArenaSet &arena_set() { static thread_local ArenaSet s; return s; }
 }  // namespace
 Arena &arena() {
     int dev = 0;
     IBH_HIP(hipGetDevice(&dev));
-    return arena_set().by_device[dev];
+    ArenaSet &s = arena_set();
+    std::lock_guard<std::mutex> lk(arena_registry().mu);      // the map may be walked by release_workspace()
+    return s.by_device[dev];
 }
+// Frees the blocks of every thread's arenas.  The caller guarantees that no build is in flight (a build holds
+// pointers into its thread's arena).
 void release_workspace() {
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
-    for (auto &kv : arena_set().by_device) {
-        if (have) (void)hipSetDevice(kv.first);
-        for (auto &b : kv.second.blocks) (void)hipFree(b.p);
-        kv.second.blocks.clear();
-    }
+    std::lock_guard<std::mutex> lk(arena_registry().mu);
+    for (ArenaSet *set : arena_registry().sets)
+        for (auto &kv : set->by_device) {
+            if (have) (void)hipSetDevice(kv.first);
+            for (auto &b : kv.second.blocks) (void)hipFree(b.p);
+            kv.second.blocks.clear();
+        }
     if (have) (void)hipSetDevice(cur);
 }
 

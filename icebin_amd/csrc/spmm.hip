@@ -827,19 +827,82 @@ static ShortrowPlan shortrow_plan(const ibh_weighted *w, int nvar, int nbatch = 
     return p;
 }
 
-void weighted_reserve(const ibh_weighted *w, int nvar) {
-    if (nvar <= 0) return;
-    const int kernel = pick_kernel(w, nvar);
-    if (kernel == 3 || w->band_n > 0) grow_scratch(w->band_part, band_part_count(w, nvar, 1), nullptr, "band");
-    if (w->sweep_ntask > 0) grow_scratch(w->sweep_part, sweep_part_count(w, nvar, 1), nullptr, "column-sweep");
-    if (kernel == 2 || w->kernel_override == 0) {
-        const ShortrowPlan p = shortrow_plan(w, nvar);
-        if (p.use_xt && pick_kernel(w, nvar) == 2) grow_scratch(w->xt, (size_t)w->ncol * (size_t)p.ldt, nullptr, "transposed-input");
+// ---- lazily built apply structures (column sweep, bands) ---------------------------------------------------
+// Which structure applies of (nvar fields, nbatch per launch) would use, by the rules the apply path has always had;
+// `seen` = the matrix has been applied before (an apply builds on the SECOND call only: the coupler's one build : one apply
+// must not pay for a structure it never reuses; ibh_weighted_prepare builds at once).
+static bool wants_sweep(const ibh_weighted *w, int nvar, int nbatch, bool seen) {
+    if (w->sweep_tried || w->sweep_ntask > 0) return false;
+    if (w->kernel_override == 4) return true;
+    const bool long_rows = w->nrow > 0 && (double)w->nnz / (double)w->nrow >= 64.0 && w->nnz <= 2 * (int64_t)w->ncol;      // AvI, AvX
+    return (w->band_eligible || (long_rows && nbatch >= get_tuning("sweep_min_batch", 4))) && w->kernel_override == 0 && seen &&
+           sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
+           (double)w->nnz * sweep_lanes(nvar, nbatch) >= (double)get_tuning("sweep_min_work", 64 << 20);
+}
+static bool wants_bands(const ibh_weighted *w, int nvar, bool seen) {
+    return w->band_eligible && !w->band_tried && w->band_n == 0 && w->sweep_ntask == 0 && seen && w->kernel_override == 0 && nvar >= 4 &&
+           (double)w->nnz * nvar >= (double)get_tuning("rowdual_min_work", 128 << 20) && get_tuning("rowdual_auto", 1);
+}
+static void drop_sweep(const ibh_weighted *w) {
+    w->sweep_ntask = 0;
+    w->sweep_task_p0.release(); w->sweep_task_ns.release(); w->sweep_col.release(); w->sweep_meta.release();
+    w->sweep_v0.release(); w->sweep_v1.release(); w->sweep_comb_ptr.release(); w->sweep_comb_p.release();
+}
+static void drop_bands(const ibh_weighted *w) {
+    w->band_n = 0;
+    w->band_ptr.release(); w->band_col.release(); w->band_rb1.release(); w->band_v0.release(); w->band_v1.release();
+}
+// A structure that cannot be built (out of memory, not representable) is no reason to fail an apply the row-by-row kernel
+// serves: the failure is swallowed, the structure marked as tried, the matrix keeps its kernel.  Never inside a capture.
+static void build_structures(const ibh_weighted *w, int nvar, int nbatch, bool seen, hipStream_t stream) {
+    const bool sweep = wants_sweep(w, nvar, nbatch, seen);
+    if (!sweep && !wants_bands(w, nvar, seen)) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
+    if (cs != hipStreamCaptureStatusNone) return;
+    if (sweep) {
+        w->sweep_tried = 1;
+        try { build_sweep_from_csr(w, stream); }
+        catch (const Error &) { (void)hipGetLastError(); drop_sweep(w); }
+    }
+    if (wants_bands(w, nvar, seen)) {
+        w->band_tried = 1;
+        try { build_bands_from_csr(w, stream); }
+        catch (const Error &) { (void)hipGetLastError(); drop_bands(w); }
+    }
+}
+
+// Scratch of every kernel that applies of (nvar, <= nbatch per launch) can pick -- all of them: a later
+// ibh_weighted_set_kernel, or a tuning change, must not turn a captured apply into an allocation.
+static void size_scratch(const ibh_weighted *w, int nvar, int nbatch) {
+    if (w->band_n > 0) grow_scratch(w->band_part, band_part_count(w, nvar, nbatch), nullptr, "band");
+    if (w->sweep_ntask > 0) grow_scratch(w->sweep_part, sweep_part_count(w, nvar, nbatch), nullptr, "column-sweep");
+    if (pick_kernel(w, nvar, nbatch) == 2 || pick_kernel(w, nvar, 1) == 2 || w->kernel_override == 0) {
+        for (int nb : {1, nbatch}) {
+            const ShortrowPlan p = shortrow_plan(w, nvar, nb);
+            const int qmax = std::max(1, get_tuning("shortrow_many", w->nrow >= (1 << 19) ? 1 : IBH_MAX_BATCH));
+            if (p.use_xt && (pick_kernel(w, nvar, nb) == 2 || w->kernel_override == 2))
+                grow_scratch(w->xt, (size_t)w->ncol * (size_t)p.ldt * (size_t)std::min(qmax, nb), nullptr, "transposed-input");
+        }
     }
     grow_scratch(w->consv, 2 * (size_t)nvar + weight_dot_scratch(std::max(w->nrow, w->ncol), nvar), nullptr, "conservation");
     // apply_transformed: the small side holds nvar fields
     grow_scratch(w->scratch, (size_t)nvar * (size_t)std::min(w->nrow, w->ncol), nullptr, "transform");
     ensure_rowsum1(w, nullptr);
+    if (get_tuning("rowblock_lpt", 0)) (void)ensure_rowperm(w, nullptr);
+}
+
+void weighted_reserve(const ibh_weighted *w, int nvar) {
+    if (nvar <= 0) return;
+    size_scratch(w, nvar, 1);
+}
+
+void weighted_prepare(const ibh_weighted *w, int nvar, int nbatch) {
+    if (nvar <= 0 || nbatch <= 0 || w->nrow == 0) return;
+    const int nb = std::min(nbatch, IBH_MAX_BATCH);           // deeper batches are split into launches of IBH_MAX_BATCH
+    build_structures(w, nvar, nb, true, nullptr);
+    size_scratch(w, nvar, nb);
+    IBH_HIP(hipStreamSynchronize(nullptr));
 }
 
 static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &bp, int nbatch, int nvar, int64_t lda,
@@ -964,21 +1027,9 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
     // for the coupler's one build : one apply, hence on the second apply and only for bandwidth-sized work (measured, 64
     // fields: 1 km EvI 292 -> 255 us; at 5 km the extra combine pass costs more than the halved traffic saves, 18.5 -> 21.9).
     // ... or, with >= 32 fields, the column-sweep structure (sweep_kernel.inl): every X element read once, in whole lines.
-    const bool long_rows = w->nrow > 0 && (double)w->nnz / (double)w->nrow >= 64.0 && w->nnz <= 2 * (int64_t)w->ncol;      // AvI, AvX
-    if (!w->sweep_tried && w->sweep_ntask == 0 &&
-        (w->kernel_override == 4 ||
-         ((w->band_eligible || (long_rows && nbatch >= get_tuning("sweep_min_batch", 4))) && w->kernel_override == 0 && w->napply >= 1 && sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
-          (double)w->nnz * sweep_lanes(nvar, nbatch) >= (double)get_tuning("sweep_min_work", 64 << 20)))) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
-        if (cs == hipStreamCaptureStatusNone) { w->sweep_tried = 1; build_sweep_from_csr(w, stream); }
-    }
-    if (w->band_eligible && !w->band_tried && w->band_n == 0 && w->sweep_ntask == 0 && w->napply >= 1 && w->kernel_override == 0 && nvar >= 4 &&
-        (double)w->nnz * nvar >= (double)get_tuning("rowdual_min_work", 128 << 20) && get_tuning("rowdual_auto", 1)) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
-        if (cs == hipStreamCaptureStatusNone) { w->band_tried = 1; build_bands_from_csr(w, stream); }
-    }
+    // This is the one place where an apply synchronises and allocates: ibh_weighted_prepare() does it up front,
+    // ibh_set_tuning("lazy_structures", 0) switches it off.
+    if (get_tuning("lazy_structures", 1)) build_structures(w, nvar, std::min(nbatch, IBH_MAX_BATCH), w->napply >= 1, stream);
     ++w->napply;
     int kernel = pick_kernel(w, nvar, nbatch);
     // the column sweep addresses a wave's 16 field planes through one buffer descriptor (32-bit offsets)

@@ -210,6 +210,11 @@ public:
     void matvec_device(const double *dxx, int nvar, long ldx, double *dyy, long ldy, bool ignore_nan, void *stream) const {
         check(ibh_weighted_matvec_device(h_, dxx, nvar, ldx, dyy, ldy, ignore_nan ? 1 : 0, stream));
     }
+    /** Build now whatever apply structure (column sweep / bands) applies of up to nvar variables, nbatch batches per
+        launch, would build lazily on their second call, and size all per-apply scratch: afterwards the device applies
+        only enqueue work (ibh_weighted_prepare).  Once per matrix, e.g. right after matrix_d() in a coupler that
+        applies the matrix more than once per step, and before capturing applies into a hipGraph. */
+    void prepare(int nvar, int nbatch = 1) const { check(ibh_weighted_prepare(h_, nvar, nbatch)); }
     /** Device-resident variant: dA_b (nvar x lda) and dB_b (nvar x ldb) are HBM pointers; enqueues on stream. */
     void apply_device(const double *dA_b, int nvar, long lda, double *dB_b, long ldb, double fill,
                       bool force_conservation, void *stream) const {

@@ -266,6 +266,13 @@ class linear_Weighted:
         applies into a hipGraph: growing scratch allocates)."""
         check(lib().ibh_weighted_reserve(self._h, int(nvar)))
 
+    def prepare(self, nvar, nbatch=1):
+        """Make applies of up to nvar variables, up to nbatch batches per launch, pure enqueues: builds the
+        column-sweep / band structure those applies would otherwise build lazily on their second call and
+        sizes all scratch (ibh_weighted_prepare).  Call once per matrix before capturing applies into a
+        hipGraph or when the latency of the first applies matters."""
+        check(lib().ibh_weighted_prepare(self._h, int(nvar), int(nbatch)))
+
     def apply_transformed_device(self, dV, T, b, out=None, fill=float("nan"), stream=None):
         """The coupler's fused product  M * (V*T + b)  on HBM-resident fields (IceCoupler.cpp:203-252,
         :445): dV torch.float64 CUDA [nvar_in, ncol_d]; T [nvar_in, nvar_out] (the sparse variable

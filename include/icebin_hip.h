@@ -209,8 +209,13 @@ int ibh_weighted_get_csr(const ibh_weighted *w, int32_t *rowptr, int32_t *colind
  * dense index spaces; rows with wM == 0 receive `fill`; when the matrix is
  * not conservative and force_conservation != 0 each variable is rescaled by
  * (Mw . A) / (wM . B).  _host takes host pointers (copies over PCIe);
- * _device takes device pointers and only enqueues work on `stream` (no allocation, copy or
- * synchronisation once the handle's scratch is sized: ibh_weighted_reserve).  lda/ldb:
+ * _device takes device pointers and only enqueues work on `stream`: no allocation, copy or
+ * synchronisation once the handle has been prepared (ibh_weighted_prepare).  On a handle that was
+ * NOT prepared an apply may (a) grow scratch (allocates; an error inside a stream capture) and (b) on
+ * the SECOND apply of a large elevation-class matrix build the column-sweep / band structure the faster
+ * kernels read (allocates, synchronises `stream` a few times; skipped inside a capture; a build that
+ * fails leaves the matrix on its row-by-row kernel, the apply still succeeds) --
+ * ibh_set_tuning("lazy_structures", 0) switches (b) off for the process.  lda/ldb:
  * distance in doubles between consecutive variables (>= dense extents); any value
  * works, ldb a multiple of 64 (512-byte planes) is fastest for the I-row matrices.
  * The handle keeps small per-apply scratch buffers: use one stream at a time per handle. */
@@ -232,9 +237,15 @@ int ibh_weighted_apply_device(const ibh_weighted *w, const double *dA_b, int32_t
 int ibh_weighted_apply_many_device(const ibh_weighted *w, int32_t nbatch, const double *const *dA_b, int32_t nvar,
                                    int64_t lda, double *const *dB_b, int64_t ldb, double fill,
                                    int force_conservation, void *stream);
-/* Size the handle's per-apply scratch for applies of up to nvar variables (transposed inputs of the
- * I-row kernels, band partial sums, conservation factors, transform scratch).  Applies grow it on
- * demand, but growing allocates: inside a stream capture that is an error, so reserve first. */
+/* Make applies of up to nvar variables, up to nbatch field batches per ibh_weighted_apply_many_device
+ * call, pure enqueues: builds NOW (synchronously, on the default stream) whatever structure those applies
+ * would otherwise build lazily (column sweep / bands: see above) and sizes every per-apply scratch buffer
+ * (transposed inputs of the I-row kernels, partial sums of the sweep / band kernels for the batch depth,
+ * conservation factors, transform scratch).  Call it once after a matrix is built and before capturing
+ * applies into a hipGraph, or whenever the latency of the first applies matters.  Eager and captured
+ * applies of a prepared handle run the same kernels and are bitwise equal.
+ * ibh_weighted_reserve(w, nvar) only sizes scratch for single applies (nbatch = 1) and builds nothing. */
+int ibh_weighted_prepare(const ibh_weighted *w, int32_t nvar, int32_t nbatch);
 int ibh_weighted_reserve(const ibh_weighted *w, int32_t nvar);
 /* The coupler's fused product B = M * (A*T + b) (IceCoupler.cpp:203-252 construct_ice_ivalsI and
  * :445 gcm_ivalsX = M * (ice_ovalsI*T + b)): dA_b [nvar_in x ncol_d] field-major device pointer,
@@ -280,8 +291,9 @@ int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
  * general pipeline built it (ibh_set_tuning("assemble_fast", 0) forces the latter).  Results are bit-identical. */
 int ibh_weighted_built_fast(const ibh_weighted *w, int *out);
 int ibh_set_tuning(const char *key, int value);
-/* Measurement hooks (bench.py): HIP events owned by the library, and a one-shot request to attach a
- * pair of them to the NEXT rowblock SpMM launch of the calling thread (hipExtLaunchKernel: start = the
+/* DIAGNOSTIC measurement hooks (bench.py only; not for product code: ibh_set_launch_events is thread-local
+ * one-shot state that changes which launch API the calling thread's next apply uses): HIP events owned by
+ * the library, and a one-shot request to attach a pair of them to the NEXT SpMM launch of the calling thread (hipExtLaunchKernel: start = the
  * kernel begins, stop = it ends -- the kernel's own duration, as rocprofv3's kernel trace reports it,
  * without the host's submission latency in front).  ibh_event_elapsed_ms waits for `stop`. */
 int ibh_event_create(void **out);
@@ -294,8 +306,9 @@ int ibh_set_launch_events(void *start, void *stop);
  * fields below 2^hi_bits / 2^lo_bits.  *path_out: 0 already ordered, 1 pieces sorted in LDS,
  * 2 device-wide radix sort.  Used by tests/test_gpu_parity.py. */
 int ibh_selftest_sort(const uint64_t *keys, int64_t n, int lo_bits, int hi_bits, uint32_t *perm_out, int *path_out);
-/* Return the per-thread workspace and all cached device blocks to the driver (the library keeps
- * freed device memory for reuse: a coupler rebuilds the same matrices every step). */
+/* Return the build workspaces of ALL host threads (the caller's and the library's worker threads') and
+ * all cached device blocks to the driver (the library keeps freed device memory for reuse: a coupler
+ * rebuilds the same matrices every step).  Call it while no build is in flight. */
 int ibh_release_cached_memory(void);
 
 #ifdef __cplusplus

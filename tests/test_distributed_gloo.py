@@ -166,3 +166,34 @@ def test_field_shard_partition():
             assert parts[0][0] == 0 and parts[-1][1] == nf
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1 and sum(sizes) == nf
+
+
+@pytest.mark.parametrize("extra", [["--fields", "3"], ["--fields-total", "7"]])
+def test_bench_self_launches_its_ranks(extra):
+    """`python bench.py --gpus 2` with no torchrun around it starts its own ranks as a child process, relays rank 0's JSON
+    line and the exit code (the command used to die on an assert).  --dry-run plays the N > 1 choreography of
+    the bench -- rendezvous on 127.0.0.1, field sharding, grouped all-gathers through FieldShardedApply, the cross-rank
+    gather check, ranks_seen -- on CPU over gloo."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "5", "--warmup", "2",
+                        "--queue-depth", "2"] + extra, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                    # ONE JSON line, rank 0's
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["value"] is None
+    assert out["gather_check"] == {"pass": True, "ranks": 2}
+    assert sorted(s["rank"] for s in out["ranks_seen"]) == [0, 1]
+    assert out["fields_total"] == (6 if extra[0] == "--fields" else 7)
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -416,6 +416,113 @@ def test_config4_full_size_1km_properties_and_parity():
     assert np.all(np.abs(back - 1.0) < 1e-11)
 
 
+def test_config2_5km_avi_iva_one_to_three_fields():
+    """BASELINE config 2: 5 km Greenland <-> 2x2.5, AvI + IvA, ONE field (and 2, 3) on one GPU, against the oracle at full
+    size, for every kernel the dispatcher can pick there -- rowblock with the row split over the four waves (WK = 4 for one
+    field, 2 for two or three), shortrow with its 4-field groups -- through the host call, the device call and a batched
+    launch; NaN-carrying inputs (merge_topo.cpp:65 applies elevmaskI itself) and `fill` in rows with wM == 0 (identity
+    dimI: masked ice cells are empty rows of IvA)."""
+    import torch
+    g, em, mm, rg = setup("g5")
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    dimI, odimI = icebin_amd.SparseSet.identity(g["nI"]), orc.SparseSet(g["nI"], init=np.arange(g["nI"]))
+    cases = [("AvI", (None, None), (None, None)), ("IvA", (None, None), (None, None)),
+             ("AvI", (None, dimI), (None, odimI)), ("IvA", (dimI, None), (odimI, None))]
+    for name, dims, odims in cases:
+        w = rm.matrix_d(name, dims, scale=True, correctA=True)
+        o = rg.matrix_d(name, em, dims=odims, scale=True, correctA=True)
+        assert_same_weighted(w, o, "config 2 " + name)
+        ident = dims != (None, None)
+        for nvar in (1, 2, 3):
+            x = syn.fields(nvar, w.ncol_d, seed=40 + nvar)
+            if name == "AvI":
+                cols = np.flatnonzero(np.isfinite(em))[1000:1003] if ident else np.arange(1000, 1003)
+                x[0, cols] = np.nan                         # a few ice cells: the NaN stays in the rows that read them
+                if ident:
+                    x[nvar - 1, np.isnan(em)] = np.nan      # masked cells are empty columns: their NaN must not leak at all
+            else:
+                x[nvar - 1, 7] = np.nan
+            ref = o.apply(x, fill=-3.0, force_conservation=False)
+            if name == "AvI":
+                assert np.isnan(ref).sum() in range(1, 8 * nvar)
+            if name == "IvA" and ident:
+                assert np.all(ref[:, np.isnan(em)] == -3.0)
+            for kernel in ("auto", "rowblock", "shortrow"):
+                w.set_kernel(kernel)
+                y = w.apply(x, fill=-3.0, force_conservation=False)
+                assert rel_linf(y, ref) <= FIELD_RTOL, (name, nvar, kernel, ident)
+                used = w.last_kernel()
+                assert used == (kernel if kernel != "auto" else ("rowblock" if name == "AvI" else "shortrow")), (name, kernel, used)
+                dx = torch.from_numpy(x).cuda()
+                yd = w.apply_device(dx, fill=-3.0, force_conservation=False)
+                ym = w.apply_many_device([dx, dx, dx, dx, dx], fill=-3.0, force_conservation=False)
+                torch.cuda.synchronize()
+                assert rel_linf(yd.cpu().numpy(), ref) <= FIELD_RTOL, (name, nvar, kernel, "device")
+                for q in (0, 4):
+                    assert np.array_equal(ym[q].cpu().numpy().view(np.uint64), yd.cpu().numpy().view(np.uint64)), (name, nvar, kernel, q)
+            w.set_kernel("auto")
+            # the 1-D form of apply() (a single field as a vector)
+            y1 = w.apply(x[0], fill=-3.0, force_conservation=False)
+            assert y1.shape == (w.nrow_d,) and rel_linf(y1, ref[0]) <= FIELD_RTOL
+        if name == "AvI" and not ident:                     # conservation of the one-field regrid, compensated sums
+            x = syn.fields(1, w.ncol_d, seed=44)
+            y = w.apply(x)
+            assert _conservation(w, x[0], y[0]) < 1e-13
+
+
+def test_config4_1km_64_fields_benched_kernels_against_the_oracle():
+    """BASELINE config 4 at the field count and through the kernels the 1 km bench lines time, against the oracle's apply
+    (1.2e8..2.5e8 multiply-adds on the host): AvI on the column sweep in a batched launch (one entry per column: the
+    IDENT variant) and on rowblock; EvI on the column sweep (single and batched) and on rowblock; IvA on shortrow with
+    the transposed-input / 16-fields-per-thread plan of GB-sized results, with 512-byte planes and with the reference's
+    contiguous planes (odd leading dimension: the re-aligning variant)."""
+    import torch
+    g, em, mm, rg = setup("g1")
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    for name in ("AvI", "EvI"):
+        w, o = rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True)
+        assert_same_weighted(w, o, name + " g1")
+        x = syn.fields(64, w.ncol_d, seed=3)
+        x[7, ::100003] = np.nan
+        ref = o.apply(x, fill=-1.0, force_conservation=False)
+        dx = torch.from_numpy(x).cuda()
+        w.set_kernel("rowblock")
+        y = w.apply_device(dx, fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert w.last_kernel() == "rowblock" and rel_linf(y.cpu().numpy(), ref) <= FIELD_RTOL, name
+        w.set_kernel("auto")
+        w.prepare(64, 4)                                 # what bench.py's W.prepare does: the sweep structure, scratch for 4 deep
+        ys = w.apply_many_device([dx] * 4, fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert w.last_kernel() == "colsweep", name
+        for q in range(4):
+            assert rel_linf(ys[q].cpu().numpy(), ref) <= FIELD_RTOL, (name, q)
+        y1 = w.apply_device(dx, fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert w.last_kernel() == ("colsweep" if name == "EvI" else "rowblock")      # AvI: the sweep in batched launches only
+        assert rel_linf(y1.cpu().numpy(), ref) <= FIELD_RTOL, name
+        for k in (0, 33):
+            if not np.isnan(x[k]).any():
+                assert _conservation(w, x[k], y1[k].cpu().numpy()) < 1e-13
+        del dx, ys, y, y1
+    w, o = rm.matrix("IvA"), rg.matrix_d("IvA", em, scale=True, correctA=True)
+    assert_same_weighted(w, o, "IvA g1")
+    x = syn.fields(64, w.ncol_d, seed=4)
+    x[5, 17] = np.nan
+    ref = o.apply(x, fill=-1.0, force_conservation=False)
+    dx = torch.from_numpy(x).cuda()
+    y = w.apply_device(dx, fill=-1.0, force_conservation=False)                       # planes padded to 512 bytes
+    torch.cuda.synchronize()
+    assert w.last_kernel() == "shortrow" and rel_linf(y.cpu().numpy(), ref) <= FIELD_RTOL
+    yc = torch.empty((64, w.nrow_d), dtype=torch.float64, device="cuda")              # the reference's layout: ldb = nrow_d (odd)
+    assert w.nrow_d % 8 != 0
+    w.apply_device(dx, out=yc, fill=-1.0, force_conservation=False)
+    ym = w.apply_many_device([dx, dx], fill=-1.0, force_conservation=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(yc.cpu().numpy().view(np.uint64), y.cpu().numpy().view(np.uint64))
+    assert np.array_equal(ym[1].cpu().numpy().view(np.uint64), y.cpu().numpy().view(np.uint64))
+
+
 def test_config5_antarctica_1km_assembly_and_apply_properties():
     # BASELINE config 5 (the Antarctic sheet, 36 012 001 ice cells, 1/2 deg GCM): COO -> CSR assembly +
     # apply at full size.  Too large for the single-core oracle: checked through properties.
@@ -528,6 +635,25 @@ def test_config5_antarctica_colsweep_agrees_with_rowblock_at_64_fields():
     assert rel_linf(y_col, y_row) <= FIELD_RTOL
     live = w.wM != 0
     assert np.all(np.abs(y_col[5][live] - 1.0) < 1e-11)
+    # ... and against the ORACLE's apply (ColMajor Eigen order) fed the GPU-built matrix: a full oracle build of this sheet is
+    # out of reach on one core, its apply is not (16 fields x 3.3e7 entries).  16 fields = config 5's per-GPU share at 8 GPUs.
+    row, col, val = w.coo_dense()
+    o = orc.Weighted.from_coo(w.nrow_d, w.ncol_d, row, col, val, w.wM, w.Mw)
+    del row, col, val
+    x16 = x[:16].contiguous()
+    ref = o.apply(x16.cpu().numpy(), fill=-1.0, force_conservation=False)
+    for kernel in ("auto", "rowblock", "colsweep"):
+        w.set_kernel(kernel)
+        y = w.apply_device(x16, fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert rel_linf(y.cpu().numpy(), ref) <= FIELD_RTOL, kernel
+    w.set_kernel("auto")
+    ys = w.apply_many_device([x16] * 4, fill=-1.0, force_conservation=False)          # (batch, field) lanes of the sweep
+    torch.cuda.synchronize()
+    assert w.last_kernel() == "colsweep"
+    for q in (0, 3):
+        assert rel_linf(ys[q].cpu().numpy(), ref) <= FIELD_RTOL
+    assert rel_linf(y_col[:16], ref) <= FIELD_RTOL
 
 
 def test_config5_greenland_1km_half_degree_sheet():
@@ -629,9 +755,12 @@ def test_cython_module_icebin_on_gpu(tmp_path):
     # `import icebin` (the reference's module name, pylib/_icebin.pyx) over the C++ host mirror: the script of
     # tests/test_conserv/test_conserv.py -- GCMRegridder(fname), regrid_matrices(sheet, elevmaskI, correctA=...),
     # matrix(name), to_coo(), coo_multiply -- against the oracle
+    # (import-only: the extension is compiled by __graft_entry__.build() and travels to the GPU box with the snapshot --
+    # no compile inside a GPU test; a box without it skips rather than builds)
     import os, sys
-    from icebin_amd.cython.build_ext import build
-    build()
+    from icebin_amd.cython.build_ext import ext_path
+    if not os.path.exists(ext_path()):
+        pytest.skip("Cython module not prebuilt (run __graft_entry__.build())")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "icebin_amd", "cython"))
     import icebin
     g, em, mm, rg = setup("g20")
@@ -1423,6 +1552,76 @@ def test_colsweep_lazy_build_batched_and_shared_dims():
         assert rel_linf(y, o2.apply(x, fill=-1.0, force_conservation=False)) <= FIELD_RTOL
     finally:
         set_tuning("sweep_min_work", 64 << 20)
+
+
+def test_prepare_makes_applies_pure_enqueues():
+    # ibh_weighted_prepare(w, nvar, nbatch): the structure an apply would build lazily on its second call exists before the
+    # FIRST one, scratch is sized for the batch depth, so a batched apply can be captured right away and equals the eager
+    # one bitwise; with lazy_structures = 0 an unprepared matrix never builds inside an apply
+    import torch
+    from icebin_amd.linear import set_tuning
+    g, em, mm, rg = setup("g5")
+    set_tuning("sweep_min_work", 1)
+    try:
+        rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+        o = rg.matrix_d("EvI", em, scale=True, correctA=True)
+        xs = [torch.from_numpy(syn.fields(64, o.ncol, seed=80 + q)).cuda() for q in range(6)]
+        xs[3][5, ::11] = float("nan")
+        # unprepared, lazy builds off: every apply stays on the row-by-row kernel
+        set_tuning("lazy_structures", 0)
+        w0 = rm.matrix("EvI")
+        for _ in range(3):
+            w0.apply_device(xs[0], fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert w0.last_kernel() == "rowblock"
+        set_tuning("lazy_structures", 1)
+        # prepared: colsweep from the first apply on, single and batched, eager == captured
+        w = rm.matrix("EvI")
+        w.prepare(64, len(xs))
+        y = w.apply_device(xs[0], fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert w.last_kernel() == "colsweep"
+        assert rel_linf(y.cpu().numpy(), o.apply(xs[0].cpu().numpy(), fill=-1.0, force_conservation=False)) <= FIELD_RTOL
+        outs = [torch.zeros((64, w.nrow_d), dtype=torch.float64, device="cuda") for _ in xs]
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):                       # no warm-up apply_many before the capture: prepare() sized the scratch
+            w.apply_many_device(xs, outs, fill=-1.0, force_conservation=False)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert w.last_kernel() == "colsweep"
+        eager = w.apply_many_device(xs, fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        for a, b, x in zip(outs, eager, xs):
+            assert np.array_equal(a.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
+            assert rel_linf(a.cpu().numpy(), o.apply(x.cpu().numpy(), fill=-1.0, force_conservation=False)) <= FIELD_RTOL
+        # an I-row matrix: the transposed-input scratch of a deep launch is sized too
+        wi, oi = rm.matrix("IvE"), rg.matrix_d("IvE", em, scale=True, correctA=True)
+        xe = [torch.from_numpy(syn.fields(16, wi.ncol_d, seed=90 + q)).cuda() for q in range(8)]
+        wi.prepare(16, len(xe))
+        oute = [torch.zeros((16, wi.nrow_d), dtype=torch.float64, device="cuda") for _ in xe]
+        gr2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr2):
+            wi.apply_many_device(xe, oute, fill=-1.0, force_conservation=False)
+        gr2.replay()
+        torch.cuda.synchronize()
+        for a, x in zip(oute, xe):
+            assert rel_linf(a.cpu().numpy(), oi.apply(x.cpu().numpy(), fill=-1.0, force_conservation=False)) <= FIELD_RTOL
+        # a structure the sweep declines (long columns: 64 items touch more rows than its table holds) fails neither
+        # prepare() nor the applies, which stay on the row kernel
+        wl = rm.matrix("IvA")
+        wl.set_kernel("colsweep")
+        wl.prepare(64, 2)
+        wl.apply_device(torch.from_numpy(syn.fields(64, wl.ncol_d)).cuda(), force_conservation=False)
+        torch.cuda.synchronize()
+        assert wl.last_kernel() in ("rowblock", "shortrow")
+        from icebin_amd import _capi
+        _capi.check(_capi.lib().ibh_release_cached_memory())       # all threads' workspaces; handles stay valid
+        y2 = w.apply_device(xs[0], fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert np.array_equal(y2.cpu().numpy().view(np.uint64), y.cpu().numpy().view(np.uint64))
+    finally:
+        set_tuning("sweep_min_work", 64 << 20)
+        set_tuning("lazy_structures", 1)
 
 
 @pytest.mark.parametrize("nvar,nbatch", [(16, 4), (16, 5), (8, 9), (12, 8), (24, 3), (32, 2), (5, 33)])
