@@ -24,6 +24,7 @@ void release_workspace();
 // synchronisation points of every matrix build).  bytes <= 256.
 void readback_sync(void *dst, const void *dsrc, size_t bytes, hipStream_t stream);
 
+
 // out[i] = sum_{j<i} in[j] (u32, wraps at 2^32); in == out allowed.  If total != nullptr the
 // grand total is written there (device pointer).  All work is enqueued on `stream`.
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total, hipStream_t stream);

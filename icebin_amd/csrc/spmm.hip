@@ -51,7 +51,8 @@ int get_tuning(const char *key, int dflt) {
 void set_tuning(const char *key, int value) {
     Tuning &t = tuning();
     std::lock_guard<std::mutex> lk(t.mu);
-    t.map[key] = value;
+    if (value == INT32_MIN) t.map.erase(key);       // back to the built-in default
+    else t.map[key] = value;
 }
 
 // ---- launch timing (ibh_set_launch_events) ---------------------------------------------------------
@@ -166,7 +167,7 @@ struct BatchPtrs {
 // fill); dual_combine_kernel adds, for every row, its own lower sum and the upper sum of the band
 // below it.  The band arrays are a filtered copy of the CSR (assemble.hip build_bands).
 template <int FPW, int WK, int UNROLL, int NW, bool DUAL = false>
-__global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
+__global__ __launch_bounds__(NW * 64, (FPW == 1 && !DUAL) ? 8 : 1) void spmm_rowblock_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
     const BatchPtrs bp, int nbatch, int qi, long ldx, int ncol, long ldy, int nrow, int nf, int nfc,
     int xcd_mode, const double *__restrict__ wM, double fill,
@@ -243,19 +244,61 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
             const bool more = nxt < end;
             if (more) stage_load(nxt, min(RB_SEG, end - nxt));
             // Full batches: every lane issues UNROLL*FPW loads before the first FMA, no predication.
+            // The weights are read from LDS when the gathered values are consumed, not before the loads are issued: a slot in
+            // flight then holds only its x (2 VGPRs per field), so that 14-16 loads per lane fit the 64 registers at which all
+            // workgroups of a single 64-field apply are resident at once (8 waves per SIMD).
             const int nfull = n - n % BATCH;
             int kb = 0;
+            if constexpr (!DUAL) {
+                for (; kb < nfull; kb += BATCH) {
+                    double x[FPW][UNROLL];
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
+                        const int off = s_col[kb + wk * 64 + lane + u * STEP] << 3;
+#pragma unroll
+                        for (int j = 0; j < FPW; ++j) x[j][u] = xload(rs[j], off);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
+                        const double v = s_val[kb + wk * 64 + lane + u * STEP];
+#pragma unroll
+                        for (int j = 0; j < FPW; ++j) acc[j] = fma(v, x[j][u], acc[j]);
+                    }
+                }
+                // Tail batch: lanes past the end re-read the last entry and are masked at the FMA (never
+                // multiplied by 0: 0*NaN must not leak into a row).
+                if (kb + wk * 64 < n) {
+                    double x[FPW][UNROLL];
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
+                        const int k = kb + wk * 64 + lane + u * STEP;
+                        const int off = s_col[k < n ? k : n - 1] << 3;
+#pragma unroll
+                        for (int j = 0; j < FPW; ++j) x[j][u] = xload(rs[j], off);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
+                        const int k = kb + wk * 64 + lane + u * STEP;
+                        const bool ok = k < n;
+                        const double v = s_val[ok ? k : n - 1];
+#pragma unroll
+                        for (int j = 0; j < FPW; ++j) acc[j] = ok ? fma(v, x[j][u], acc[j]) : acc[j];
+                    }
+                }
+            } else {
             for (; kb < nfull; kb += BATCH) {
                 int off[UNROLL];
-                double v[UNROLL], v2[DUAL ? UNROLL : 1];
-                bool h0[DUAL ? UNROLL : 1], h1[DUAL ? UNROLL : 1];
+                double v[UNROLL], v2[UNROLL];
+                bool h0[UNROLL], h1[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     const int k = kb + wk * 64 + lane + u * STEP;
                     const int c = s_col[k];
-                    off[u] = DUAL ? (c & 0x3fffffff) << 3 : c << 3;
+                    off[u] = (c & 0x3fffffff) << 3;
                     v[u] = s_val[k];
-                    if (DUAL) { v2[u] = s_val2[k]; h0[u] = (c >> 30) & 1; h1[u] = c < 0; }
+                    v2[u] = s_val2[k]; h0[u] = (c >> 30) & 1; h1[u] = c < 0;
                 }
                 double x[FPW][UNROLL];
 #pragma unroll
@@ -265,28 +308,24 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 #pragma unroll
                 for (int j = 0; j < FPW; ++j)
 #pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) {
-                        if (DUAL) {                          // a missing partner is never multiplied (0*NaN)
-                            acc[j] = h0[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
-                            acc2[j] = h1[u] ? fma(v2[u], x[j][u], acc2[j]) : acc2[j];
-                        } else acc[j] = fma(v[u], x[j][u], acc[j]);
+                    for (int u = 0; u < UNROLL; ++u) {     // a missing partner is never multiplied (0*NaN)
+                        acc[j] = h0[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
+                        acc2[j] = h1[u] ? fma(v2[u], x[j][u], acc2[j]) : acc2[j];
                     }
             }
-            // Tail batch: lanes past the end re-read the last entry and are masked at the FMA (never
-            // multiplied by 0: 0*NaN must not leak into a row).
             if (kb + wk * 64 < n) {
                 int off[UNROLL];
-                double v[UNROLL], v2[DUAL ? UNROLL : 1];
-                bool ok[UNROLL], ok2[DUAL ? UNROLL : 1];
+                double v[UNROLL], v2[UNROLL];
+                bool ok[UNROLL], ok2[UNROLL];
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     const int k = kb + wk * 64 + lane + u * STEP;
                     ok[u] = k < n;
                     const int kk = ok[u] ? k : n - 1;
                     const int c = s_col[kk];
-                    off[u] = DUAL ? (c & 0x3fffffff) << 3 : c << 3;
+                    off[u] = (c & 0x3fffffff) << 3;
                     v[u] = s_val[kk];
-                    if (DUAL) { v2[u] = s_val2[kk]; ok2[u] = ok[u] && c < 0; ok[u] = ok[u] && ((c >> 30) & 1); }
+                    v2[u] = s_val2[kk]; ok2[u] = ok[u] && c < 0; ok[u] = ok[u] && ((c >> 30) & 1);
                 }
                 double x[FPW][UNROLL];
 #pragma unroll
@@ -298,8 +337,9 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
 #pragma unroll
                     for (int u = 0; u < UNROLL; ++u) {
                         acc[j] = ok[u] ? fma(v[u], x[j][u], acc[j]) : acc[j];
-                        if (DUAL) acc2[j] = ok2[u] ? fma(v2[u], x[j][u], acc2[j]) : acc2[j];
+                        acc2[j] = ok2[u] ? fma(v2[u], x[j][u], acc2[j]) : acc2[j];
                     }
+            }
             }
             if (more) {
                 __syncthreads();                      // every wave is done reading this segment
@@ -342,6 +382,78 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowblock_kernel(
         }
     }
 }
+
+// ---- rowone: ONE apply per launch, one field per wave -- the lean form of rowblock for the reference's own call shape ----------
+// (Weighted_Eigen::apply, one call per matrix: merge_topo.cpp:65, icebin22m.cpp:153).  Same staging, same per-lane order,
+// same wave_sum as rowblock with FPW = WK = 1 -> the same bits; what is gone is everything a single launch does not need: the
+// batch loop and its pointer table in the kernel arguments, the cross-segment prefetch registers, the full / tail batch split.
+// A row of <= U*64 entries (every row of the 5 km matrices) is ONE staged segment and ONE batch of U gathers per lane; the
+// weights are read from LDS when the gathers land, so a slot in flight holds two registers and U = 14..16 fits the 64
+// registers at which all workgroups of a 64-field apply are resident at once.  Measured against rowblock on the headline
+// shape (scratch/chain_bench.hip has the decomposition: empty launch 4.1 us, matrix-free stream 7.9, this chain 9.8).
+template <int NW, int U>
+__global__ __launch_bounds__(NW * 64, 8) void spmm_rowone_kernel(
+    const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
+    const double *__restrict__ X, double *__restrict__ Y, long ldx, int ncol, long ldy, int nrow, int nf, int nfc,
+    int xcd_mode, const double *__restrict__ wM, double fill)
+{
+    constexpr int T = NW * 64, SEG = U * 64, ST = (SEG + T - 1) / T;
+    __shared__ int s_col[SEG];
+    __shared__ double s_val[SEG];
+    int r, fc;
+    if (!block_to_task(blockIdx.x, nrow, nfc, xcd_mode, r, fc)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fw = fc * NW + wave;
+    const int f = fw < nf ? fw : nf - 1;            // clamp: tail fields read valid memory, never stored
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)f * ldx), 0, ncol * 8, 0x00020000);
+    double acc = 0.0;
+    for (int seg = beg; seg < end; seg += SEG) {
+        const int n = min(SEG, end - seg);
+        int cc[ST];
+        double vv[ST];
+#pragma unroll
+        for (int i = 0; i < ST; ++i) {              // all loads first (clamped, unconditional)
+            const int k = min((int)threadIdx.x + i * T, n - 1);
+            cc[i] = colind[seg + k];
+            vv[i] = vals[seg + k];
+        }
+        if (seg != beg) __syncthreads();            // every wave is done with the previous segment
+#pragma unroll
+        for (int i = 0; i < ST; ++i) {
+            const int k = threadIdx.x + i * T;
+            if (k < n) { s_col[k] = cc[i]; s_val[k] = vv[i]; }
+        }
+        __syncthreads();
+        double x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = lane + 64 * u;
+            x[u] = xload(rs, s_col[k < n ? k : n - 1] << 3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {               // lanes past the end are masked, never multiplied by 0 (0*NaN)
+            const int k = lane + 64 * u;
+            const bool ok = k < n;
+            const double v = s_val[ok ? k : n - 1];
+            acc = ok ? fma(v, x[u], acc) : acc;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && fw < nf) Y[(long)fw * ldy + r] = wM[r] == 0.0 ? fill : acc;      // mask_result, IceCoupler.cpp:186-201
+}
+// Tried on top of this and dropped (measured on MI355X, 5 km AvI, 64 fields): RUN HINTS -- the first-seen numbering makes a
+// row's columns a contiguous run behind ~18 scattered ones, so the gathers of the run were issued with arithmetic addresses
+// together with the staging loads -- bought nothing (10.44 against 10.48 us): the FMA chain starts with chunk 0, whose gather
+// still waits for the staged columns and then queues behind every other load of the CU.  In-kernel stamps
+// (scratch/chain_bench.hip, CHAIN_TIMELINE) show why: the X phase is throughput-bound -- a wave needs a median 3.5 us just to
+// ISSUE its 14 gathers because the memory pipeline is full -- so what a single launch can still gain is its 1.2 us prologue.
+// A staging-free variant ("rowdirect": a wave owns (row, 4 fields) and reads colind / vals itself, all chunks of the row in
+// flight at once, row pointers in the kernel arguments, no LDS, no barrier) was SLOWER at every size (5 km 12.6 against
+// 11.7 us, 1 km 235 against 186): 1.5 x the vector-memory instructions per gathered element, and row pointers in the kernarg
+// segment are a memory round trip like any other (12.64 against 12.60 us with / without).
 
 constexpr int SR_THREADS = 256;
 
@@ -621,6 +733,10 @@ static void launch_rowblock(const ibh_weighted *w, const BatchPtrs &bp, int nbat
         // (a row is one partly filled batch when the unroll overshoots it: 5 km EvI, 2.1 passes of 64 per row, 26.2 / 18.4 us
         // with four loads in flight, 23.6 / 16.6 with two)
         unroll = mean > 6.0 ? 8 : mean > 3.0 ? 4 : mean > 1.5 ? 2 : 1;
+        // one field per wave: the weights are read when the gathers land, a slot in flight holds two registers -> a row of up to
+        // 896 entries in ONE batch of 14 gathers per lane (measured, 5 km AvI, 32 applies per launch: 7.31 -> 7.03 us per apply;
+        // 12 or 16 are slower: 8.5 / 7.4)
+        if (FPW == 1 && WK == 1 && NW == 8 && mean > 8.0 && mean <= 14.0) unroll = 14;
     }
     // batches per workgroup: the staged row segment and the prologue are shared by qi batches
     int qi = 1;
@@ -641,8 +757,27 @@ static void launch_rowblock(const ibh_weighted *w, const BatchPtrs &bp, int nbat
     if (unroll == 1) IBH_RB(1);
     else if (unroll == 2) IBH_RB(2);
     else if (unroll == 8) IBH_RB(8);
+    else if (unroll > 8 && FPW == 1 && WK == 1) {      // one batch covers a whole row of <= 768 / 896 / 1024 entries
+        constexpr bool one = FPW == 1 && WK == 1;
+        if (unroll <= 12) IBH_RB((one ? 12 : 8)); else if (unroll <= 14) IBH_RB((one ? 14 : 8)); else IBH_RB((one ? 16 : 8));
+    }
     else IBH_RB(4);
 #undef IBH_RB
+    IBH_HIP(hipGetLastError());
+}
+
+template <int NW, int U>
+static void launch_rowone(const ibh_weighted *w, const double *X, double *Y, int nvar, long lda, long ldb, double fill, hipStream_t stream)
+{
+    const int nfc = ceil_div(nvar, NW);
+    int xcd_mode;
+    const long nb = rowblock_grid(w->nrow, nfc, xcd_mode);
+    IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
+    IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
+    hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+    hipExtLaunchKernelGGL((spmm_rowone_kernel<NW, U>), dim3((unsigned)nb), dim3(NW * 64), 0, stream, ev0, ev1, 0, w->rowptr.p, w->colind.p,
+                          w->val.p, X, Y, lda, w->ncol, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill);
     IBH_HIP(hipGetLastError());
 }
 
@@ -947,6 +1082,19 @@ static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &
         }
         // deep batched launches: 8 waves (8 fields) per workgroup halve the workgroup count per batch
         // (measured at the 5 km headline shape, depth 16: 7.36 against 7.51 us per apply)
+        // one apply per launch, >= 8 fields, rows of a few hundred entries: the lean kernel (same bits as rowblock with wk == 1)
+        const double mean_len = w->nrow ? (double)w->nnz / (double)w->nrow : 0.0;
+        const int rowone = get_tuning("rowone", nbatch == 1 && wk == 1 && nvar >= 32 && mean_len >= 192.0 && mean_len <= 1024.0 ? 1 : 0);
+        if (rowone && nbatch == 1 && wk == 1) {
+            int u = get_tuning("rowone_unroll", mean_len > 768.0 ? 16 : 14), nw = get_tuning("rowone_waves", 8);
+            const double *X1 = bp.x[0];
+            double *Y1 = bp.y[0];
+#define IBH_R1(N, UU) launch_rowone<N, UU>(w, X1, Y1, nvar, (long)lda, (long)ldb, fill, stream)
+            if (nw == 4) { if (u <= 8) IBH_R1(4, 8); else if (u <= 12) IBH_R1(4, 12); else if (u <= 14) IBH_R1(4, 14); else IBH_R1(4, 16); }
+            else { if (u <= 8) IBH_R1(8, 8); else if (u <= 12) IBH_R1(8, 12); else if (u <= 14) IBH_R1(8, 14); else IBH_R1(8, 16); }
+#undef IBH_R1
+            return;
+        }
         const int nw = get_tuning("rowblock_waves", nbatch >= 8 && fpw == 1 && wk == 1 ? 8 : 4);
 #define IBH_L(F, K, N) launch_rowblock<F, K, N>(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream)
         if (nw == 8 && wk == 1) {
