@@ -1572,6 +1572,136 @@ bool build_sweep_from_csr(const ibh_weighted *cw, hipStream_t st) {
     return true;
 }
 
+// ---- row-group structure (spmm.hip rowgroup) of an E-row matrix, from its CSR -------------------------------------------
+// A group = the rows whose keys decode to the same GCM cell (its elevation classes), in ascending row order: slot s of
+// group g.  The group's entries are ordered by column and paired per column into items (an ice cell lies between two classes
+// of a GCM cell: one item with both weights).  Exact copies of M's values.  Declined (false, nothing kept) when a group has
+// more than IBH_GSLOTS rows or a column more than two entries in one group.  Host synchronisations for sizes; runs once per
+// matrix (ibh_weighted_prepare, or lazily from a later apply).
+constexpr uint32_t GRP_HAS0 = 1u << 16, GRP_HAS1 = 1u << 17;
+static const int64_t *dims_device_table(ibh_sparse_set *set, int n, hipStream_t st);
+__global__ void k_rg_rowkeys(RgView rg, const int64_t *__restrict__ row_s, int nrow, uint64_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrow) return;
+    long a, hc;
+    e_decode(rg, row_s[r], a, hc);
+    keys[r] = (uint64_t)a; idx[r] = (uint32_t)r;
+}
+__global__ void k_rg_heads(const uint64_t *__restrict__ keys, long n, uint32_t *__restrict__ h) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) h[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// sorted rows -> (group, slot): gstart[g] = position of the group's first row
+__global__ void k_rg_gstart(const uint32_t *__restrict__ h, const uint32_t *__restrict__ hscan, int nrow, int32_t *__restrict__ gstart) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrow && h[i]) gstart[hscan[i]] = i;
+}
+__global__ void k_rg_slots(const uint32_t *__restrict__ h, const uint32_t *__restrict__ hscan, const uint32_t *__restrict__ srow, int nrow,
+                           int ngrp, const int32_t *__restrict__ gstart, int32_t *__restrict__ grp_of_row, int32_t *__restrict__ slot_of_row,
+                           int32_t *__restrict__ slotrow, int32_t *__restrict__ grp_ns, uint32_t *__restrict__ d_maxns) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrow) return;
+    const int g = (int)(hscan[i] + h[i]) - 1, s = i - gstart[g];
+    const int r = (int)srow[i];
+    grp_of_row[r] = g; slot_of_row[r] = s;
+    if (s < IBH_GSLOTS) slotrow[g * IBH_GSLOTS + s] = r;
+    if (i + 1 == nrow || h[i + 1]) { grp_ns[g] = s + 1; atomicMax(d_maxns, (uint32_t)(s + 1)); }
+}
+__global__ void k_rg_entrykeys(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind, int nrow, const int32_t *__restrict__ grp_of_row,
+                               uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, int32_t *__restrict__ erow) {
+    const int r = blockIdx.x;                       // one workgroup per row
+    const uint64_t g = (uint64_t)(uint32_t)grp_of_row[r] << 32;
+    for (int k = rowptr[r] + threadIdx.x; k < rowptr[r + 1]; k += blockDim.x) { keys[k] = g | (uint32_t)colind[k]; idx[k] = (uint32_t)k; erow[k] = r; }
+}
+// item heads of the (group, column)-sorted entries: a run of equal keys is one item (two entries at most: else *d_bad)
+__global__ void k_rg_itemheads(const uint64_t *__restrict__ keys, long n, uint32_t *__restrict__ h, uint32_t *__restrict__ d_bad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool head = i == 0 || keys[i] != keys[i - 1];
+    h[i] = head ? 1u : 0u;
+    if (i >= 2 && keys[i] == keys[i - 1] && keys[i] == keys[i - 2]) *d_bad = 1u;
+}
+__global__ void k_rg_items(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ h,
+                           const uint32_t *__restrict__ hscan, long n, const int32_t *__restrict__ erow, const int32_t *__restrict__ slot_of_row,
+                           const double *__restrict__ val, int32_t *__restrict__ it_col, uint32_t *__restrict__ meta, double *__restrict__ v0,
+                           double *__restrict__ v1, int32_t *__restrict__ it_grp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !h[i]) return;
+    const long it = (long)hscan[i];
+    const uint32_t s0 = (uint32_t)slot_of_row[erow[idx[i]]];
+    uint32_t m = s0 | GRP_HAS0;
+    double w1 = 0.0;
+    if (i + 1 < n && keys[i + 1] == keys[i]) {
+        m |= ((uint32_t)slot_of_row[erow[idx[i + 1]]] << 8) | GRP_HAS1;
+        w1 = val[idx[i + 1]];
+    }
+    it_col[it] = (int32_t)(uint32_t)keys[i]; meta[it] = m; v0[it] = val[idx[i]]; v1[it] = w1;
+    it_grp[it] = (int32_t)(keys[i] >> 32);
+}
+bool build_groups_from_csr(const ibh_weighted *cw, hipStream_t st) {
+    ibh_weighted *w = const_cast<ibh_weighted *>(cw);
+    if (w->grp_n > 0 || !w->band_eligible || w->nnz == 0 || w->nrow == 0 || w->nnz >= (1ll << 31) - 64) return false;
+    if (!w->dims[0]) return false;
+    Arena &A = arena();
+    A.reset();
+    const int T = 256, nrow = w->nrow;
+    const long nnz = w->nnz;
+    const int64_t *row_s = dims_device_table(w->dims[0], nrow, st);       // the row keys (a caller-supplied set may live on the host only)
+    RgView rg{};
+    rg.sA = w->band_sA; rg.sHC = w->band_sHC;
+    uint32_t *d_cnt = A.get<uint32_t>(8);
+    IBH_HIP(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * 8, st));
+    // rows by GCM cell (stable: ascending row inside a group)
+    uint64_t *rk = A.get<uint64_t>((size_t)nrow), *rk2 = A.get<uint64_t>((size_t)nrow);
+    uint32_t *ri = A.get<uint32_t>((size_t)nrow), *ri2 = A.get<uint32_t>((size_t)nrow);
+    hipLaunchKernelGGL(k_rg_rowkeys, dim3(ceil_div(nrow, T)), dim3(T), 0, st, rg, row_s, nrow, rk, ri);
+    KeyField rf{0, 32};
+    if (radix_sort_pairs(rk, rk2, ri, ri2, (size_t)nrow, &rf, 1, st)) { std::swap(rk, rk2); std::swap(ri, ri2); }
+    uint32_t *rh = A.get<uint32_t>((size_t)nrow), *rhs = A.get<uint32_t>((size_t)nrow);
+    hipLaunchKernelGGL(k_rg_heads, dim3(ceil_div(nrow, T)), dim3(T), 0, st, rk, (long)nrow, rh);
+    exclusive_scan_u32(rh, rhs, (size_t)nrow, d_cnt + 0, st);
+    uint32_t h[8];
+    readback_sync(h, d_cnt, sizeof(h), st);
+    const int ngrp = (int)h[0];
+    if (ngrp <= 0) return false;
+    int32_t *gstart = A.get<int32_t>((size_t)ngrp);
+    int32_t *grp_of_row = A.get<int32_t>((size_t)nrow), *slot_of_row = A.get<int32_t>((size_t)nrow);
+    DevBuf<int32_t> slotrow((size_t)ngrp * IBH_GSLOTS), grp_ns((size_t)ngrp), grp_ptr((size_t)ngrp + 1);
+    IBH_HIP(hipMemsetAsync(slotrow.p, 0, sizeof(int32_t) * (size_t)ngrp * IBH_GSLOTS, st));
+    hipLaunchKernelGGL(k_rg_gstart, dim3(ceil_div(nrow, T)), dim3(T), 0, st, rh, rhs, nrow, gstart);
+    hipLaunchKernelGGL(k_rg_slots, dim3(ceil_div(nrow, T)), dim3(T), 0, st, rh, rhs, ri, nrow, ngrp, gstart, grp_of_row, slot_of_row, slotrow.p,
+                       grp_ns.p, d_cnt + 1);
+    // entries by (group, column): stable, so the two entries of a column keep their row (= slot) order
+    uint64_t *keys = A.get<uint64_t>((size_t)nnz), *keys2 = A.get<uint64_t>((size_t)nnz);
+    uint32_t *idx = A.get<uint32_t>((size_t)nnz), *idx2 = A.get<uint32_t>((size_t)nnz);
+    int32_t *erow = A.get<int32_t>((size_t)nnz);
+    hipLaunchKernelGGL(k_rg_entrykeys, dim3(nrow), dim3(T), 0, st, w->rowptr.p, w->colind.p, nrow, grp_of_row, keys, idx, erow);
+    KeyField ef[2] = {{0, bits_for((uint64_t)w->ncol)}, {32, bits_for((uint64_t)ngrp)}};
+    if (radix_sort_pairs(keys, keys2, idx, idx2, (size_t)nnz, ef, 2, st)) { std::swap(keys, keys2); std::swap(idx, idx2); }
+    uint32_t *ih = A.get<uint32_t>((size_t)nnz), *ihs = A.get<uint32_t>((size_t)nnz);
+    hipLaunchKernelGGL(k_rg_itemheads, dim3(ceil_div(nnz, T)), dim3(T), 0, st, keys, nnz, ih, d_cnt + 3);
+    exclusive_scan_u32(ih, ihs, (size_t)nnz, d_cnt + 2, st);
+    readback_sync(h, d_cnt, sizeof(h), st);
+    const int maxns = (int)h[1];
+    const long nitems = (long)h[2];
+    if (getenv("IBH_SWEEP_DEBUG")) fprintf(stderr, "groups: nrow %d ngrp %d maxns %d nitems %ld bad %u\n", nrow, ngrp, maxns, nitems, h[3]);
+    if (maxns > IBH_GSLOTS || h[3] != 0 || nitems <= 0) return false;
+    DevBuf<int32_t> it_col((size_t)nitems);
+    DevBuf<uint32_t> it_meta((size_t)nitems);
+    DevBuf<double> it_v0((size_t)nitems), it_v1((size_t)nitems);
+    int32_t *it_grp = A.get<int32_t>((size_t)nitems);
+    hipLaunchKernelGGL(k_rg_items, dim3(ceil_div(nnz, T)), dim3(T), 0, st, keys, idx, ih, ihs, nnz, erow, slot_of_row, w->val.p, it_col.p, it_meta.p,
+                       it_v0.p, it_v1.p, it_grp);
+    rowptr_from_rows(it_grp, nitems, ngrp, grp_ptr.p, st);
+    IBH_HIP(hipGetLastError());
+    IBH_HIP(hipStreamSynchronize(st));              // (the arena is reused by the next build)
+    w->grp_ptr = std::move(grp_ptr); w->grp_ns = std::move(grp_ns); w->grp_slotrow = std::move(slotrow);
+    w->grp_col = std::move(it_col); w->grp_meta = std::move(it_meta); w->grp_v0 = std::move(it_v0); w->grp_v1 = std::move(it_v1);
+    w->grp_nslot = maxns; w->grp_nitems = (int32_t)nitems;
+    w->grp_n = ngrp;
+    return true;
+}
+
 #include "fastasm.inl"
 
 // ---- RegridMatrices_Dynamic::matrix_d ----------------------------------------------------------

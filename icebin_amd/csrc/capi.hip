@@ -623,13 +623,14 @@ int ibh_weighted_set_kernel(ibh_weighted *w, const char *name) {
         else if (!strcmp(name, "shortrow")) w->kernel_override = 2;
         else if (!strcmp(name, "colsweep")) w->kernel_override = 4;       // falls back to rowblock when the matrix has no column-sweep structure
         else if (!strcmp(name, "rowdual")) w->kernel_override = 3;        // falls back to rowblock when the matrix has no bands
+        else if (!strcmp(name, "rowgroup")) w->kernel_override = 5;       // falls back to rowblock when the matrix has no row groups
         else fail(IBH_EINVAL, "unknown kernel '%s'", name);
     });
 }
 int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen) {
     return guarded([&] {
         IBH_CHECK(w && buf && buflen > 0, "bad argument");
-        snprintf(buf, (size_t)buflen, "%s", w->last_kernel == 1 ? "rowblock" : w->last_kernel == 2 ? "shortrow" : w->last_kernel == 3 ? "rowdual" : w->last_kernel == 4 ? "colsweep" : "none");
+        snprintf(buf, (size_t)buflen, "%s", w->last_kernel == 1 ? "rowblock" : w->last_kernel == 2 ? "shortrow" : w->last_kernel == 3 ? "rowdual" : w->last_kernel == 4 ? "colsweep" : w->last_kernel == 5 ? "rowgroup" : "none");
     });
 }
 int ibh_weighted_built_fast(const ibh_weighted *w, int *out) {

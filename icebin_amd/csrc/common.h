@@ -103,6 +103,7 @@ struct DevBuf {
 };
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+constexpr int IBH_GSLOTS = 32;      // most rows (elevation classes of one GCM cell) in a row group (spmm.hip rowgroup)
 inline int bits_for(uint64_t n) {   // bits needed to represent values in [0, n)
     int b = 0;
     while (b < 64 && (n > (1ull << b))) ++b;
@@ -228,6 +229,15 @@ struct ibh_weighted {
     mutable ibh::DevBuf<double> sweep_v0, sweep_v1;
     mutable ibh::DevBuf<int32_t> sweep_comb_ptr, sweep_comb_p;     // [nrow+1], [nprow]: the partial-sum rows that make up row r, in task order
     mutable ibh::DevBuf<double> sweep_part;              // per-apply partial sums [nbatch][nprow][fields padded to 64]
+    // rowgroup (EvI, EvX; spmm.hip): the rows of one GCM cell (its elevation classes) form a GROUP; the group's entries are
+    // listed once per distinct column, ascending, as ITEMS {col, meta = slot0 | slot1 << 8 | has-bits, v0, v1} -- the column
+    // set of a group is the AvI row of its GCM cell, so X is gathered once per (GCM cell, ice cell) instead of once per class;
+    // slot s of group g is row grp_slotrow[g * IBH_GSLOTS + s].  Built from the CSR (assemble.hip build_groups_from_csr).
+    mutable int grp_tried = 0;
+    mutable int32_t grp_n = 0, grp_nslot = 0, grp_nitems = 0;          // groups (0: not built), most rows in a group, items
+    mutable ibh::DevBuf<int32_t> grp_ptr, grp_ns, grp_slotrow, grp_col; // [grp_n+1] items of a group; [grp_n] rows of a group; [grp_n*IBH_GSLOTS]; [nitems]
+    mutable ibh::DevBuf<uint32_t> grp_meta;
+    mutable ibh::DevBuf<double> grp_v0, grp_v1;
     mutable bool have_rowsum1 = false;
     mutable ibh::DevBuf<int32_t> rowperm;                // rows by descending length (batched rowblock launches)
     mutable bool have_rowperm = false;
@@ -255,6 +265,8 @@ void weighted_prepare(const ibh_weighted *w, int nvar, int nbatch);
 void build_bands_from_csr(const ibh_weighted *w, hipStream_t st);
 // assemble.hip: the column-sweep structure of an E-row matrix from its CSR (sweep_kernel.inl); false: not representable
 bool build_sweep_from_csr(const ibh_weighted *w, hipStream_t st);
+// assemble.hip: the row-group structure of an E-row matrix from its CSR (spmm.hip rowgroup); false: not representable
+bool build_groups_from_csr(const ibh_weighted *w, hipStream_t st);
 void matvec_legacy_launch(const ibh_weighted *w, const double *dx, int nvar, int64_t ldx, double *dy, int64_t ldy,
                           int ignore_nan, hipStream_t stream);
 void spmm_transformed_launch(const ibh_weighted *w, const double *dA, int nvar_in, int64_t lda, const double *T,

@@ -455,6 +455,113 @@ __global__ __launch_bounds__(NW * 64, 8) void spmm_rowone_kernel(
 // 11.7 us, 1 km 235 against 186): 1.5 x the vector-memory instructions per gathered element, and row pointers in the kernarg
 // segment are a memory round trip like any other (12.64 against 12.60 us with / without).
 
+// ---- rowgroup: E-row matrices (EvI, EvX), one workgroup per (GCM cell, chunk of fields) ------------------------------------------
+// An ice cell between two elevation classes is a column of TWO rows of M -- (GCM cell a, class k) and (a, k+1) -- so row by row
+// every X element is gathered twice, and each of the ~10 class rows of a GCM cell touches ~15 % of the cell's footprint: most
+// of every line it fetches belongs to other classes (5 km EvI: ~100 MB effective for a 42 MB apply).  Here the rows of one GCM
+// cell form a GROUP whose entries are listed once per distinct column, ascending, as items {col, slot0, slot1, v0, v1}
+// (assemble.hip build_groups_from_csr): the column set of a group is the AvI row of its GCM cell -- a contiguous run behind a
+// few cells shared with earlier GCM cells -- so the gathers are those of the A-row kernel: every X element once, whole lines.
+// Lane = column, wave = field (as rowone): lane L multiplies its column's value into the sums of the column's two classes,
+// kept in a per-wave LDS table acc[slot][lane] (bank = lane: conflict-free whatever the slots); at the end one wave_sum per
+// class.  A group holds ALL entries of its rows, so the result is final: no partial sums, no second kernel.  Fixed order
+// throughout (per lane: items lane, lane + 64, ... ascending; then the wave sum) -> bitwise reproducible; entries are
+// predicated by existence, never multiplied by a padded zero (0*NaN).
+struct GroupView {
+    const int *ptr, *ns, *slotrow, *col;
+    const unsigned *meta;
+    const double *v0, *v1;
+    int ngrp, nslot;
+};
+constexpr unsigned RG_HAS0 = 1u << 16, RG_HAS1 = 1u << 17;
+template <int NW, int U>
+__global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView gv, const BatchPtrs bp, long ldx, int ncol, long ldy, int nf,
+                                                               int nfc, int xcd_mode, const double *__restrict__ wM, double fill)
+{
+    constexpr int T = NW * 64, SEG = U * 64, ST = SEG / T;
+    static_assert(SEG % T == 0, "segment is a multiple of the workgroup");
+    extern __shared__ double rg_lds[];
+    double *s_v0 = rg_lds, *s_v1 = rg_lds + SEG;
+    int *s_col = reinterpret_cast<int *>(rg_lds + 2 * SEG);
+    unsigned *s_meta = reinterpret_cast<unsigned *>(s_col + SEG);
+    double *s_tab = rg_lds + 3 * SEG;                       // [NW][nslot][64]
+    int g, fc;
+    if (!block_to_task(blockIdx.x, gv.ngrp, nfc, xcd_mode, g, fc)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fw = fc * NW + wave;
+    const int f = fw < nf ? fw : nf - 1;            // clamp: tail fields read valid memory, never stored
+    const double *__restrict__ X = bp.x[blockIdx.y];
+    double *__restrict__ Y = bp.y[blockIdx.y];
+    const int beg = gv.ptr[g], end = gv.ptr[g + 1], ns = gv.ns[g];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)f * ldx), 0, ncol * 8, 0x00020000);
+    double *tab = s_tab + (long)wave * gv.nslot * 64 + lane;
+    for (int s = 0; s < ns; ++s) tab[s * 64] = 0.0;
+    for (int seg = beg; seg < end; seg += SEG) {
+        const int n = min(SEG, end - seg);
+        int cc[ST];
+        unsigned mm[ST];
+        double a0[ST], a1[ST];
+#pragma unroll
+        for (int i = 0; i < ST; ++i) {              // all loads first (clamped, unconditional)
+            const int k = seg + min((int)threadIdx.x + i * T, n - 1);
+            cc[i] = gv.col[k]; mm[i] = gv.meta[k]; a0[i] = gv.v0[k]; a1[i] = gv.v1[k];
+        }
+        if (seg != beg) __syncthreads();            // every wave is done with the previous segment
+#pragma unroll
+        for (int i = 0; i < ST; ++i) {
+            const int k = threadIdx.x + i * T;
+            if (k < n) { s_col[k] = cc[i]; s_meta[k] = mm[i]; s_v0[k] = a0[i]; s_v1[k] = a1[i]; }
+        }
+        __syncthreads();
+        double x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = lane + 64 * u;
+            x[u] = xload(rs, s_col[k < n ? k : n - 1] << 3);
+        }
+        // the items' slots and weights come out of LDS while the gathers fly ...
+        unsigned m[U];
+        double w0[U], w1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = lane + 64 * u;
+            const int kk = k < n ? k : n - 1;
+            m[u] = k < n ? s_meta[kk] : 0u;             // lanes past the end: no has-bit
+            w0[u] = s_v0[kk]; w1[u] = s_v1[kk];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ... and the products go to the LDS pipe as ds_add_f64 WITHOUT return, back to back: the sums of a lane are added in
+        // program order (deterministic) and the wave never waits for a read-modify-write round trip
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (m[u] & RG_HAS0) __hip_atomic_fetch_add(tab + (m[u] & 0xffu) * 64, w0[u] * x[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (m[u] & RG_HAS1) __hip_atomic_fetch_add(tab + ((m[u] >> 8) & 0xffu) * 64, w1[u] * x[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    // class sums: lane L adds one half (32 lanes' worth) of slot L % 32, starting at a lane-dependent offset (bank = 2 x index:
+    // two lanes per bank instead of all 64), then the two halves meet; fixed order per lane -> reproducible
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const int sl = lane & 31, half = lane >> 5;
+    double tot = 0.0;
+    if (sl < ns) {
+        const double *row = s_tab + ((long)wave * gv.nslot + sl) * 64 + half * 32;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) tot += row[(j + lane) & 31];
+    }
+    tot += __shfl_xor(tot, 32, 64);
+    if (half == 0 && sl < ns && fw < nf) {
+        const int r = gv.slotrow[g * IBH_GSLOTS + sl];
+        Y[(long)fw * ldy + r] = wM[r] == 0.0 ? fill : tot;      // mask_result, IceCoupler.cpp:186-201
+    }
+}
+
+// Measured on MI355X (us per apply, one launch / 16 per launch; rowblock in brackets): 5 km EvI 64 fields 17.1 / 14.8 (23.0 / 16.5),
+// 16 fields 7.5 / 3.9 (8.8 / 4.9); 1 km EvI 64 fields 223 / 204 (colsweep 231 / 203).  The read-modify-write of the class table
+// was the first bottleneck (32.5 us at 5 km with plain LDS loads and stores: a dependent round trip per item); a variant without
+// staging (every wave reads its items from global memory, LDS = tables only, no barrier) lost at every size (21.4 / 16.3 us at
+// 5 km, 322 at 1 km): as for the A-row kernel, extra vector-memory instructions cost more than barriers and LDS footprint.
+
 constexpr int SR_THREADS = 256;
 
 // XT[c*ldt + f] = X[f*ldx + c]; pad columns f in [nf, ldt) are zeroed (read for tail fields, never stored)
@@ -781,6 +888,32 @@ static void launch_rowone(const ibh_weighted *w, const double *X, double *Y, int
     IBH_HIP(hipGetLastError());
 }
 
+template <int NW, int U>
+static void launch_rowgroup(const ibh_weighted *w, const BatchPtrs &bp, int nbatch, int nvar, long lda, long ldb, double fill, hipStream_t stream)
+{
+    const int nfc = ceil_div(nvar, NW);
+    int xcd_mode;
+    const long nb = rowblock_grid(w->grp_n, nfc, xcd_mode);
+    IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
+    IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
+    GroupView gv{w->grp_ptr.p, w->grp_ns.p, w->grp_slotrow.p, w->grp_col.p, w->grp_meta.p, w->grp_v0.p, w->grp_v1.p, w->grp_n, w->grp_nslot};
+    const size_t lds = (size_t)(3 * U * 64 + NW * w->grp_nslot * 64) * sizeof(double);
+    hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+    if (lds > 64 * 1024) {                               // beyond the default dynamic-LDS limit: raise it once per device
+        static std::mutex mu;
+        static bool raised[64] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        if (!raised[w->device & 63]) {
+            IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_rowgroup_kernel<NW, U>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised[w->device & 63] = true;
+        }
+    }
+    hipExtLaunchKernelGGL((spmm_rowgroup_kernel<NW, U>), dim3((unsigned)nb, (unsigned)nbatch), dim3(NW * 64), lds, stream, ev0, ev1, 0, gv, bp,
+                          lda, w->ncol, ldb, nvar, nfc, xcd_mode, w->wM.p, fill);
+    IBH_HIP(hipGetLastError());
+}
+
 // B[f, r] = lower-class sum of band r + upper-class sum of the band below it (rb1[r], -1: none)
 __global__ void dual_combine_kernel(const double *__restrict__ P0, const double *__restrict__ P1, long ldp, long pstride,
                                     const int *__restrict__ rb1, const double *__restrict__ wM, double fill,
@@ -916,7 +1049,7 @@ static void launch_sweep(const ibh_weighted *w, const BatchPtrs &bp, int nbatch,
     IBH_HIP(hipGetLastError());
 }
 
-// which kernel serves (w, nvar): 1 rowblock, 2 shortrow, 3 rowdual, 4 colsweep
+// which kernel serves (w, nvar): 1 rowblock, 2 shortrow, 3 rowdual, 4 colsweep, 5 rowgroup
 static int pick_kernel(const ibh_weighted *w, int nvar, int nbatch = 1) {
     int kernel = w->kernel_override;
     if (kernel == 4 && w->sweep_ntask == 0) kernel = 0;       // no column-sweep structure: the automatic choice
@@ -932,6 +1065,9 @@ static int pick_kernel(const ibh_weighted *w, int nvar, int nbatch = 1) {
     // per apply 32 deep, but 193 against 183 us one launch per apply -- two kernels and a prologue per task)
     if (kernel == 1 && w->kernel_override == 0 && w->sweep_ntask > 0 && sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
         (w->band_eligible || nbatch >= get_tuning("sweep_min_batch", 4))) kernel = 4;
+    // the row groups of an E-row matrix, once they exist (ibh_weighted_prepare, or a later apply): every X element gathered once
+    if (kernel == 1 && w->kernel_override == 0 && w->grp_n > 0 && nvar >= 4 && get_tuning("rowgroup_auto", 1)) kernel = 5;
+    if (kernel == 5 && w->grp_n == 0) kernel = 1;             // no row groups were built for this matrix
     if (kernel == 1 && w->kernel_override == 0 && w->band_n > 0 && nvar >= 4 && get_tuning("rowdual_auto", 1)) kernel = 3;
     if (kernel == 3 && w->band_n == 0) kernel = 1;            // no bands were built for this matrix
     return kernel;
@@ -978,6 +1114,26 @@ static bool wants_bands(const ibh_weighted *w, int nvar, bool seen) {
     return w->band_eligible && !w->band_tried && w->band_n == 0 && w->sweep_ntask == 0 && seen && w->kernel_override == 0 && nvar >= 4 &&
            (double)w->nnz * nvar >= (double)get_tuning("rowdual_min_work", 128 << 20) && get_tuning("rowdual_auto", 1);
 }
+// row groups: the E-row matrices the column sweep does not take -- too little work per launch for it (5 km: the sweep is
+// latency-bound there), too few fields, or a structure it declined; at 1 km the two tie at 64 fields and the sweep wins with
+// fewer (batches share its lanes).  The structure costs about as much as the matrix build itself: built by ibh_weighted_prepare.
+static bool sweep_sized(const ibh_weighted *w, int nvar, int nbatch) {
+    return sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
+           (double)w->nnz * sweep_lanes(nvar, nbatch) >= (double)get_tuning("sweep_min_work", 64 << 20);
+}
+static bool wants_groups(const ibh_weighted *w, int nvar, int nbatch, long seen) {
+    if (!w->band_eligible || w->grp_tried || w->grp_n > 0) return false;
+    if (w->kernel_override == 5) return true;
+    const bool sweep_serves = w->sweep_ntask > 0 || (!w->sweep_tried && sweep_sized(w, nvar, nbatch));
+    // (an apply builds them only on request -- ibh_set_tuning("rowgroup_after", n): from the n-th apply on -- because the switch of
+    // kernels changes the rounding of later results against earlier ones; ibh_weighted_prepare is the deterministic way)
+    return w->kernel_override == 0 && !sweep_serves && seen >= get_tuning("rowgroup_after", 1 << 30) && nvar >= 4 && get_tuning("rowgroup_auto", 1);
+}
+static void drop_groups(const ibh_weighted *w) {
+    w->grp_n = 0;
+    w->grp_ptr.release(); w->grp_ns.release(); w->grp_slotrow.release(); w->grp_col.release(); w->grp_meta.release();
+    w->grp_v0.release(); w->grp_v1.release();
+}
 static void drop_sweep(const ibh_weighted *w) {
     w->sweep_ntask = 0;
     w->sweep_task_p0.release(); w->sweep_task_ns.release(); w->sweep_col.release(); w->sweep_meta.release();
@@ -989,13 +1145,20 @@ static void drop_bands(const ibh_weighted *w) {
 }
 // A structure that cannot be built (out of memory, not representable) is no reason to fail an apply the row-by-row kernel
 // serves: the failure is swallowed, the structure marked as tried, the matrix keeps its kernel.  Never inside a capture.
-static void build_structures(const ibh_weighted *w, int nvar, int nbatch, bool seen, hipStream_t stream) {
-    const bool sweep = wants_sweep(w, nvar, nbatch, seen);
-    if (!sweep && !wants_bands(w, nvar, seen)) return;
+static void build_structures(const ibh_weighted *w, int nvar, int nbatch, bool seen, hipStream_t stream, long nseen = 1l << 30) {
+    const bool groups = wants_groups(w, nvar, nbatch, seen ? nseen : 0);
+    const bool sweep = !groups && w->grp_n == 0 && wants_sweep(w, nvar, nbatch, seen);
+    if (!groups && !sweep && (w->grp_n > 0 || !wants_bands(w, nvar, seen))) return;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
     if (cs != hipStreamCaptureStatusNone) return;
-    if (sweep) {
+    if (groups) {
+        w->grp_tried = 1;
+        try { if (build_groups_from_csr(w, stream)) return; }
+        catch (const Error &) { (void)hipGetLastError(); drop_groups(w); }
+        if (!wants_sweep(w, nvar, nbatch, seen) && !wants_bands(w, nvar, seen)) return;     // declined: the older structures may still apply
+    }
+    if (sweep || (groups && wants_sweep(w, nvar, nbatch, seen))) {
         w->sweep_tried = 1;
         try { build_sweep_from_csr(w, stream); }
         catch (const Error &) { (void)hipGetLastError(); drop_sweep(w); }
@@ -1060,7 +1223,14 @@ static void launch_one(const ibh_weighted *w, int kernel, const BatchPtrs &bp, i
 static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &bp, int nbatch, int nvar, int64_t lda,
                             int64_t ldb, double fill, hipStream_t stream)
 {
-    if (kernel == 4) {
+    if (kernel == 5) {
+        // 8 waves (fields) share a staged segment from 32 fields (5 km, 64 fields: 17.1 against 19.3 us with 4)
+        const int u = get_tuning("rowgroup_unroll", 8), nw = get_tuning("rowgroup_waves", nvar >= 32 ? 8 : 4);
+#define IBH_RG(N, UU) launch_rowgroup<N, UU>(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream)
+        if (nw == 8) { if (u <= 8) IBH_RG(8, 8); else IBH_RG(8, 16); }
+        else { if (u <= 4) IBH_RG(4, 4); else if (u <= 8) IBH_RG(4, 8); else IBH_RG(4, 16); }
+#undef IBH_RG
+    } else if (kernel == 4) {
         launch_sweep(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream);
     } else if (kernel == 3) {
         const long pairs = (long)w->nrow * nvar;
@@ -1177,7 +1347,7 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
     // ... or, with >= 32 fields, the column-sweep structure (sweep_kernel.inl): every X element read once, in whole lines.
     // This is the one place where an apply synchronises and allocates: ibh_weighted_prepare() does it up front,
     // ibh_set_tuning("lazy_structures", 0) switches it off.
-    if (get_tuning("lazy_structures", 1)) build_structures(w, nvar, std::min(nbatch, IBH_MAX_BATCH), w->napply >= 1, stream);
+    if (get_tuning("lazy_structures", 1)) build_structures(w, nvar, std::min(nbatch, IBH_MAX_BATCH), w->napply >= 1, stream, (long)w->napply);
     ++w->napply;
     int kernel = pick_kernel(w, nvar, nbatch);
     // the column sweep addresses a wave's 16 field planes through one buffer descriptor (32-bit offsets)

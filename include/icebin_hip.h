@@ -285,7 +285,7 @@ typedef struct ibh_weighted_device_view {
 int ibh_weighted_device_view_get(const ibh_weighted *w, ibh_weighted_device_view *out);
 
 /* Tuning / introspection (not part of the reference interface). */
-int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow", "rowdual", "colsweep" */
+int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow", "rowdual", "colsweep", "rowgroup" */
 int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
 /* 1 when the matrix was assembled by the plan-based fast path for sorted exchange grids (fastasm.inl), 0 when the
  * general pipeline built it (ibh_set_tuning("assemble_fast", 0) forces the latter).  Results are bit-identical. */

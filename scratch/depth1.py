@@ -34,12 +34,13 @@ for spec in args:
     cfg, name, nf = parts[0], parts[1], int(parts[2])
     tune = dict(kv.split("=") for kv in parts[3].split(",") if kv) if len(parts) > 3 else {}
     tune_all = dict(tune)
-    tune = {k: v for k, v in tune.items() if k not in ("nbuf", "raw")}
+    tune = {k: v for k, v in tune.items() if k not in ("nbuf", "raw", "kernel")}
     for k in KEYS - set(tune):
         icebin_amd.set_tuning(k, -2 ** 31)          # back to the built-in default
     for k, v in tune.items():
         icebin_amd.set_tuning(k, int(v)); KEYS.add(k)
     W = matrix(cfg, name)
+    W.set_kernel(tune_all.get("kernel", "auto"))
     nrow, ncol, nnz = W.nrow_d, W.ncol_d, W.nnz
     B = 12 * nnz + 4 * (nrow + 1) + 8 * nf * (ncol + nrow)
     ldy = (nrow + 63) // 64 * 64 if nrow >= 4096 else nrow

@@ -1499,6 +1499,88 @@ def test_colsweep_on_grid_variants(variant):
     assert w.last_kernel() in ("rowblock", "shortrow")
 
 
+@pytest.mark.parametrize("variant", ["sorted", "shuffled", "elev_class", "x_fastest", "g20"])
+def test_rowgroup_on_grid_variants(variant):
+    """The row-group apply of the E-row matrices (spmm.hip rowgroup: the elevation classes of one GCM cell form a group whose
+    columns are gathered once) against the oracle: 1..130 fields, NaN-carrying fields, fill, both interpolation styles, both
+    ice index orders, shuffled exchange cells (general assembly path), a coarse grid (few cells per class), batched launches
+    bitwise equal to separate applies, inside a hipGraph, and a shared dimE in a scrambled order (the rows of a group are
+    not consecutive)."""
+    import torch
+    kw = dict(sorted={}, shuffled=dict(order="shuffled"), elev_class={}, x_fastest=dict(x_fastest=True), g20={})[variant]
+    g = syn.make_grids("g20" if variant == "g20" else "g5", **kw)
+    if variant == "elev_class":
+        g["interp_style"] = 1
+    em = syn.dome_elevmask(g)
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    for name in ("EvI", "EvX"):
+        w, o = rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True)
+        w.set_kernel("rowgroup")
+        for nvar in (64, 40, 130, 7, 1):
+            x = syn.fields(nvar, w.ncol_d, seed=7 + nvar)
+            x[nvar // 2, ::7] = np.nan              # NaN in a field must stay in the rows that use those cells
+            y = w.apply(x, fill=-1.0, force_conservation=False)
+            assert w.last_kernel() == "rowgroup", (name, nvar)
+            assert rel_linf(y, o.apply(x, fill=-1.0, force_conservation=False)) <= FIELD_RTOL, (name, nvar)
+        if name == "EvI":
+            xs = [torch.from_numpy(syn.fields(16, w.ncol_d, seed=400 + q)).cuda() for q in range(5)]
+            xs[2][3, ::5] = float("nan")
+            sep = [w.apply_device(x, fill=-1.0, force_conservation=False).clone() for x in xs]
+            outs = [torch.zeros_like(sep[0]) for _ in xs]
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                w.apply_many_device(xs, outs, fill=-1.0, force_conservation=False)
+            gr.replay()
+            torch.cuda.synchronize()
+            assert w.last_kernel() == "rowgroup"
+            for a, b, x in zip(outs, sep, xs):
+                assert np.array_equal(a.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
+                assert rel_linf(a.cpu().numpy(), o.apply(x.cpu().numpy(), fill=-1.0, force_conservation=False)) <= FIELD_RTOL
+    # a shared dimE in a scrambled order, holding keys this mask never touches (rows without entries: 0, or fill when wM == 0)
+    o = rg.matrix_d("EvI", em, scale=True, correctA=True)
+    nE = g["nA"] * len(g["hcdefs"])
+    extra = np.setdiff1d(np.arange(nE), o.dims[0])[:5]
+    perm = np.random.default_rng(5).permutation(np.concatenate([o.dims[0], extra]))
+    dimE, odimE = icebin_amd.SparseSet(nE, perm), orc.SparseSet(nE, init=perm)
+    w2 = rm.matrix_d("EvI", (dimE, None), scale=True, correctA=True)
+    o2 = rg.matrix_d("EvI", em, (odimE, None), scale=True, correctA=True)
+    assert_same_weighted(w2, o2, "EvI scrambled dimE")
+    w2.set_kernel("rowgroup")
+    x = syn.fields(24, w2.ncol_d)
+    y = w2.apply(x, fill=-1.0, force_conservation=False)
+    assert w2.last_kernel() == "rowgroup"
+    assert rel_linf(y, o2.apply(x, fill=-1.0, force_conservation=False)) <= FIELD_RTOL
+    # automatic choice: a matrix below the column sweep's size gets its row groups from ibh_weighted_prepare -- or, on request
+    # (rowgroup_after), lazily from the n-th apply on; without either every apply runs row by row
+    if variant == "sorted":
+        x = syn.fields(16, o.ncol, seed=9)
+        ref = o.apply(x, fill=-1.0, force_conservation=False)
+        for after, expect in ((None, ["rowblock"] * 5), (3, ["rowblock"] * 3 + ["rowgroup"] * 2)):
+            if after is not None:
+                icebin_amd.set_tuning("rowgroup_after", after)
+            try:
+                w4 = rm.matrix("EvI")
+                kernels = []
+                for _ in range(5):
+                    y = w4.apply(x, fill=-1.0, force_conservation=False)
+                    kernels.append(w4.last_kernel())
+                    assert rel_linf(y, ref) <= FIELD_RTOL
+                assert kernels == expect, kernels
+            finally:
+                icebin_amd.set_tuning("rowgroup_after", -2 ** 31)
+        w5 = rm.matrix("EvI")
+        w5.prepare(16, 4)
+        assert rel_linf(w5.apply(x, fill=-1.0, force_conservation=False), ref) <= FIELD_RTOL and w5.last_kernel() == "rowgroup"
+        y1 = w5.apply(x[:1], fill=-1.0, force_conservation=False)            # fewer than 4 fields: the row kernel splits the row over the waves
+        assert w5.last_kernel() == "rowblock" and rel_linf(y1, ref[:1]) <= FIELD_RTOL
+    # matrices without elevation-class rows have no groups: the request falls back
+    w3 = rm.matrix("AvI")
+    w3.set_kernel("rowgroup")
+    w3.apply(syn.fields(8, w3.ncol_d), force_conservation=False)
+    assert w3.last_kernel() == "rowblock"
+
+
 def test_colsweep_lazy_build_batched_and_shared_dims():
     # with >= 32 fields an E-row matrix that is applied again gets the column-sweep structure from its CSR; batched launches
     # are bitwise separate applies (also inside a hipGraph once the structure exists); a shared dimE in a permuted order
