@@ -497,23 +497,35 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)f * ldx), 0, ncol * 8, 0x00020000);
     double *tab = s_tab + (long)wave * gv.nslot * 64 + lane;
     for (int s = 0; s < ns; ++s) tab[s * 64] = 0.0;
-    for (int seg = beg; seg < end; seg += SEG) {
-        const int n = min(SEG, end - seg);
-        int cc[ST];
-        unsigned mm[ST];
-        double a0[ST], a1[ST];
+    // The group is walked in segments of SEG items staged in LDS; the loads of segment s+1 are issued before segment s is
+    // processed (they fly while X streams) and written to LDS after it.
+    int cc[ST];
+    unsigned mm[ST];
+    double a0[ST], a1[ST];
+    auto stage_load = [&](int seg, int n) {         // all loads first (clamped, unconditional)
 #pragma unroll
-        for (int i = 0; i < ST; ++i) {              // all loads first (clamped, unconditional)
+        for (int i = 0; i < ST; ++i) {
             const int k = seg + min((int)threadIdx.x + i * T, n - 1);
             cc[i] = gv.col[k]; mm[i] = gv.meta[k]; a0[i] = gv.v0[k]; a1[i] = gv.v1[k];
         }
-        if (seg != beg) __syncthreads();            // every wave is done with the previous segment
+    };
+    auto stage_store = [&](int n) {
 #pragma unroll
         for (int i = 0; i < ST; ++i) {
             const int k = threadIdx.x + i * T;
             if (k < n) { s_col[k] = cc[i]; s_meta[k] = mm[i]; s_v0[k] = a0[i]; s_v1[k] = a1[i]; }
         }
+    };
+    if (beg < end) {
+        stage_load(beg, min(SEG, end - beg));
+        stage_store(min(SEG, end - beg));
         __syncthreads();
+    }
+    for (int seg = beg; seg < end; seg += SEG) {
+        const int n = min(SEG, end - seg);
+        const int nxt = seg + SEG;
+        const bool more = nxt < end;
+        if (more) stage_load(nxt, min(SEG, end - nxt));
         double x[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -537,6 +549,11 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView 
         for (int u = 0; u < U; ++u) {
             if (m[u] & RG_HAS0) __hip_atomic_fetch_add(tab + (m[u] & 0xffu) * 64, w0[u] * x[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (m[u] & RG_HAS1) __hip_atomic_fetch_add(tab + ((m[u] >> 8) & 0xffu) * 64, w1[u] * x[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (more) {
+            __syncthreads();                        // every wave is done reading this segment
+            stage_store(min(SEG, end - nxt));
+            __syncthreads();
         }
     }
     // class sums: lane L adds one half (32 lanes' worth) of slot L % 32, starting at a lane-dependent offset (bank = 2 x index:
@@ -1060,13 +1077,18 @@ static int pick_kernel(const ibh_weighted *w, int nvar, int nbatch = 1) {
         const bool few_rows = w->nrow <= get_tuning("rowblock_max_short_rows", 16384);
         kernel = (mean >= 64.0 || (few_rows && mean >= (double)get_tuning("rowblock_min_mean_nnz", 6))) ? 1 : 2;
     }
-    // the column sweep, once its structure exists: always for E-row matrices (every X element read once instead of twice);
-    // for the other long-row matrices (AvI, AvX) in batched launches only (measured at 1 km, 64 fields: 167 against 173 us
-    // per apply 32 deep, but 193 against 183 us one launch per apply -- two kernels and a prologue per task)
-    if (kernel == 1 && w->kernel_override == 0 && w->sweep_ntask > 0 && sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
-        (w->band_eligible || nbatch >= get_tuning("sweep_min_batch", 4))) kernel = 4;
-    // the row groups of an E-row matrix, once they exist (ibh_weighted_prepare, or a later apply): every X element gathered once
-    if (kernel == 1 && w->kernel_override == 0 && w->grp_n > 0 && nvar >= 4 && get_tuning("rowgroup_auto", 1)) kernel = 5;
+    // E-row matrices (EvI, EvX), once the structure exists: the row groups (every X element gathered once per GCM cell; measured
+    // against the sweep at 1 km, 64 fields: 221 against 247 us one launch per apply, 199 against 203-223 batched) -- except
+    // batched launches of FEWER than 32 fields, where the batches share the lanes of the column sweep (1 km, 16 fields, 16 per
+    // launch: 51 against 63 us per apply).  The other long-row matrices (AvI, AvX) take the sweep in batched launches only
+    // (1 km, 64 fields: 167 against 173 us per apply 32 deep, but 193 against 183 us one launch per apply).
+    if (kernel == 1 && w->kernel_override == 0) {
+        const bool sweep_ok = w->sweep_ntask > 0 && sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
+                              (w->band_eligible || nbatch >= get_tuning("sweep_min_batch", 4));
+        const bool grp_ok = w->grp_n > 0 && nvar >= 4 && get_tuning("rowgroup_auto", 1);
+        if (grp_ok && (nvar >= 32 || !sweep_ok)) kernel = 5;
+        else if (sweep_ok) kernel = 4;
+    }
     if (kernel == 5 && w->grp_n == 0) kernel = 1;             // no row groups were built for this matrix
     if (kernel == 1 && w->kernel_override == 0 && w->band_n > 0 && nvar >= 4 && get_tuning("rowdual_auto", 1)) kernel = 3;
     if (kernel == 3 && w->band_n == 0) kernel = 1;            // no bands were built for this matrix
@@ -1106,7 +1128,8 @@ static bool wants_sweep(const ibh_weighted *w, int nvar, int nbatch, bool seen) 
     if (w->sweep_tried || w->sweep_ntask > 0) return false;
     if (w->kernel_override == 4) return true;
     const bool long_rows = w->nrow > 0 && (double)w->nnz / (double)w->nrow >= 64.0 && w->nnz <= 2 * (int64_t)w->ncol;      // AvI, AvX
-    return (w->band_eligible || (long_rows && nbatch >= get_tuning("sweep_min_batch", 4))) && w->kernel_override == 0 && seen &&
+    const bool e_rows = w->band_eligible && (nvar < 32 || (w->grp_tried && w->grp_n == 0) || !get_tuning("rowgroup_auto", 1));
+    return (e_rows || (long_rows && nbatch >= get_tuning("sweep_min_batch", 4))) && w->kernel_override == 0 && seen &&
            sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
            (double)w->nnz * sweep_lanes(nvar, nbatch) >= (double)get_tuning("sweep_min_work", 64 << 20);
 }
@@ -1114,20 +1137,21 @@ static bool wants_bands(const ibh_weighted *w, int nvar, bool seen) {
     return w->band_eligible && !w->band_tried && w->band_n == 0 && w->sweep_ntask == 0 && seen && w->kernel_override == 0 && nvar >= 4 &&
            (double)w->nnz * nvar >= (double)get_tuning("rowdual_min_work", 128 << 20) && get_tuning("rowdual_auto", 1);
 }
-// row groups: the E-row matrices the column sweep does not take -- too little work per launch for it (5 km: the sweep is
-// latency-bound there), too few fields, or a structure it declined; at 1 km the two tie at 64 fields and the sweep wins with
-// fewer (batches share its lanes).  The structure costs about as much as the matrix build itself: built by ibh_weighted_prepare.
+// Row groups (rowgroup kernel) of an E-row matrix: bandwidth-sized matrices applied to >= 32 fields get them like the sweep
+// always got its structure -- on the SECOND apply, or at once in ibh_weighted_prepare; with fewer fields such a matrix takes the
+// sweep (batches share its lanes).  Small matrices (5 km: the sweep is latency-bound there) get them from ibh_weighted_prepare
+// only: the structure costs about as much as the matrix build itself, and an apply that switched kernels on its own would change
+// the rounding of later results against earlier ones (ibh_set_tuning("rowgroup_after", n) asks for exactly that, from the
+// n-th apply on).
 static bool sweep_sized(const ibh_weighted *w, int nvar, int nbatch) {
-    return sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
-           (double)w->nnz * sweep_lanes(nvar, nbatch) >= (double)get_tuning("sweep_min_work", 64 << 20);
+    return (double)w->nnz * std::max(sweep_lanes(nvar, nbatch), std::min(nvar, 64)) >= (double)get_tuning("sweep_min_work", 64 << 20);
 }
 static bool wants_groups(const ibh_weighted *w, int nvar, int nbatch, long seen) {
     if (!w->band_eligible || w->grp_tried || w->grp_n > 0) return false;
     if (w->kernel_override == 5) return true;
-    const bool sweep_serves = w->sweep_ntask > 0 || (!w->sweep_tried && sweep_sized(w, nvar, nbatch));
-    // (an apply builds them only on request -- ibh_set_tuning("rowgroup_after", n): from the n-th apply on -- because the switch of
-    // kernels changes the rounding of later results against earlier ones; ibh_weighted_prepare is the deterministic way)
-    return w->kernel_override == 0 && !sweep_serves && seen >= get_tuning("rowgroup_after", 1 << 30) && nvar >= 4 && get_tuning("rowgroup_auto", 1);
+    if (w->kernel_override != 0 || nvar < 4 || !get_tuning("rowgroup_auto", 1)) return false;
+    if (sweep_sized(w, nvar, nbatch)) return nvar >= 32 && seen >= 1;
+    return seen >= get_tuning("rowgroup_after", 1 << 30);
 }
 static void drop_groups(const ibh_weighted *w) {
     w->grp_n = 0;
@@ -1146,24 +1170,22 @@ static void drop_bands(const ibh_weighted *w) {
 // A structure that cannot be built (out of memory, not representable) is no reason to fail an apply the row-by-row kernel
 // serves: the failure is swallowed, the structure marked as tried, the matrix keeps its kernel.  Never inside a capture.
 static void build_structures(const ibh_weighted *w, int nvar, int nbatch, bool seen, hipStream_t stream, long nseen = 1l << 30) {
-    const bool groups = wants_groups(w, nvar, nbatch, seen ? nseen : 0);
-    const bool sweep = !groups && w->grp_n == 0 && wants_sweep(w, nvar, nbatch, seen);
-    if (!groups && !sweep && (w->grp_n > 0 || !wants_bands(w, nvar, seen))) return;
+    const long ns = seen ? nseen : 0;
+    if (!wants_groups(w, nvar, nbatch, ns) && !wants_sweep(w, nvar, nbatch, seen) && !wants_bands(w, nvar, seen)) return;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
     if (cs != hipStreamCaptureStatusNone) return;
-    if (groups) {
+    if (wants_groups(w, nvar, nbatch, ns)) {
         w->grp_tried = 1;
-        try { if (build_groups_from_csr(w, stream)) return; }
+        try { (void)build_groups_from_csr(w, stream); }
         catch (const Error &) { (void)hipGetLastError(); drop_groups(w); }
-        if (!wants_sweep(w, nvar, nbatch, seen) && !wants_bands(w, nvar, seen)) return;     // declined: the older structures may still apply
     }
-    if (sweep || (groups && wants_sweep(w, nvar, nbatch, seen))) {
+    if (wants_sweep(w, nvar, nbatch, seen)) {           // (also: an E-row matrix whose groups were declined just now)
         w->sweep_tried = 1;
-        try { build_sweep_from_csr(w, stream); }
+        try { (void)build_sweep_from_csr(w, stream); }
         catch (const Error &) { (void)hipGetLastError(); drop_sweep(w); }
     }
-    if (wants_bands(w, nvar, seen)) {
+    if (w->grp_n == 0 && wants_bands(w, nvar, seen)) {
         w->band_tried = 1;
         try { build_bands_from_csr(w, stream); }
         catch (const Error &) { (void)hipGetLastError(); drop_bands(w); }

@@ -1,0 +1,66 @@
+"""BASELINE config 3: 5 km, 40 elevation classes, the chain EvI -> AvE -> IvA on 16 fields (ice -> elevation classes ->
+atmosphere -> ice), (a) as three stream-ordered applies, (b) captured once into a hipGraph and replayed: ONE submission
+per chain.  Prints wall microseconds per chain (many back-to-back chains, cold rotating inputs) and checks the result of the
+last replay against the eager chain bitwise.  usage: chain3.py [nfields] [config]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import icebin_amd
+from icebin_amd import synthetic as syn
+
+nf = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+cfg = sys.argv[2] if len(sys.argv) > 2 else "g5"
+g = syn.make_grids(cfg); em = syn.dome_elevmask(g)
+rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em, scale=True, correctA=True)
+W = {n: rm.matrix(n) for n in ("EvI", "AvE", "IvA")}
+for w in W.values():
+    w.prepare(nf, 1)
+nI_d, nE_d, nA_d = W["EvI"].ncol_d, W["EvI"].nrow_d, W["AvE"].nrow_d
+assert W["AvE"].ncol_d == nE_d and W["IvA"].ncol_d == nA_d
+nbuf = max(2, -(-(512 << 20) // (8 * nf * nI_d)))
+x0 = torch.from_numpy(syn.fields(nf, nI_d)).cuda()
+X = [x0 + 1e-3 * b for b in range(min(nbuf, 32))]
+xin = torch.empty_like(x0)
+yE = torch.zeros((nf, nE_d), dtype=torch.float64, device="cuda")
+yA = torch.zeros((nf, nA_d), dtype=torch.float64, device="cuda")
+ld = (W["IvA"].nrow_d + 63) // 64 * 64
+yI = torch.zeros((nf, ld), dtype=torch.float64, device="cuda")[:, :W["IvA"].nrow_d]
+
+
+def chain(x):
+    W["EvI"].apply_device(x, out=yE, force_conservation=False)
+    W["AvE"].apply_device(yE, out=yA, force_conservation=False)
+    W["IvA"].apply_device(yA, out=yI, force_conservation=False)
+
+
+for x in X[:4]:
+    chain(x)
+torch.cuda.synchronize()
+N = 400
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(N):
+    chain(X[i % len(X)])
+e1.record(); torch.cuda.synchronize()
+eager_us = e0.elapsed_time(e1) * 1e3 / N
+ref = yI.clone()
+# one graph per input buffer (a graph bakes its pointers in): capture the chain on every rotating input
+graphs = []
+for x in X:
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        chain(x)
+    graphs.append(gr)
+for gr in graphs[:4]:
+    gr.replay()
+torch.cuda.synchronize()
+e0.record()
+for i in range(N):
+    graphs[i % len(graphs)].replay()
+e1.record(); torch.cuda.synchronize()
+graph_us = e0.elapsed_time(e1) * 1e3 / N
+same = bool(torch.equal(yI.view(torch.int64), ref.view(torch.int64)))
+B = sum(12 * w.nnz + 4 * (w.nrow_d + 1) + 8 * nf * (w.ncol_d + w.nrow_d) for w in W.values())
+print("%s chain EvI->AvE->IvA, %d fields: kernels %s; %.1f MB algorithmic per chain; eager %.2f us per chain, hipGraph replay %.2f us per chain "
+      "(%.1f %% of 8 TB/s); graph result == eager result bitwise: %s" %
+      (cfg, nf, "/".join(W[n].last_kernel() for n in ("EvI", "AvE", "IvA")), B / 1e6, eager_us, graph_us, B / graph_us / 1e3 / 8000 * 100, same), flush=True)

@@ -473,7 +473,7 @@ def test_config2_5km_avi_iva_one_to_three_fields():
 def test_config4_1km_64_fields_benched_kernels_against_the_oracle():
     """BASELINE config 4 at the field count and through the kernels the 1 km bench lines time, against the oracle's apply
     (1.2e8..2.5e8 multiply-adds on the host): AvI on the column sweep in a batched launch (one entry per column: the
-    IDENT variant) and on rowblock; EvI on the column sweep (single and batched) and on rowblock; IvA on shortrow with
+    IDENT variant) and on rowblock; EvI on the row groups (single and batched), on the column sweep and on rowblock; IvA on shortrow with
     the transposed-input / 16-fields-per-thread plan of GB-sized results, with 512-byte planes and with the reference's
     contiguous planes (odd leading dimension: the re-aligning variant)."""
     import torch
@@ -494,12 +494,18 @@ def test_config4_1km_64_fields_benched_kernels_against_the_oracle():
         w.prepare(64, 4)                                 # what bench.py's W.prepare does: the sweep structure, scratch for 4 deep
         ys = w.apply_many_device([dx] * 4, fill=-1.0, force_conservation=False)
         torch.cuda.synchronize()
-        assert w.last_kernel() == "colsweep", name
+        assert w.last_kernel() == ("rowgroup" if name == "EvI" else "colsweep"), name
         for q in range(4):
             assert rel_linf(ys[q].cpu().numpy(), ref) <= FIELD_RTOL, (name, q)
         y1 = w.apply_device(dx, fill=-1.0, force_conservation=False)
         torch.cuda.synchronize()
-        assert w.last_kernel() == ("colsweep" if name == "EvI" else "rowblock")      # AvI: the sweep in batched launches only
+        assert w.last_kernel() == ("rowgroup" if name == "EvI" else "rowblock")      # AvI: the sweep in batched launches only
+        if name == "EvI":                                # the sweep serves batched launches of fewer fields: also against the oracle
+            w.set_kernel("colsweep")
+            yc = w.apply_many_device([dx] * 2, fill=-1.0, force_conservation=False)
+            torch.cuda.synchronize()
+            assert w.last_kernel() == "colsweep" and rel_linf(yc[1].cpu().numpy(), ref) <= FIELD_RTOL
+            w.set_kernel("auto")
         assert rel_linf(y1.cpu().numpy(), ref) <= FIELD_RTOL, name
         for k in (0, 33):
             if not np.isnan(x[k]).any():
@@ -1589,6 +1595,7 @@ def test_colsweep_lazy_build_batched_and_shared_dims():
     from icebin_amd.linear import set_tuning
     g, em, mm, rg = setup("g5")
     set_tuning("sweep_min_work", 1)
+    set_tuning("rowgroup_auto", 0)          # (with >= 32 fields the automatic choice for an E-row matrix is the row groups now)
     try:
         rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
         w, o = rm.matrix("EvI"), rg.matrix_d("EvI", em, scale=True, correctA=True)
@@ -1634,6 +1641,7 @@ def test_colsweep_lazy_build_batched_and_shared_dims():
         assert rel_linf(y, o2.apply(x, fill=-1.0, force_conservation=False)) <= FIELD_RTOL
     finally:
         set_tuning("sweep_min_work", 64 << 20)
+        set_tuning("rowgroup_auto", 1)
 
 
 def test_prepare_makes_applies_pure_enqueues():
@@ -1657,12 +1665,12 @@ def test_prepare_makes_applies_pure_enqueues():
         torch.cuda.synchronize()
         assert w0.last_kernel() == "rowblock"
         set_tuning("lazy_structures", 1)
-        # prepared: colsweep from the first apply on, single and batched, eager == captured
+        # prepared: the row groups from the first apply on, single and batched, eager == captured
         w = rm.matrix("EvI")
         w.prepare(64, len(xs))
         y = w.apply_device(xs[0], fill=-1.0, force_conservation=False)
         torch.cuda.synchronize()
-        assert w.last_kernel() == "colsweep"
+        assert w.last_kernel() == "rowgroup"
         assert rel_linf(y.cpu().numpy(), o.apply(xs[0].cpu().numpy(), fill=-1.0, force_conservation=False)) <= FIELD_RTOL
         outs = [torch.zeros((64, w.nrow_d), dtype=torch.float64, device="cuda") for _ in xs]
         gr = torch.cuda.CUDAGraph()
@@ -1670,11 +1678,24 @@ def test_prepare_makes_applies_pure_enqueues():
             w.apply_many_device(xs, outs, fill=-1.0, force_conservation=False)
         gr.replay()
         torch.cuda.synchronize()
-        assert w.last_kernel() == "colsweep"
+        assert w.last_kernel() == "rowgroup"
         eager = w.apply_many_device(xs, fill=-1.0, force_conservation=False)
         torch.cuda.synchronize()
         for a, b, x in zip(outs, eager, xs):
             assert np.array_equal(a.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
+            assert rel_linf(a.cpu().numpy(), o.apply(x.cpu().numpy(), fill=-1.0, force_conservation=False)) <= FIELD_RTOL
+        # fewer than 32 fields in batched launches: the column sweep (batches share its lanes), scratch sized for the depth
+        ws = rm.matrix("EvI")
+        x16 = [x[:16].contiguous() for x in xs[:4]]
+        ws.prepare(16, 4)
+        o16 = [torch.zeros((16, ws.nrow_d), dtype=torch.float64, device="cuda") for _ in x16]
+        gr3 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr3):
+            ws.apply_many_device(x16, o16, fill=-1.0, force_conservation=False)
+        gr3.replay()
+        torch.cuda.synchronize()
+        assert ws.last_kernel() == "colsweep"
+        for a, x in zip(o16, x16):
             assert rel_linf(a.cpu().numpy(), o.apply(x.cpu().numpy(), fill=-1.0, force_conservation=False)) <= FIELD_RTOL
         # an I-row matrix: the transposed-input scratch of a deep launch is sized too
         wi, oi = rm.matrix("IvE"), rg.matrix_d("IvE", em, scale=True, correctA=True)
@@ -1715,6 +1736,7 @@ def test_colsweep_batches_share_lanes(nvar, nbatch):
     from icebin_amd.linear import set_tuning
     g, em, mm, rg = setup("g5")
     set_tuning("sweep_min_work", 1)
+    set_tuning("rowgroup_auto", 0)          # (32 fields would go to the row groups)
     try:
         rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
         w, o = rm.matrix("EvI"), rg.matrix_d("EvI", em, scale=True, correctA=True)
@@ -1734,6 +1756,7 @@ def test_colsweep_batches_share_lanes(nvar, nbatch):
         assert rel_linf(y.cpu().numpy(), o.apply(xs[0].cpu().numpy(), fill=-2.0, force_conservation=False)) <= FIELD_RTOL
     finally:
         set_tuning("sweep_min_work", 64 << 20)
+        set_tuning("rowgroup_auto", 1)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
