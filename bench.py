@@ -194,7 +194,18 @@ def main():
     # results of `depth` applies share ONE all-gather while they are small (a [64, 122] AvI result is 62 KB:
     # a collective of that size is latency-bound); a result of megabytes (I-row matrices) is gathered per apply
     gsteps = depth if 8 * nf * ldy < (4 << 20) else 1
-    sharded = FieldShardedApply(W, nf_total, None, dev, steps_per_gather=gsteps) if use_dist else None
+    # ICEBIN_BENCH_SHARDED=cabi: the gathers through the library's own RCCL calls (ibh_comm, ibh_weighted_apply_*_sharded_device:
+    # direct peer-to-peer exchange) instead of torch.distributed's all_gather_into_tensor -- the path a C++ host takes
+    sharded = None
+    sharded_via = None
+    if use_dist:
+        if os.environ.get("ICEBIN_BENCH_SHARDED", "torch") == "cabi" and backend == "nccl":
+            from icebin_amd.distributed import CabiFieldShardedApply, Communicator
+            sharded = CabiFieldShardedApply(W, nf_total, Communicator(world, rank, rccl=True), dev, steps_per_gather=gsteps)
+            sharded_via = "C-ABI: ibh_weighted_apply_many_sharded_device (grouped ncclSend/ncclRecv to every peer)"
+        else:
+            sharded = FieldShardedApply(W, nf_total, None, dev, steps_per_gather=gsteps)
+            sharded_via = "torch.distributed all_gather_into_tensor (%s)" % backend
 
     def plan(i0, n, depth_=None, nbuf_=None):
         """Launch plan for steps i0 .. i0+n-1: (count, X pointers, X pointer table, Y pointer table),
@@ -427,6 +438,7 @@ def main():
             result["spmm_only_ms"] = spmm_only
             result["spmm_plus_gather_ms"] = dt / args.steps * 1e3
             result["gather_bytes_per_rank_per_step"] = 8 * nf * ((nrow + 63) // 64 * 64)
+            result["gather_via"] = sharded_via
             result["gather_check"] = gather_check
             result["ranks_seen"] = ranks_seen
         if not args.no_cpu_baseline and world == 1:

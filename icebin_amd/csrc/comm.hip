@@ -1,0 +1,285 @@
+// comm.hip -- field-sharded applies across the GPUs of one node, behind the C-ABI.
+//
+// One process per GPU; rank r owns the fields [r*nvar_local, (r+1)*nvar_local) of a multi-field regrid (contiguous in the
+// field-major arrays), the CSR is replicated, the SpMM needs no communication, and the results are reassembled on every
+// rank.  The reference has no counterpart: it gathers everything to MPI rank 0 and regrids there
+// (modele/GCMCoupler_ModelE.cpp:764-792).
+//
+// The exchange is DIRECT: every rank sends its block of a field group to each peer and receives the peers' blocks into
+// their final places in the caller's result array (grouped ncclSend / ncclRecv) -- on MI355X xGMI is a full mesh of
+// point-to-point links (7 x ~153 GB/s per GPU), so seven concurrent peer transfers use all links at once, and no ring
+// collective has to walk one link at a time; in-place (no staging copy) for any row range of the result.  It runs on a stream
+// the communicator owns: the SpMM of field block b+1 (and of the next apply) overlaps the exchange of block b.
+// RCCL is loaded at run time (dlopen): a box without librccl still loads libicebin_hip.so; world 1 needs no library at all.
+// A caller may also plug in its own transport (ibh_comm_create_custom: the tests run two ranks over a host-staged one).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <memory>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace ibh {
+namespace {
+struct nccl_uid { char internal[IBH_UNIQUE_ID_BYTES]; };
+typedef void *nccl_comm_t;
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(nccl_uid *) = nullptr;
+    int (*CommInitRank)(nccl_comm_t *, int, nccl_uid, int) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+constexpr int kNcclFloat64 = 8;      // ncclDataType_t (rccl.h: ncclFloat64 = 8)
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the copy already in the process first (a PyTorch process has loaded its bundled librccl: one RCCL per process)
+        const char *names[] = {getenv("ICEBIN_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            if (!n || !*n) continue;
+            r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (r.h) break;
+        }
+        for (const char *n : names) {
+            if (r.h) break;
+            if (!n || !*n) continue;
+            r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!r.h) { r.err = std::string("librccl not found (") + (dlerror() ? dlerror() : "?") + "); set ICEBIN_RCCL_LIB"; return; }
+        auto sym = [&](const char *name) { void *p = dlsym(r.h, name); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + name; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return r;
+}
+Rccl &need_rccl() {
+    Rccl &r = rccl();
+    if (!r.err.empty()) fail(IBH_ENOTIMPL, "multi-GPU exchange needs RCCL: %s", r.err.c_str());
+    return r;
+}
+#define IBH_NCCL(expr)                                                                                             \
+    do {                                                                                                           \
+        const int e_ = (expr);                                                                                     \
+        if (e_ != 0) ::ibh::fail(IBH_EHIP, "%s failed: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(e_) : "?"); \
+    } while (0)
+}  // namespace
+}  // namespace ibh
+
+struct ibh_comm {
+    int world = 1, rank = 0, device = 0;
+    ibh::nccl_comm_t nccl = nullptr;
+    ibh_exchange_fn custom = nullptr;
+    void *custom_user = nullptr;
+    hipStream_t xs = nullptr;            // the exchange stream
+    hipEvent_t ready = nullptr;
+    // exchanges in flight: the byte range of the result array each one writes and the event behind it.  A later apply whose
+    // results overlap such a range is ordered behind THAT exchange only -- so with two alternating result arrays the SpMM of
+    // apply k+1 overlaps the exchange of apply k.
+    static constexpr int RING = 8;
+    struct Flight { const char *lo = nullptr, *hi = nullptr; hipEvent_t ev = nullptr; bool live = false; } ring[RING];
+    int next = 0;
+};
+
+using namespace ibh;
+
+static void comm_common_init(ibh_comm *c) {
+    IBH_HIP(hipGetDevice(&c->device));
+    IBH_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+    IBH_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    for (auto &f : c->ring) IBH_HIP(hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
+}
+// the SpMM about to write [lo, hi) on stream st must not overtake an exchange that still reads / writes that range
+static void order_behind_flights(ibh_comm *c, const void *lo, const void *hi, hipStream_t st) {
+    for (auto &f : c->ring)
+        if (f.live && static_cast<const char *>(lo) < f.hi && f.lo < static_cast<const char *>(hi)) {
+            IBH_HIP(hipStreamWaitEvent(st, f.ev, 0));
+            f.live = false;
+        }
+}
+// the exchange just enqueued on c->xs covers [lo, hi)
+static void record_flight(ibh_comm *c, const void *lo, const void *hi, hipStream_t st) {
+    ibh_comm::Flight &f = c->ring[c->next];
+    c->next = (c->next + 1) % ibh_comm::RING;
+    if (f.live) IBH_HIP(hipStreamWaitEvent(st, f.ev, 0));      // the ring is full: the oldest exchange becomes a dependency of the stream
+    IBH_HIP(hipEventRecord(f.ev, c->xs));
+    f.lo = static_cast<const char *>(lo); f.hi = static_cast<const char *>(hi); f.live = true;
+}
+
+// for every base of the list: every rank's `count` doubles at base + rank*stride reach base + rank*stride on every peer; enqueued
+// on the exchange stream as ONE group (one RCCL launch however many results travel)
+static void exchange(ibh_comm *c, double *const *d_bases, int nbase, int64_t count, int64_t stride) {
+    if (c->world == 1 || count == 0 || nbase == 0) return;
+    if (c->custom) {
+        for (int q = 0; q < nbase; ++q) {
+            const int rc = c->custom(c->custom_user, d_bases[q], count, stride, c->world, c->rank, c->xs);
+            if (rc != 0) fail(IBH_EHIP, "custom exchange callback failed (%d)", rc);
+        }
+        return;
+    }
+    Rccl &r = need_rccl();
+    IBH_NCCL(r.GroupStart());
+    for (int k = 1; k < c->world; ++k) {             // peers in a rotated order: at step k everybody talks to a different partner
+        const int to = (c->rank + k) % c->world, from = (c->rank - k + c->world) % c->world;
+        for (int q = 0; q < nbase; ++q) {
+            IBH_NCCL(r.Send(d_bases[q] + (int64_t)c->rank * stride, (size_t)count, kNcclFloat64, to, c->nccl, c->xs));
+            IBH_NCCL(r.Recv(d_bases[q] + (int64_t)from * stride, (size_t)count, kNcclFloat64, from, c->nccl, c->xs));
+        }
+    }
+    IBH_NCCL(r.GroupEnd());
+}
+
+extern "C" {
+
+int ibh_comm_unique_id(char id[IBH_UNIQUE_ID_BYTES]) {
+    return guarded([&] {
+        IBH_CHECK(id != nullptr, "null argument");
+        nccl_uid u;
+        IBH_NCCL(need_rccl().GetUniqueId(&u));
+        memcpy(id, u.internal, IBH_UNIQUE_ID_BYTES);
+    });
+}
+
+int ibh_comm_create(int world, int rank, const char id[IBH_UNIQUE_ID_BYTES], ibh_comm **out) {
+    return guarded([&] {
+        IBH_CHECK(out != nullptr && world >= 1 && rank >= 0 && rank < world, "bad communicator shape (world %d, rank %d)", world, rank);
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) fail(IBH_ENODEVICE, "no HIP device available; libicebin_hip has no CPU fallback");
+        std::unique_ptr<ibh_comm> c(new ibh_comm);
+        c->world = world; c->rank = rank;
+        comm_common_init(c.get());
+        IBH_CHECK(world == 1 || id != nullptr, "a communicator of %d ranks needs the unique id rank 0 obtained from ibh_comm_unique_id", world);
+        if (id != nullptr) {                        // (also at world 1 when an id is given: one rank is a valid RCCL communicator)
+            nccl_uid u;
+            memcpy(u.internal, id, IBH_UNIQUE_ID_BYTES);
+            IBH_NCCL(need_rccl().CommInitRank(&c->nccl, world, u, rank));
+        }
+        *out = c.release();
+    });
+}
+
+int ibh_comm_create_custom(int world, int rank, ibh_exchange_fn fn, void *user, ibh_comm **out) {
+    return guarded([&] {
+        IBH_CHECK(out != nullptr && world >= 1 && rank >= 0 && rank < world && fn != nullptr, "bad arguments");
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) fail(IBH_ENODEVICE, "no HIP device available; libicebin_hip has no CPU fallback");
+        std::unique_ptr<ibh_comm> c(new ibh_comm);
+        c->world = world; c->rank = rank; c->custom = fn; c->custom_user = user;
+        comm_common_init(c.get());
+        *out = c.release();
+    });
+}
+
+int ibh_comm_destroy(ibh_comm *c) {
+    return guarded([&] {
+        if (!c) return;
+        if (c->xs) (void)hipStreamSynchronize(c->xs);
+        if (c->nccl && rccl().CommDestroy) (void)rccl().CommDestroy(c->nccl);
+        if (c->ready) (void)hipEventDestroy(c->ready);
+        for (auto &f : c->ring) if (f.ev) (void)hipEventDestroy(f.ev);
+        if (c->xs) (void)hipStreamDestroy(c->xs);
+        delete c;
+    });
+}
+
+int ibh_comm_info(const ibh_comm *c, int *world, int *rank) {
+    return guarded([&] {
+        IBH_CHECK(c != nullptr, "null argument");
+        if (world) *world = c->world;
+        if (rank) *rank = c->rank;
+    });
+}
+
+int ibh_comm_wait(ibh_comm *c, void *stream) {
+    return guarded([&] {
+        IBH_CHECK(c != nullptr, "null argument");
+        for (auto &f : c->ring)
+            if (f.live) { IBH_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), f.ev, 0)); f.live = false; }
+    });
+}
+
+int ibh_weighted_apply_sharded_device(const ibh_weighted *w, ibh_comm *c, const double *dA_local, int32_t nvar_local, int64_t lda,
+                                      double *dB_all, int64_t ldb, double fill, int32_t block_fields, void *stream) {
+    return guarded([&] {
+        IBH_CHECK(w && c && nvar_local >= 0 && (nvar_local == 0 || (dA_local && dB_all)), "bad arguments");
+        int dev = -1;
+        IBH_HIP(hipGetDevice(&dev));
+        IBH_CHECK(dev == w->device && dev == c->device, "matrix (device %d), communicator (device %d) and current device (%d) differ",
+                  w->device, c->device, dev);
+        if (nvar_local == 0) return;
+        IBH_CHECK(lda >= w->ncol && ldb >= w->nrow, "apply: leading dimensions (%ld, %ld) smaller than (%d, %d)", (long)lda, (long)ldb, w->ncol, w->nrow);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        // field blocks: small results travel as ONE exchange per apply (a [64, 122] AvI result is 62 KB: latency-bound), results
+        // of megabytes (I-row matrices) a few fields at a time so that the exchange of block b overlaps the SpMM of block b+1
+        int bf = block_fields;
+        if (bf <= 0) {
+            const double plane_mb = 8.0 * (double)ldb / 1048576.0;
+            bf = plane_mb * nvar_local <= 4.0 ? nvar_local : std::max(1, std::min(nvar_local, (int)(16.0 / std::max(plane_mb, 1e-9))));
+        }
+        bf = std::min(bf, (int)nvar_local);
+        double *mine = dB_all + (int64_t)c->rank * nvar_local * ldb;
+        const int64_t stride = (int64_t)nvar_local * ldb;
+        // an earlier exchange may still be writing into this result array: order the new SpMM behind it
+        order_behind_flights(c, dB_all, dB_all + (int64_t)c->world * stride, st);
+        for (int f0 = 0; f0 < nvar_local; f0 += bf) {
+            const int nb = std::min(bf, nvar_local - f0);
+            spmm_launch(w, dA_local + (int64_t)f0 * lda, nb, lda, mine + (int64_t)f0 * ldb, ldb, fill, 0, st);
+            if (c->world > 1) {
+                IBH_HIP(hipEventRecord(c->ready, st));
+                IBH_HIP(hipStreamWaitEvent(c->xs, c->ready, 0));
+                // the last field of a block ends at row nrow of its plane: the padding up to ldb of that last plane is not sent
+                double *base = dB_all + (int64_t)f0 * ldb;
+                exchange(c, &base, 1, (int64_t)(nb - 1) * ldb + w->nrow, stride);
+            }
+        }
+        if (c->world > 1) record_flight(c, dB_all, dB_all + (int64_t)c->world * stride, st);
+    });
+}
+
+int ibh_weighted_apply_many_sharded_device(const ibh_weighted *w, ibh_comm *c, int32_t nbatch, const double *const *dA_local,
+                                           int32_t nvar_local, int64_t lda, double *const *dB_all, int64_t ldb, double fill, void *stream) {
+    return guarded([&] {
+        IBH_CHECK(w && c && nbatch >= 0 && nvar_local >= 0 && (nbatch == 0 || nvar_local == 0 || (dA_local && dB_all)), "bad arguments");
+        int dev = -1;
+        IBH_HIP(hipGetDevice(&dev));
+        IBH_CHECK(dev == w->device && dev == c->device, "matrix (device %d), communicator (device %d) and current device (%d) differ",
+                  w->device, c->device, dev);
+        if (nbatch == 0 || nvar_local == 0) return;
+        IBH_CHECK(lda >= w->ncol && ldb >= w->nrow, "apply: leading dimensions (%ld, %ld) smaller than (%d, %d)", (long)lda, (long)ldb, w->ncol, w->nrow);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int64_t stride = (int64_t)nvar_local * ldb;
+        std::vector<double *> mine((size_t)nbatch);
+        for (int q = 0; q < nbatch; ++q) {
+            IBH_CHECK(dA_local[q] && dB_all[q], "apply: null field pointer in batch %d", q);
+            mine[(size_t)q] = dB_all[q] + (int64_t)c->rank * stride;
+        }
+        const double *lo = dB_all[0], *hi = dB_all[0];
+        for (int q = 0; q < nbatch; ++q) { lo = std::min<const double *>(lo, dB_all[q]); hi = std::max<const double *>(hi, dB_all[q] + (int64_t)c->world * stride); }
+        order_behind_flights(c, lo, hi, st);
+        spmm_launch_many(w, nbatch, dA_local, nvar_local, lda, mine.data(), ldb, fill, 0, st);
+        if (c->world > 1) {
+            IBH_HIP(hipEventRecord(c->ready, st));
+            IBH_HIP(hipStreamWaitEvent(c->xs, c->ready, 0));
+            exchange(c, dB_all, nbatch, (int64_t)(nvar_local - 1) * ldb + w->nrow, stride);
+            record_flight(c, lo, hi, st);
+        }
+    });
+}
+
+}  // extern "C"

@@ -292,3 +292,150 @@ class FieldShardedApply:
             r0, r1 = field_shard(self.nf_total, self.world, r)
             parts.append(o[r, : r1 - r0, : self.nrow])
         return torch.cat(parts, dim=0)
+
+
+# ---- the same behind the C-ABI: ibh_comm + ibh_weighted_apply_sharded_device (RCCL called from the library) ----------------
+class Communicator:
+    """ibh_comm: the ranks of a field-sharded regrid, one process per GPU.  `bootstrap` ships rank 0's 128-byte RCCL unique id
+    to the other ranks -- by default through torch.distributed.broadcast_object_list on whatever process group is up (any
+    backend: it only carries 128 bytes); a C++ host would use its own channel (ModelE: MPI_Bcast).  world == 1 needs nothing.
+    `exchange` (a Python callable, tests only) replaces RCCL by a custom transport (ibh_comm_create_custom)."""
+
+    def __init__(self, world=1, rank=0, bootstrap=None, exchange=None, rccl=None):
+        """rccl: None = only when world > 1; True = also at world 1 (a one-rank RCCL communicator: exercises the library's
+        RCCL binding on a single GPU)."""
+        import ctypes as C
+        from . import _capi
+        self._capi, self._C = _capi, C
+        L = _capi.lib()
+        h = C.c_void_p()
+        self._cb = None
+        if exchange is not None:
+            proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p)
+
+            def _cb(user, d_base, count, stride, w, r, stream):
+                try:
+                    exchange(d_base, count, stride, w, r, stream)
+                    return 0
+                except Exception:      # noqa: BLE001 -- must not unwind through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = proto(_cb)
+            _capi.check(L.ibh_comm_create_custom(world, rank, C.cast(self._cb, C.c_void_p), None, C.byref(h)))
+        elif world == 1 and not rccl:
+            _capi.check(L.ibh_comm_create(1, 0, None, C.byref(h)))
+        else:
+            buf = C.create_string_buffer(128)
+            if rank == 0:
+                _capi.check(L.ibh_comm_unique_id(buf))
+            if world == 1:
+                uid = buf.raw
+            elif bootstrap is None:
+                box = [buf.raw]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+            else:
+                uid = bootstrap(buf.raw if rank == 0 else None)
+            _capi.check(L.ibh_comm_create(world, rank, uid, C.byref(h)))
+        self._h, self.world, self.rank = h, world, rank
+
+    def __del__(self):
+        try:
+            self._capi.destroy("ibh_comm_destroy", getattr(self, "_h", None))
+        except Exception:      # interpreter shutdown
+            pass
+        self._h = None
+
+    def wait(self, stream=None):
+        """Make `stream` (a raw stream handle; default torch's current stream) wait for the exchanges enqueued so far."""
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        self._capi.check(self._capi.lib().ibh_comm_wait(self._h, self._C.c_void_p(s)))
+
+
+def apply_sharded(weighted, comm, x_local, out_all=None, fill=float("nan"), block_fields=0, stream=None):
+    """ibh_weighted_apply_sharded_device: x_local [nvar_local, ncol_d] (torch.float64, CUDA) -> out_all
+    [world * nvar_local, nrow_d] on every rank (rows padded to 512 bytes when allocated here); complete after comm.wait()."""
+    import ctypes as C
+    from . import _capi
+    assert x_local.is_cuda and x_local.dtype == torch.float64 and x_local.dim() == 2 and x_local.stride(1) == 1
+    nl = x_local.shape[0]
+    if out_all is None:
+        ld = (weighted.nrow_d + 63) // 64 * 64
+        out_all = torch.zeros((comm.world * nl, ld), dtype=torch.float64, device=x_local.device)[:, : weighted.nrow_d]
+    assert out_all.shape == (comm.world * nl, weighted.nrow_d) and out_all.stride(1) == 1
+    s = torch.cuda.current_stream(x_local.device).cuda_stream if stream is None else stream
+    _capi.check(_capi.lib().ibh_weighted_apply_sharded_device(
+        weighted._h, comm._h, C.c_void_p(x_local.data_ptr()), nl, max(x_local.stride(0), weighted.ncol_d), C.c_void_p(out_all.data_ptr()),
+        max(out_all.stride(0), weighted.nrow_d), float(fill), int(block_fields), C.c_void_p(s)))
+    return out_all
+
+
+def apply_many_sharded(weighted, comm, xs_local, outs_all, fill=float("nan"), stream=None):
+    """ibh_weighted_apply_many_sharded_device: len(xs_local) field batches through ONE SpMM launch and ONE grouped exchange;
+    outs_all: list of [world * nvar_local, nrow_d] result arrays (all with the same row stride)."""
+    import ctypes as C
+    from . import _capi
+    nb = len(xs_local)
+    assert nb == len(outs_all) and nb >= 1
+    nl, lda = xs_local[0].shape[0], max(xs_local[0].stride(0), weighted.ncol_d)
+    ldb = max(outs_all[0].stride(0), weighted.nrow_d)
+    for x, o in zip(xs_local, outs_all):
+        assert x.is_cuda and x.dtype == torch.float64 and x.shape == (nl, weighted.ncol_d) and max(x.stride(0), weighted.ncol_d) == lda
+        assert o.shape == (comm.world * nl, weighted.nrow_d) and max(o.stride(0), weighted.nrow_d) == ldb and o.stride(1) == 1
+    xa = (C.c_void_p * nb)(*[x.data_ptr() for x in xs_local])
+    oa = (C.c_void_p * nb)(*[o.data_ptr() for o in outs_all])
+    s = torch.cuda.current_stream(xs_local[0].device).cuda_stream if stream is None else stream
+    _capi.check(_capi.lib().ibh_weighted_apply_many_sharded_device(weighted._h, comm._h, nb, xa, nl, lda, oa, ldb, float(fill), C.c_void_p(s)))
+    return outs_all
+
+
+class CabiFieldShardedApply:
+    """The interface bench.py drives (FieldShardedApply: apply_ptr / apply_many_ptr / flush / wait / result) over the C-ABI
+    path: ibh_weighted_apply_(many_)sharded_device on a Communicator -- the library calls RCCL itself, as a C++ host would use
+    it.  Equal shards only; two alternating result arrays per group slot, so the exchange of group g overlaps the SpMMs of
+    group g+1 (the library orders work by the address ranges in flight)."""
+
+    def __init__(self, weighted, nf_total, comm, device, steps_per_gather=1):
+        import ctypes as C
+        from . import _capi
+        self._C, self._capi, self._L = C, _capi, _capi.lib()
+        self.w, self.comm, self.G = weighted, comm, int(steps_per_gather)
+        assert nf_total % comm.world == 0, "the C-ABI sharded apply takes equal shards"
+        self.nl, self.nf_total = nf_total // comm.world, nf_total
+        self.nrow, self.ncol = weighted.nrow_d, weighted.ncol_d
+        self.ld = (self.nrow + 63) // 64 * 64
+        self.device = device
+        self._out = [torch.zeros((self.G, nf_total, self.ld), dtype=torch.float64, device=device) for _ in range(2)]
+        self._i = 0
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def apply_many_ptr(self, x_ptrs, ldx, fill=float("nan")):
+        C, m, i = self._C, len(x_ptrs), self._i
+        g, slot = (i // self.G) & 1, i % self.G
+        assert 1 <= m <= self.G - slot
+        xa = (C.c_void_p * m)(*x_ptrs)
+        oa = (C.c_void_p * m)(*[self._out[g][slot + s].data_ptr() for s in range(m)])
+        self._capi.check(self._L.ibh_weighted_apply_many_sharded_device(self.w._h, self.comm._h, m, xa, self.nl, ldx, oa, self.ld, fill, self._stream()))
+        self._i = i + m
+        return g, slot
+
+    def apply_ptr(self, x_ptr, ldx, fill=float("nan")):
+        C, i = self._C, self._i
+        g, slot = (i // self.G) & 1, i % self.G
+        self._capi.check(self._L.ibh_weighted_apply_sharded_device(self.w._h, self.comm._h, C.c_void_p(x_ptr), self.nl, ldx,
+                                                                   C.c_void_p(self._out[g][slot].data_ptr()), self.ld, fill, 0, self._stream()))
+        self._i = i + 1
+        return g, slot
+
+    def flush(self):
+        if self._i % self.G:
+            self._i += self.G - self._i % self.G
+
+    def wait(self):
+        self.comm.wait()
+
+    def result(self, g, slot):
+        return self._out[g][slot][:, : self.nrow]

@@ -105,6 +105,30 @@ struct RegridParams {
         : scale(_scale), correctA(_correctA), sigma(_sigma) {}
 };
 
+/** The ranks of a field-sharded regrid, one process per GPU (ibh_comm; RCCL over xGMI underneath).  Rank 0 calls
+    Communicator::unique_id() and ships the 128 bytes to the others with whatever the host program has (ModelE: MPI_Bcast);
+    then every rank constructs Communicator(world, rank, id) on its own device.  world == 1 needs neither id nor RCCL. */
+class Communicator {
+    ibh_comm *h_ = nullptr;
+public:
+    static std::array<char, IBH_UNIQUE_ID_BYTES> unique_id() {
+        std::array<char, IBH_UNIQUE_ID_BYTES> id;
+        check(ibh_comm_unique_id(id.data()));
+        return id;
+    }
+    Communicator() { check(ibh_comm_create(1, 0, nullptr, &h_)); }
+    Communicator(int world, int rank, std::array<char, IBH_UNIQUE_ID_BYTES> const &id) { check(ibh_comm_create(world, rank, id.data(), &h_)); }
+    Communicator(int world, int rank, ibh_exchange_fn fn, void *user) { check(ibh_comm_create_custom(world, rank, fn, user, &h_)); }
+    Communicator(Communicator const &) = delete;
+    Communicator &operator=(Communicator const &) = delete;
+    ~Communicator() { if (h_) ibh_comm_destroy(h_); }
+    int world() const { int w; check(ibh_comm_info(h_, &w, nullptr)); return w; }
+    int rank() const { int r; check(ibh_comm_info(h_, nullptr, &r)); return r; }
+    /** make `stream` wait for the exchanges enqueued so far: the gathered results are complete behind it */
+    void wait(void *stream) const { check(ibh_comm_wait(h_, stream)); }
+    ibh_comm *handle() const { return h_; }
+};
+
 namespace linear {
 /** ibmisc::linear::Weighted / Weighted_Eigen: M plus wM, Mw, dims, conservative, scaled. */
 class Weighted {
@@ -215,6 +239,20 @@ public:
         only enqueue work (ibh_weighted_prepare).  Once per matrix, e.g. right after matrix_d() in a coupler that
         applies the matrix more than once per step, and before capturing applies into a hipGraph. */
     void prepare(int nvar, int nbatch = 1) const { check(ibh_weighted_prepare(h_, nvar, nbatch)); }
+    /** apply() of world x nvar_local fields sharded by field over the ranks of `comm`: this rank's dA_local (nvar_local x lda)
+        -> dB_all (world*nvar_local x ldb, the same on every rank once comm.wait(stream) has been honoured).  The SpMM runs on
+        `stream`, the peer-to-peer exchange on the communicator's own stream, block_fields fields at a time (0: by size). */
+    void apply_sharded_device(Communicator const &comm, const double *dA_local, int nvar_local, long lda, double *dB_all, long ldb,
+                              double fill, void *stream, int block_fields = 0) const {
+        check(ibh_weighted_apply_sharded_device(h_, comm.handle(), dA_local, nvar_local, lda, dB_all, ldb, fill, block_fields, stream));
+    }
+    /** several field batches: ONE SpMM launch, ONE grouped exchange (ibh_weighted_apply_many_sharded_device) */
+    void apply_many_sharded_device(Communicator const &comm, std::vector<const double *> const &dA_local, int nvar_local, long lda,
+                                   std::vector<double *> const &dB_all, long ldb, double fill, void *stream) const {
+        if (dA_local.size() != dB_all.size()) throw Exception(IBH_EINVAL, "apply_many_sharded_device: batch lists differ in length");
+        check(ibh_weighted_apply_many_sharded_device(h_, comm.handle(), (int32_t)dA_local.size(), dA_local.data(), nvar_local, lda,
+                                                     dB_all.data(), ldb, fill, stream));
+    }
     /** Device-resident variant: dA_b (nvar x lda) and dB_b (nvar x ldb) are HBM pointers; enqueues on stream. */
     void apply_device(const double *dA_b, int nvar, long lda, double *dB_b, long ldb, double fill,
                       bool force_conservation, void *stream) const {

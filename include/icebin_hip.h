@@ -276,6 +276,47 @@ int ibh_coo_matvec(double *yy /* [nrow] in/out */, const double *xx /* [ncol] */
 int ibh_weighted_apply_weight_host(const ibh_weighted *w, int dim, const double *A_b,
                                    int32_t nvar, int64_t lda, double *out /* [nvar] */);
 
+/* ------------------------------------------------------------------------- */
+/* Field-sharded applies across the GPUs of one node (BASELINE.json north_star).  One process per GPU:
+ * rank r owns the fields [r*nvar_local, (r+1)*nvar_local) of a regrid of world*nvar_local fields (contiguous in the
+ * field-major arrays), every rank holds the same matrix (built redundantly: a build is cheaper than broadcasting it),
+ * the SpMM needs no communication and the results are reassembled on EVERY rank.  The reference has no counterpart:
+ * it gathers everything to MPI rank 0 and regrids there (modele/GCMCoupler_ModelE.cpp:764-792).
+ *   ibh_comm_unique_id   rank 0 obtains an id (ncclGetUniqueId) and ships it to the other ranks by whatever the host
+ *                        program has (MPI_Bcast in ModelE: GCMCoupler_ModelE.cpp; a file; torch.distributed);
+ *   ibh_comm_create      every rank: the communicator on its CURRENT device (ncclCommInitRank; id may be NULL for
+ *                        world == 1, which needs no RCCL).  RCCL is loaded at run time (dlopen; ICEBIN_RCCL_LIB
+ *                        overrides the search): without it only world == 1 and custom transports work;
+ *   ibh_comm_create_custom  the same choreography over a transport the caller supplies (tests; other fabrics):
+ *                        fn(user, d_base, count, stride, world, rank, stream) must deliver every rank's `count` doubles at
+ *                        d_base + rank*stride to d_base + rank*stride on every peer, ordered on `stream`; 0 = success. */
+#define IBH_UNIQUE_ID_BYTES 128
+typedef struct ibh_comm ibh_comm;
+typedef int (*ibh_exchange_fn)(void *user, double *d_base, int64_t count, int64_t stride, int world, int rank, void *stream);
+int ibh_comm_unique_id(char id[IBH_UNIQUE_ID_BYTES]);
+int ibh_comm_create(int world, int rank, const char id[IBH_UNIQUE_ID_BYTES], ibh_comm **out);
+int ibh_comm_create_custom(int world, int rank, ibh_exchange_fn fn, void *user, ibh_comm **out);
+int ibh_comm_destroy(ibh_comm *c);
+int ibh_comm_info(const ibh_comm *c, int *world, int *rank);
+/* Weighted::apply of world*nvar_local fields, sharded by field: dB_all [world*nvar_local x ldb] (device, the same
+ * shape on every rank) receives rank r's results in rows [r*nvar_local, (r+1)*nvar_local).  The local SpMM is enqueued on
+ * `stream` and writes straight into this rank's rows; the exchange -- direct peer-to-peer sends (xGMI is a full mesh:
+ * seven concurrent transfers use all links) -- runs on a stream the communicator owns, `block_fields` fields at a time
+ * (0: chosen by size -- one exchange for KB-sized results, blocks of ~16 MB for the GB-sized results of the I-row
+ * matrices) so that it overlaps the SpMM of the following block and of the following apply.  dB_all is complete once
+ * ibh_comm_wait(c, s) has made stream s wait for the exchanges enqueued so far.  Same results as ibh_weighted_apply_device
+ * on each rank's fields (bitwise), conservative matrices only (no force_conservation). */
+int ibh_weighted_apply_sharded_device(const ibh_weighted *w, ibh_comm *c, const double *dA_local, int32_t nvar_local,
+                                      int64_t lda, double *dB_all, int64_t ldb, double fill, int32_t block_fields,
+                                      void *stream);
+/* The same for nbatch independent field batches (ibh_weighted_apply_many_device: ONE SpMM launch) whose results travel in
+ * ONE grouped exchange -- for KB-sized results (A- and E-row matrices: a [64, 122] AvI result is 62 KB) an exchange per
+ * apply is latency-bound, a group of 32 is not.  dA_local / dB_all: host arrays of nbatch device pointers. */
+int ibh_weighted_apply_many_sharded_device(const ibh_weighted *w, ibh_comm *c, int32_t nbatch, const double *const *dA_local,
+                                           int32_t nvar_local, int64_t lda, double *const *dB_all, int64_t ldb, double fill,
+                                           void *stream);
+int ibh_comm_wait(ibh_comm *c, void *stream);
+
 /* Device pointers of the CSR and weights, for callers that keep fields resident
  * (IceCoupler.cpp:408,445,456 read ->M and ->wM directly). */
 typedef struct ibh_weighted_device_view {

@@ -197,3 +197,130 @@ def test_bench_refuses_a_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
                        timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+# ---- the sharded apply behind the C-ABI (ibh_comm, ibh_weighted_apply_sharded_device) ------------------------------------
+def _sharded_cases():
+    return (("AvI", 6, 0), ("AvI", 6, 4), ("IvA", 5, 2), ("EvI", 8, 0))       # (matrix, fields per rank, block_fields)
+
+
+@pytest.mark.gpu
+def test_sharded_apply_world1_through_rccl():
+    """World 1 on the one GPU of the box, with a real RCCL communicator (ibh_comm_unique_id -> ncclGetUniqueId,
+    ibh_comm_create -> ncclCommInitRank: librccl is dlopen'ed by the library): the sharded apply is the plain apply."""
+    sys.path.insert(0, ROOT)
+    import icebin_amd
+    from icebin_amd import synthetic as syn
+    from icebin_amd.distributed import Communicator, apply_sharded
+    g = syn.make_grids("g20")
+    em = syn.dome_elevmask(g)
+    rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em, scale=True, correctA=True)
+    for comm in (Communicator(1, 0), Communicator(1, 0, rccl=True)):      # without RCCL; a one-rank RCCL communicator
+        for name, nl, bf in _sharded_cases():
+            w = rm.matrix(name)
+            x = torch.from_numpy(syn.fields(nl, w.ncol_d, seed=11)).cuda()
+            x[0, 3] = float("nan")
+            ref = w.apply_device(x, fill=-2.0, force_conservation=False)
+            out = apply_sharded(w, comm, x, fill=-2.0, block_fields=bf)
+            comm.wait()
+            torch.cuda.synchronize()
+            if bf == 0:
+                assert np.array_equal(out.cpu().numpy().view(np.uint64), ref.cpu().numpy().view(np.uint64)), name
+            else:       # a block of fewer fields may take another launch shape: same sums, rounding-level differences at most
+                a, b = out.cpu().numpy(), ref.cpu().numpy()
+                assert np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b)) <= 1e-12 * np.nanmax(np.abs(b)), name
+
+
+def _worker_sharded(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import icebin_amd
+        from icebin_amd import synthetic as syn
+        from icebin_amd.distributed import Communicator, apply_sharded
+        torch.cuda.set_device(0)                        # both ranks share the box's one card: the transport is host-staged
+        g = syn.make_grids("g20")
+        em = syn.dome_elevmask(g)
+        rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em, scale=True, correctA=True)
+        state = {}
+
+        def exchange(d_base, count, stride, w_, r_, stream):
+            # every rank's `count` doubles at d_base + rank*stride -> the same place on every peer (gloo, through the host)
+            flat = state["out"]
+            off = (d_base - flat.data_ptr()) // 8
+            torch.cuda.synchronize()
+            mine = flat[off + r_ * stride: off + r_ * stride + count].cpu()
+            parts = [torch.empty_like(mine) for _ in range(w_)]
+            dist.all_gather(parts, mine)
+            for p in range(w_):
+                if p != r_:
+                    flat[off + p * stride: off + p * stride + count].copy_(parts[p])
+            torch.cuda.synchronize()
+            state["calls"] = state.get("calls", 0) + 1
+        comm = Communicator(world, rank, exchange=exchange)
+        ok = True
+        ncalls = []
+        for name, nl, bf in _sharded_cases():
+            w = rm.matrix(name)
+            x_all = syn.fields(world * nl, w.ncol_d, seed=21)        # the same on every rank
+            x_all[1, 5] = np.nan
+            ld = (w.nrow_d + 63) // 64 * 64
+            store = torch.full((world * nl, ld), -9.0, dtype=torch.float64, device="cuda")
+            state["out"], state["calls"] = store.view(-1), 0
+            x_loc = torch.from_numpy(x_all[rank * nl:(rank + 1) * nl].copy()).cuda()
+            out = apply_sharded(w, comm, x_loc, out_all=store[:, : w.nrow_d], fill=-2.0, block_fields=bf)
+            comm.wait()
+            torch.cuda.synchronize()
+            ncalls.append(state["calls"])
+            for p in range(world):                                   # every rank's rows against that rank's own apply
+                xp = torch.from_numpy(x_all[p * nl:(p + 1) * nl].copy()).cuda()
+                if bf == 0:
+                    ref = w.apply_device(xp, fill=-2.0, force_conservation=False).cpu().numpy()
+                else:
+                    ref = np.concatenate([w.apply_device(xp[f0:f0 + bf].contiguous(), fill=-2.0, force_conservation=False).cpu().numpy()
+                                          for f0 in range(0, nl, bf)])
+                got = out[p * nl:(p + 1) * nl].cpu().numpy()
+                ok = ok and bool(np.array_equal(got.view(np.uint64), ref.view(np.uint64)))
+        # several field batches: one SpMM launch, one grouped exchange (the transport is called once per result here)
+        from icebin_amd.distributed import apply_many_sharded
+        w, nl, nb = rm.matrix("AvI"), 4, 3
+        ld = (w.nrow_d + 63) // 64 * 64
+        big = torch.full((nb, world * nl, ld), -9.0, dtype=torch.float64, device="cuda")
+        state["out"], state["calls"] = big.view(-1), 0
+        x_all = [syn.fields(world * nl, w.ncol_d, seed=31 + k) for k in range(nb)]
+        xs = [torch.from_numpy(xa[rank * nl:(rank + 1) * nl].copy()).cuda() for xa in x_all]
+        outs = apply_many_sharded(w, comm, xs, [big[k][:, : w.nrow_d] for k in range(nb)], fill=-2.0)
+        comm.wait()
+        torch.cuda.synchronize()
+        ncalls.append(state["calls"])
+        for k in range(nb):
+            for p in range(world):
+                xp = torch.from_numpy(x_all[k][p * nl:(p + 1) * nl].copy()).cuda()
+                ref = w.apply_device(xp, fill=-2.0, force_conservation=False).cpu().numpy()
+                ok = ok and bool(np.array_equal(outs[k][p * nl:(p + 1) * nl].cpu().numpy().view(np.uint64), ref.view(np.uint64)))
+        q.put((rank, ok, ncalls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_apply_two_ranks_over_a_custom_transport():
+    """ibh_weighted_apply_sharded_device with world 2: two processes share the box's GPU (RCCL refuses two ranks on one
+    device), the exchange goes through ibh_comm_create_custom -- a gloo all-gather staged through the host -- so the library's
+    own choreography runs with a peer: the local SpMM straight into this rank's rows of the gathered array, the exchange per
+    field block with the right offsets / counts / strides, ordering between SpMM and exchange, ibh_comm_wait."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert all(ok for _, ok, _ in got), got
+    # one exchange per field block: 6 fields in one, 6 in blocks of 4, 5 in blocks of 2, 8 in one
+    assert got[0][2] == [1, 2, 3, 1, 3] and got[1][2] == [1, 2, 3, 1, 3], got
