@@ -229,8 +229,11 @@ int ibh_weighted_apply_sharded_device(const ibh_weighted *w, ibh_comm *c, const 
         // of megabytes (I-row matrices) a few fields at a time so that the exchange of block b overlaps the SpMM of block b+1
         int bf = block_fields;
         if (bf <= 0) {
+            // (the I-row kernel works on 8-16 fields per thread: blocks of fewer than 8 fields cost it its efficiency -- 64 one-field
+            // launches of the 1 km IvA take 1.13 ms against 0.20 ms for one 64-field launch)
             const double plane_mb = 8.0 * (double)ldb / 1048576.0;
-            bf = plane_mb * nvar_local <= 4.0 ? nvar_local : std::max(1, std::min(nvar_local, (int)(16.0 / std::max(plane_mb, 1e-9))));
+            bf = (c->world == 1 || plane_mb * nvar_local <= 4.0) ? nvar_local
+                 : std::max(8, std::min(nvar_local, 8 * (int)(128.0 / std::max(8.0 * plane_mb, 1e-9))));
         }
         bf = std::min(bf, (int)nvar_local);
         double *mine = dB_all + (int64_t)c->rank * nvar_local * ldb;

@@ -302,8 +302,8 @@ int ibh_comm_info(const ibh_comm *c, int *world, int *rank);
  * shape on every rank) receives rank r's results in rows [r*nvar_local, (r+1)*nvar_local).  The local SpMM is enqueued on
  * `stream` and writes straight into this rank's rows; the exchange -- direct peer-to-peer sends (xGMI is a full mesh:
  * seven concurrent transfers use all links) -- runs on a stream the communicator owns, `block_fields` fields at a time
- * (0: chosen by size -- one exchange for KB-sized results, blocks of ~16 MB for the GB-sized results of the I-row
- * matrices) so that it overlaps the SpMM of the following block and of the following apply.  dB_all is complete once
+ * (0: chosen by size -- one exchange for KB-sized results, blocks of >= 8 fields and ~128 MB for the GB-sized results of
+ * the I-row matrices) so that it overlaps the SpMM of the following block and of the following apply.  dB_all is complete once
  * ibh_comm_wait(c, s) has made stream s wait for the exchanges enqueued so far.  Same results as ibh_weighted_apply_device
  * on each rank's fields (bitwise), conservative matrices only (no force_conservation). */
 int ibh_weighted_apply_sharded_device(const ibh_weighted *w, ibh_comm *c, const double *dA_local, int32_t nvar_local,
