@@ -1242,6 +1242,219 @@ __global__ __launch_bounds__(SMD_WAVES * 64) void k_smooth_direct(SmoothView v, 
     if (64 + lane < K) { ocol[ob + 64 + lane] = c1; oval[ob + 64 + lane] = a1; }
 }
 
+// ---- smoothI * M by spatial tiles (round 3): grids too large for one wave per row ---------------------------------------
+// The direct kernel above lets every row walk its ~3 600 candidates alone (three passes, five gathers per candidate: 13 ms at
+// 5 km); the triplet pipeline materialises ~10^8 neighbour pairs and sorts them twice (12 ms).  But the rows of one spatial bin
+// share their candidates -- the members of the 3 x 3 bins around it.  So: ONE WAVE per 64 rows of a bin; the candidates are
+// staged 64 at a time in LDS (compact records in bin order: position, elevation, area, and the candidate's row of M already
+// translated to slots of the bin's column table) and every lane runs its own row against the staged candidate, which is
+// wave-uniform: broadcast LDS reads, no gathers in the inner loop.  One pass sums the denominator and adds w_ij * M[j, c] into an
+// LDS table acc[slot][lane] with ds_add_f64 (no return: nothing waits), noting the slot in a 128-bit presence mask per lane --
+// row i holds column c iff a neighbour within two sigmas does, exactly the reference's structure; the sums are divided by the
+// denominator at the end.  The bin's column table (the distinct columns of all members of its 3 x 3 neighbourhood, ascending) comes from a
+// small pre-kernel; a compaction kernel turns (presence, table) into CSR rows.  Sums run in candidate order (bin by bin,
+// member by member), fixed: reproducible; entries agree with the oracle's ascending-j order to rounding (the test's 1e-12).
+// More than SMT_KMAX columns around a bin, or a member row of M with more than SMT_ROWMAX entries: the triplet pipeline serves
+// the build.
+constexpr int SMT_KMAX = 128, SMT_ROWMAX = 8, SMT_HASH = 1024;
+struct SmtCand { double x, y, z, area; };
+// compact records in member (bin) order: position / elevation / area, and the member's row of M entry-major
+// (mcol[e * nmem + q], mval[...]): the tile kernel stages them with coalesced, independent loads
+__global__ void k_smt_pack(SmoothView v, const int32_t *__restrict__ members, int nmem, const int32_t *__restrict__ rowptr,
+                           const int32_t *__restrict__ colind, const double *__restrict__ val, SmtCand *__restrict__ cand,
+                           unsigned char *__restrict__ mne, int32_t *__restrict__ mcol, double *__restrict__ mval) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nmem) return;
+    const int d = members[q];
+    double c[3];
+    (void)smooth_tuple(v, d, c);
+    cand[q] = SmtCand{c[0], c[1], c[2], v.area[d]};
+    const int e0 = rowptr[d], ne = min(rowptr[d + 1] - e0, SMT_ROWMAX);
+    mne[q] = (unsigned char)ne;
+    for (int e = 0; e < SMT_ROWMAX; ++e) {
+        mcol[(size_t)e * nmem + q] = e < ne ? colind[e0 + e] : 0;
+        mval[(size_t)e * nmem + q] = e < ne ? val[e0 + e] : 0.0;
+    }
+}
+// per bin: the distinct columns of the members of its 3 x 3 neighbourhood, ascending -> bincols[b * SMT_KMAX ..], binK[b];
+// waves the bin needs (64 rows each) -> binwaves[b]
+__global__ __launch_bounds__(256) void k_smt_bincols(SmoothView v, const uint32_t *__restrict__ binstart, const int32_t *__restrict__ members,
+                                                     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                     int32_t *__restrict__ bincols, int32_t *__restrict__ binK, uint32_t *__restrict__ binwaves,
+                                                     uint32_t *__restrict__ flags) {
+    __shared__ int s_hash[SMT_HASH];
+    __shared__ int s_n;
+    const int b = blockIdx.x, bx = b % v.nbx, by = b / v.nbx;
+    const uint32_t mine = binstart[b + 1] - binstart[b];
+    if (threadIdx.x == 0) { binwaves[b] = (mine + 63) / 64; s_n = 0; }
+    if (mine == 0) { if (threadIdx.x == 0) binK[b] = 0; return; }
+    for (int q = threadIdx.x; q < SMT_HASH; q += blockDim.x) s_hash[q] = -1;
+    __syncthreads();
+    const int x0 = max(bx - 1, 0), x1 = min(bx + 1, v.nbx - 1), y0 = max(by - 1, 0), y1 = min(by + 1, v.nby - 1);
+    for (int yy = y0; yy <= y1; ++yy) {
+        const uint32_t qb = binstart[yy * v.nbx + x0], qe = binstart[yy * v.nbx + x1 + 1];
+        for (uint32_t q = qb + threadIdx.x; q < qe; q += blockDim.x) {
+            const int j = members[q];
+            if (rowptr[j + 1] - rowptr[j] > SMT_ROWMAX) atomicOr(flags, 2u);
+            for (int e = rowptr[j]; e < rowptr[j + 1]; ++e) {
+                const int c = colind[e];
+                unsigned h = ((unsigned)c * 2654435761u) >> 22;
+                for (int probe = 0; probe < SMT_HASH; ++probe) {
+                    const int old = atomicCAS(&s_hash[h], -1, c);
+                    if (old == -1) { atomicAdd(&s_n, 1); break; }
+                    if (old == c) break;
+                    h = (h + 1) & (SMT_HASH - 1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int K = s_n;
+    if (threadIdx.x == 0) binK[b] = K;
+    if (K > SMT_KMAX) { if (threadIdx.x == 0) atomicOr(flags, 1u); return; }
+    for (int q = threadIdx.x; q < SMT_HASH; q += blockDim.x) {
+        const int k = s_hash[q];
+        if (k < 0) continue;
+        int rank = 0;
+        for (int t = 0; t < SMT_HASH; ++t) { const int o = s_hash[t]; rank += (o >= 0 && o < k) ? 1 : 0; }
+        bincols[(size_t)b * SMT_KMAX + rank] = k;
+    }
+}
+// wavebin[w] = the bin of wave w (wstart: exclusive scan of binwaves)
+__global__ void k_smt_wavebin(const uint32_t *__restrict__ wstart, const uint32_t *__restrict__ binwaves, int nbins, int32_t *__restrict__ wavebin) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbins) return;
+    for (uint32_t k = 0; k < binwaves[b]; ++k) wavebin[wstart[b] + k] = b;
+}
+__global__ __launch_bounds__(64) void k_smt_tile(SmoothView v, const uint32_t *__restrict__ binstart, const int32_t *__restrict__ members,
+                                                 const SmtCand *__restrict__ cand, const unsigned char *__restrict__ mne,
+                                                 const int32_t *__restrict__ mcol, const double *__restrict__ mval, int nmem,
+                                                 const int32_t *__restrict__ bincols, const int32_t *__restrict__ binK,
+                                                 const uint32_t *__restrict__ wstart, const int32_t *__restrict__ wavebin, int kstride,
+                                                 double *__restrict__ scratch, unsigned long long *__restrict__ pres, uint32_t *__restrict__ rowlen) {
+    extern __shared__ double smt_lds[];
+    double *acc = smt_lds;                                       // [K][64]
+    SmtCand *s_c = reinterpret_cast<SmtCand *>(smt_lds + (size_t)kstride * 64);      // [64]
+    double *s_val = reinterpret_cast<double *>(s_c + 64);        // [64][SMT_ROWMAX]
+    int *s_cols = reinterpret_cast<int *>(s_val + 64 * SMT_ROWMAX);                  // [SMT_KMAX]
+    unsigned char *s_slot = reinterpret_cast<unsigned char *>(s_cols + SMT_KMAX);    // [64][SMT_ROWMAX]
+    unsigned char *s_ne = s_slot + 64 * SMT_ROWMAX;             // [64]
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const int b = wavebin[w], bx = b % v.nbx, by = b / v.nbx;
+    const int K = binK[b];
+    const uint32_t q0 = binstart[b] + (uint32_t)(w - (int)wstart[b]) * 64u, qend = binstart[b + 1];
+    const bool live = q0 + lane < qend;
+    const SmtCand me = cand[live ? q0 + lane : qend - 1];
+    for (int k = lane; k < K; k += 64) s_cols[k] = bincols[(size_t)b * SMT_KMAX + k];
+    for (int k = 0; k < K; ++k) acc[k * 64 + lane] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int x0 = max(bx - 1, 0), x1 = min(bx + 1, v.nbx - 1), y0 = max(by - 1, 0), y1 = min(by + 1, v.nby - 1);
+    // weight of the staged candidate for this lane's row, < 0: not a neighbour (smoother.cpp:29-36).  The reference divides by
+    // the sigmas; three f64 divisions per pair are most of the arithmetic here, so the distance is formed with reciprocals and
+    // only a pair within 1e-9 of the cut (nds == 4: cells exactly two sigmas apart on a regular grid) repeats the reference's
+    // divisions to decide on which side it falls -- the structure stays exactly the reference's, the weights differ from the
+    // divided form in the last bit at most.
+    const double rx = 1.0 / v.sx, ry = 1.0 / v.sy, rz = 1.0 / v.sz;
+    auto weight = [&](const SmtCand &c) {
+        const double d0 = (c.x - me.x) * rx, d1 = (c.y - me.y) * ry, d2 = (c.z - me.z) * rz;
+        double nds = 0;
+        nds = nds + d0 * d0; nds = nds + d1 * d1; nds = nds + d2 * d2;
+        bool in = nds < 4.0;
+        if (fabs(nds - 4.0) < 1e-9) {
+            const double e0 = (c.x - me.x) / v.sx, e1 = (c.y - me.y) / v.sy, e2 = (c.z - me.z) / v.sz;
+            double ex = 0;
+            ex = ex + e0 * e0; ex = ex + e1 * e1; ex = ex + e2 * e2;
+            in = ex < 4.0;
+        }
+        return in ? exp(-.5 * nds) * c.area : -1.0;
+    };
+    // ONE pass: the denominator and the unnormalised sums together (the reference multiplies every term by factor = 1 / denom
+    // first, smoother.cpp:62-64; factoring it out of the sum changes the rounding, not the value: the test's 1e-12)
+    double denom = 0.0;
+    unsigned long long p0 = 0ull, p1 = 0ull;
+    for (int yy = y0; yy <= y1; ++yy) {
+        const uint32_t qb = binstart[yy * v.nbx + x0], qe = binstart[yy * v.nbx + x1 + 1];
+        // the records of chunk c+1 are loaded (coalesced, independent: one round trip) while chunk c is consumed
+        auto fetch = [&](uint32_t qq, SmtCand &fc, int &fne, int &c0, int &c1, double &a0, double &a1) {
+            const uint32_t q = min(qq + (uint32_t)lane, qe - 1);
+            fc = cand[q]; fne = mne[q]; c0 = mcol[q]; c1 = mcol[(size_t)nmem + q]; a0 = mval[q]; a1 = mval[(size_t)nmem + q];
+        };
+        SmtCand fc; int fne, fc0, fc1; double fa0, fa1;
+        if (qb < qe) fetch(qb, fc, fne, fc0, fc1, fa0, fa1);
+        for (uint32_t qq = qb; qq < qe; qq += 64) {
+            const int nst = (int)min(64u, qe - qq);
+            __builtin_amdgcn_wave_barrier();                     // the previous chunk has been consumed
+            auto slot_of = [&](int c) {                          // the column is in the bin's table by construction
+                int lo = 0, hi = K - 1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cols[mid] < c) lo = mid + 1; else hi = mid; }
+                return lo;
+            };
+            if (lane < nst) {
+                s_c[lane] = fc;
+                s_ne[lane] = (unsigned char)fne;
+                if (fne > 0) { s_slot[lane * SMT_ROWMAX] = (unsigned char)slot_of(fc0); s_val[lane * SMT_ROWMAX] = fa0; }
+                if (fne > 1) { s_slot[lane * SMT_ROWMAX + 1] = (unsigned char)slot_of(fc1); s_val[lane * SMT_ROWMAX + 1] = fa1; }
+                for (int e = 2; e < fne; ++e) {                  // (an ice cell under several GCM cells: rare)
+                    s_slot[lane * SMT_ROWMAX + e] = (unsigned char)slot_of(mcol[(size_t)e * nmem + qq + lane]);
+                    s_val[lane * SMT_ROWMAX + e] = mval[(size_t)e * nmem + qq + lane];
+                }
+            }
+            if (qq + 64 < qe) fetch(qq + 64, fc, fne, fc0, fc1, fa0, fa1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (int t = 0; t < nst; ++t) {
+                const double wgt = weight(s_c[t]);
+                const bool hit = live && wgt >= 0.0;
+                if (hit) denom += wgt;
+                const int ne = s_ne[t];
+                for (int e = 0; e < ne; ++e) {                   // (wave-uniform: every lane looks at the same candidate)
+                    const int k = s_slot[t * SMT_ROWMAX + e];
+                    if (hit) {
+                        __hip_atomic_fetch_add(acc + k * 64 + lane, wgt * s_val[t * SMT_ROWMAX + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (k < 64) p0 |= 1ull << k; else p1 |= 1ull << (k - 64);
+                    }
+                }
+            }
+        }
+    }
+    const double factor = live ? 1.0 / denom : 0.0;              // smoother.cpp:62
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < K; ++k) scratch[((size_t)w * kstride + k) * 64 + lane] = factor * acc[k * 64 + lane];
+    if (live) {
+        pres[2 * (size_t)(q0 + lane)] = p0; pres[2 * (size_t)(q0 + lane) + 1] = p1;
+        rowlen[members[q0 + lane]] = (uint32_t)(__popcll(p0) + __popcll(p1));
+    }
+}
+__global__ void k_smt_emit(const uint32_t *__restrict__ binstart, const int32_t *__restrict__ members, int nmem, const uint32_t *__restrict__ wstart,
+                           const int32_t *__restrict__ memberbin, const int32_t *__restrict__ bincols, int kstride, const double *__restrict__ scratch,
+                           const unsigned long long *__restrict__ pres, const int32_t *__restrict__ orowptr, int32_t *__restrict__ ocol,
+                           double *__restrict__ oval) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nmem) return;
+    const int b = memberbin[q];
+    const uint32_t rel = (uint32_t)q - binstart[b];
+    const size_t w = wstart[b] + rel / 64;
+    const int lane = (int)(rel & 63u);
+    int o = orowptr[members[q]];
+    for (int half = 0; half < 2; ++half) {
+        unsigned long long m = pres[2 * (size_t)q + half];
+        while (m) {
+            const int k = __builtin_ctzll(m) + 64 * half;
+            m &= m - 1;
+            ocol[o] = bincols[(size_t)b * SMT_KMAX + k];
+            oval[o] = scratch[(w * kstride + k) * 64 + lane];
+            ++o;
+        }
+    }
+}
+// bin of every member position (for the compaction kernel)
+__global__ void k_smt_memberbin(const uint32_t *__restrict__ binstart, int nbins, int32_t *__restrict__ memberbin) {
+    const int b = blockIdx.x;
+    for (uint32_t q = binstart[b] + threadIdx.x; q < binstart[b + 1]; q += blockDim.x) memberbin[q] = b;
+}
+
 static void smooth_matrix(ibh_weighted *w, const ibh_regrid_matrices *rm, const int64_t *row_s, const double sigma[3],
                           hipStream_t st) {
     const ibh_regridder *g = rm->rg;
@@ -1273,7 +1486,77 @@ static void smooth_matrix(ibh_weighted *w, const ibh_regrid_matrices *rm, const 
     // but slower at 5 km, 13 against 12 ms: three passes of ~3600 candidate evaluations per row, each five gathers; the
     // direct form is therefore taken for small problems only.  `smooth_direct`: 1 always, 0 never, -1 by size.)
     const int direct = get_tuning("smooth_direct", -1);
-    if (direct > 0 || (direct < 0 && n <= get_tuning("smooth_direct_max_rows", 16384))) {
+    const bool take_direct = direct > 0 || (direct < 0 && n <= get_tuning("smooth_direct_max_rows", 16384));
+    const int tile = get_tuning("smooth_tile", -1);
+    if (tile > 0 || (tile < 0 && !take_direct)) {
+        // tiles (k_smt_*): column tables per bin -> one wave per 64 rows of a bin -> compaction; two read-backs
+        const int nb = (int)nbins;
+        uint32_t h4[4];
+        IBH_HIP(hipMemsetAsync(d_cnt, 0, 3 * sizeof(uint32_t), st));
+        int32_t *bincols = A.get<int32_t>(nbins * SMT_KMAX), *binK = A.get<int32_t>(nbins);
+        uint32_t *binwaves = A.get<uint32_t>(nbins + 1), *wstart = A.get<uint32_t>(nbins + 1);
+        // members of all bins = the unmasked rows: binstart[nbins]
+        hipLaunchKernelGGL(k_smt_bincols, dim3(nb), dim3(256), 0, st, v, binstart, members, w->rowptr.p, w->colind.p, bincols, binK, binwaves, d_cnt + 1);
+        exclusive_scan_u32(binwaves, wstart, nbins, d_cnt, st);
+        IBH_HIP(hipMemcpyAsync(d_cnt + 2, binstart + nbins, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        readback_sync(h4, d_cnt, sizeof(h4), st);
+        if ((int)h4[3] != big) {
+            int64_t sc = 0;
+            IBH_HIP(hipMemcpy(&sc, row_s + (int)h4[3], sizeof(int64_t), hipMemcpyDeviceToHost));
+            fail(IBH_EINVAL, "Area of cell %ld must be non-zero", (long)sc);
+        }
+        if (h4[1] == 0) {
+            const int nwaves = (int)h4[0], nmem = (int)h4[2];
+            std::vector<int32_t> hK(nbins);
+            IBH_HIP(hipMemcpy(hK.data(), binK, sizeof(int32_t) * nbins, hipMemcpyDeviceToHost));
+            int kmax = 1;
+            for (size_t q = 0; q < nbins; ++q) kmax = std::max(kmax, hK[q]);
+            uint32_t *rowlen = A.get<uint32_t>((size_t)n + 1);
+            IBH_HIP(hipMemsetAsync(rowlen, 0, sizeof(uint32_t) * ((size_t)n + 1), st));
+            SmtCand *cand = A.get<SmtCand>((size_t)std::max(nmem, 1));
+            int32_t *wavebin = A.get<int32_t>((size_t)std::max(nwaves, 1)), *memberbin = A.get<int32_t>((size_t)std::max(nmem, 1));
+            double *scratch = A.get<double>((size_t)std::max(nwaves, 1) * kmax * 64);
+            unsigned long long *pres = A.get<unsigned long long>(2 * (size_t)std::max(nmem, 1));
+            unsigned char *mne = A.get<unsigned char>((size_t)std::max(nmem, 1));
+            int32_t *mcol = A.get<int32_t>((size_t)std::max(nmem, 1) * SMT_ROWMAX);
+            double *mval = A.get<double>((size_t)std::max(nmem, 1) * SMT_ROWMAX);
+            DevBuf<int32_t> nrowptr((size_t)n + 1);
+            if (nmem) {
+                hipLaunchKernelGGL(k_smt_pack, dim3(ceil_div(nmem, T)), dim3(T), 0, st, v, members, nmem, w->rowptr.p, w->colind.p, w->val.p, cand, mne, mcol, mval);
+                hipLaunchKernelGGL(k_smt_wavebin, dim3(ceil_div(nb, T)), dim3(T), 0, st, wstart, binwaves, nb, wavebin);
+                hipLaunchKernelGGL(k_smt_memberbin, dim3(nb), dim3(64), 0, st, binstart, nb, memberbin);
+                const size_t lds = (size_t)kmax * 64 * 8 + 64 * sizeof(SmtCand) + 64 * SMT_ROWMAX * 8 + SMT_KMAX * 4 + 64 * SMT_ROWMAX + 64;
+                static std::mutex mu;
+                static bool raised[64] = {};
+                if (lds > 64 * 1024) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!raised[w->device & 63]) {
+                        IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_smt_tile), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        raised[w->device & 63] = true;
+                    }
+                }
+                hipLaunchKernelGGL(k_smt_tile, dim3(nwaves), dim3(64), lds, st, v, binstart, members, cand, mne, mcol, mval, nmem, bincols, binK,
+                                   wstart, wavebin, kmax, scratch, pres, rowlen);
+            }
+            exclusive_scan_u32(rowlen, reinterpret_cast<uint32_t *>(nrowptr.p), (size_t)n, d_cnt, st);
+            readback_sync(h4, d_cnt, sizeof(h4), st);
+            const uint32_t nnz2 = h4[0];
+            IBH_CHECK(nnz2 < (1u << 31), "smoothed matrix too large (%u entries)", nnz2);
+            IBH_HIP(hipMemcpyAsync(nrowptr.p + n, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            DevBuf<int32_t> ncol((size_t)nnz2);
+            DevBuf<double> nval((size_t)nnz2);
+            if (nmem) hipLaunchKernelGGL(k_smt_emit, dim3(ceil_div(nmem, T)), dim3(T), 0, st, binstart, members, nmem, wstart, memberbin, bincols, kmax, scratch,
+                                         pres, nrowptr.p, ncol.p, nval.p);
+            IBH_HIP(hipGetLastError());
+            IBH_HIP(hipStreamSynchronize(st));
+            w->rowptr = std::move(nrowptr); w->colind = std::move(ncol); w->val = std::move(nval);
+            w->nnz = nnz2;
+            w->conservative = 0;            // conservative = !smooth, RegridMatrices_Dynamic.cpp:167
+            return;
+        }
+        // more than SMT_KMAX columns around a bin, or a member row longer than SMT_ROWMAX: the pipelines below serve the build
+    }
+    if (take_direct) {
         // direct rows (k_smooth_direct): count -> scan -> emit; one read-back (error word, overflow flag, nnz)
         uint32_t *rowlen = A.get<uint32_t>((size_t)n + 1);
         IBH_HIP(hipMemsetAsync(d_cnt, 0, 3 * sizeof(uint32_t), st));

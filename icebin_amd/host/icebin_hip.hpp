@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/icebin_hip.h"
+#include "ncio.hpp"
 
 namespace icebin {
 
@@ -90,6 +91,26 @@ public:
         return d;
     }
     ibh_sparse_set *handle() const { return h_; }
+    /** SparseSet::ncio (matrix_formats.rst:23-27): `int64 <vname>(<vname>.dense_extent)` with attribute `sparse_extent`.
+        Reading replaces the contents of this set (it must not be in use by a matrix). */
+    void ncio(NcIO &ncio, std::string const &vname) {
+        if (ncio.reading()) {
+            nc::Var const &v = ncio.file.var(vname);
+            std::vector<int64_t> t = v.data.as<int64_t>();
+            ibh_sparse_set *h = nullptr;
+            check(ibh_sparse_set_from_array(v.att("sparse_extent").at<int64_t>(0), t.data(), (int32_t)t.size(), &h));
+            if (h_) ibh_sparse_set_destroy(h_);
+            h_ = h; cache_.clear();
+        } else {
+            if (ncio.file.has_var(vname)) return;            // dims shared by several matrices are written once (IceCoupler.cpp:479-487)
+            std::vector<long> const &t = to_sparse_all();
+            std::vector<int64_t> t64(t.begin(), t.end());
+            const std::string d = ncio.file.add_dim(vname + ".dense_extent", (int64_t)t64.size());
+            const int64_t ext = sparse_extent();
+            ncio.file.add_var(vname, {d}, nc::Array::of(t64), {{"sparse_extent", nc::Array::of(&ext, 1)}});
+            ncio.touch();
+        }
+    }
 private:
     mutable std::vector<long> cache_;
 };
@@ -135,8 +156,13 @@ class Weighted {
     ibh_weighted *h_;
     mutable std::vector<double> wM_, Mw_;
     mutable bool have_wM_ = false, have_Mw_ = false;
+    bool file_dims_ = false;                       // loaded by ncio(): the dims are those of the file (the handle's are identities)
+    std::array<std::vector<long>, 2> file_dim_;
+    std::array<long, 2> file_extent_ = {{0, 0}};
 public:
-    bool conservative, scaled;
+    bool conservative = true, scaled = true;
+    /** an empty matrix, to be filled by ncio() from a file */
+    Weighted() : h_(nullptr) {}
     explicit Weighted(ibh_weighted *h) : h_(h) {
         int c, s;
         check(ibh_weighted_flags(h, &c, &s));
@@ -152,15 +178,83 @@ public:
     long nnz() const { int64_t n; check(ibh_weighted_shape(h_, nullptr, nullptr, &n)); return (long)n; }
     /** Sparse shape (dims[k]->sparse_extent()). */
     std::array<long, 2> shape() const {
+        if (file_dims_) return {{file_extent_[0], file_extent_[1]}};
         int64_t a, b;
         check(ibh_weighted_dim(h_, 0, &a, nullptr)); check(ibh_weighted_dim(h_, 1, &b, nullptr));
         return {{(long)a, (long)b}};
     }
     /** dims[k]->to_sparse(j) for all j */
     std::vector<long> dim_to_sparse(int k) const {
+        if (file_dims_) return file_dim_[(size_t)k];
         std::vector<int64_t> t((size_t)shape_d()[(size_t)k]);
         check(ibh_weighted_dim_to_sparse(h_, k, t.data()));
         return std::vector<long>(t.begin(), t.end());
+    }
+    /** Weighted_Eigen::ncio(ncio, vname, {dimB, dimA}) (modele/global_ec.cpp:571-605, IceCoupler.cpp:473-488): the "Eigen
+        format" of sphinx/source/matrix_formats.rst:9-63 -- the dims under their own names (written once when several matrices
+        share them), `<v>.info` {type "EIGEN", conservative, scaled, dim_names}, `<v>.M.info` {shape, conservative},
+        `<v>.M.indices(nnz, rank)`, `<v>.M.values`, `<v>.Mw`, `<v>.wM`.  With a reading NcIO the matrix is LOADED from the file
+        (to_eigen_M, eigen_types.cpp:9-34: ibh_weighted_from_coo) and keeps the file's dims. */
+    void ncio(NcIO &ncio, std::string const &vname, std::array<std::string, 2> const &dim_names = {{"", ""}}) {
+        if (ncio.reading()) {
+            nc::File const &f = ncio.file;
+            nc::Var const &info = f.var(vname + ".info");
+            if (nc::find(info.attrs, "type") && info.att("type").str() != "EIGEN")
+                throw Exception(IBH_ENOTIMPL, vname + ": matrix type '" + info.att("type").str() + "' is not the Eigen format");
+            std::vector<std::string> names = nc::split_names(info.att("dim_names").str());
+            if (names.size() != 2) throw Exception(IBH_EINVAL, vname + ".info:dim_names must name two dims");
+            for (int k = 0; k < 2; ++k) {
+                std::string n = names[(size_t)k];
+                if (n.compare(0, vname.size() + 1, vname + ".") == 0) n = n.substr(vname.size() + 1);
+                nc::Var const &d = f.var(n);
+                std::vector<int64_t> t = d.data.as<int64_t>();
+                file_dim_[(size_t)k].assign(t.begin(), t.end());
+                file_extent_[(size_t)k] = (long)d.att("sparse_extent").at<int64_t>(0);
+            }
+            std::vector<int32_t> ind = f.var(vname + ".M.indices").data.as<int32_t>();
+            std::vector<double> val = f.var(vname + ".M.values").data.as<double>();
+            std::vector<double> wMv = f.var(vname + ".wM").data.as<double>(), Mwv = f.var(vname + ".Mw").data.as<double>();
+            std::vector<int32_t> row(val.size()), col(val.size());
+            for (size_t e = 0; e < val.size(); ++e) { row[e] = ind[2 * e]; col[e] = ind[2 * e + 1]; }
+            const int cons = nc::find(info.attrs, "conservative") ? info.att("conservative").at<int>(0) : 1;
+            const int sc = nc::find(info.attrs, "scaled") ? info.att("scaled").at<int>(0) : 1;
+            ibh_weighted *h = nullptr;
+            check(ibh_weighted_from_coo((int32_t)wMv.size(), (int32_t)Mwv.size(), (int64_t)val.size(), row.data(), col.data(), val.data(),
+                                        wMv.data(), Mwv.data(), cons, sc, &h));
+            if (h_) ibh_weighted_destroy(h_);
+            h_ = h; conservative = cons != 0; scaled = sc != 0; file_dims_ = true; have_wM_ = have_Mw_ = false;
+            return;
+        }
+        if (dim_names[0].empty() || dim_names[1].empty()) throw Exception(IBH_EINVAL, "Weighted::ncio: writing needs the two dim names");
+        nc::File &f = ncio.file;
+        std::array<std::string, 2> dnames;
+        for (int k = 0; k < 2; ++k) {
+            std::vector<long> t = dim_to_sparse(k);
+            std::vector<int64_t> t64(t.begin(), t.end());
+            dnames[(size_t)k] = f.add_dim(dim_names[(size_t)k] + ".dense_extent", (int64_t)t64.size());
+            if (!f.has_var(dim_names[(size_t)k])) {
+                const int64_t ext = shape()[(size_t)k];
+                f.add_var(dim_names[(size_t)k], {dnames[(size_t)k]}, nc::Array::of(t64), {{"sparse_extent", nc::Array::of(&ext, 1)}});
+            }
+        }
+        std::vector<int> row, col; std::vector<double> val;
+        M_coo(row, col, val);
+        const int32_t zero32 = 0, cons = conservative ? 1 : 0, sc = scaled ? 1 : 0;
+        const int64_t zero64 = 0;
+        f.add_var(vname + ".info", {}, nc::Array::of(&zero32, 1),
+                  {{"type", nc::Array::str("EIGEN")}, {"conservative", nc::Array::of(&cons, 1)}, {"scaled", nc::Array::of(&sc, 1)},
+                   {"dim_names", nc::Array::str(vname + "." + dim_names[0] + "," + vname + "." + dim_names[1])}});
+        const int64_t shp[2] = {(int64_t)shape_d()[0], (int64_t)shape_d()[1]};
+        f.add_var(vname + ".M.info", {}, nc::Array::of(&zero64, 1),
+                  {{"shape", nc::Array::of(shp, 2)}, {"conservative", nc::Array::str(conservative ? "t" : "f")}});
+        const std::string dn = f.add_dim(vname + ".M.nnz", (int64_t)val.size()), dr = f.add_dim(vname + ".M.rank", 2);
+        std::vector<int32_t> ind(2 * val.size());
+        for (size_t e = 0; e < val.size(); ++e) { ind[2 * e] = row[e]; ind[2 * e + 1] = col[e]; }
+        f.add_var(vname + ".M.indices", {dn, dr}, nc::Array::of(ind));
+        f.add_var(vname + ".M.values", {dn}, nc::Array::of(val));
+        f.add_var(vname + ".Mw", {dnames[1]}, nc::Array::of(Mw()));
+        f.add_var(vname + ".wM", {dnames[0]}, nc::Array::of(wM()));
+        ncio.touch();
     }
     /** wM / Mw: host mirrors, downloaded once (the matrix is immutable after its build); wM(jj) as at
         IceCoupler.cpp:456. */
@@ -297,8 +391,12 @@ class IceRegridder {
     ibh_regridder *h_ = nullptr;
     std::string _name;
     long _nI = 0, _nX = 0;
+    // host copies of what ncio() writes (IceRegridder::ncio, IceRegridder.cpp:75-90); drop_host_copy() releases them
+    ExchangeGrid aexgrid_;
+    std::vector<double> gridA_proj_area_, gridI_centroid_xy_;
 public:
     int interp_style = InterpStyle::Z_INTERP;
+    void drop_host_copy() { aexgrid_ = ExchangeGrid(); gridA_proj_area_.clear(); gridI_centroid_xy_.clear(); gridA_proj_area_.shrink_to_fit(); }
     ~IceRegridder() { if (h_) ibh_regridder_destroy(h_); }
     std::string const &name() const { return _name; }
     size_t nI() const { return (size_t)_nI; }
@@ -418,10 +516,95 @@ public:
         d.I_centroid_xy = gridI_centroid_xy.empty() ? nullptr : gridI_centroid_xy.data();
         check(ibh_regridder_create(&d, &sheet->h_));
         sheet->_name = name; sheet->_nI = nI; sheet->_nX = (long)d.nX; sheet->interp_style = interp_style;
+        sheet->aexgrid_ = aexgrid; sheet->gridA_proj_area_ = proj; sheet->gridI_centroid_xy_ = gridI_centroid_xy;
         size_t ix = sheets_.size();
         sheets_index_[name] = ix;
         sheets_.push_back(std::move(sheet));
         return ix;
+    }
+    /** GCMRegridder_Standard::ncio(ncio, vname) (GCMRegridder.cpp:104-150, AbbrGrid.cpp:23-29,167-194, IceRegridder.cpp:75-90): the
+        IceBin input file -- `<v>.info` {correctA, sheets}, `<v>.agridA.*`, `<v>.indexingHC`, `<v>.hcdefs(<v>.nhc)`, and per sheet
+        `<v>.<sheet>.info` {name, interp_style}, `.gridA_proj_area`, `.agridI.*`, `.aexgrid.indices / .overlaps`.  Reading builds
+        this (empty) regridder from the file, sheets included (their arrays go to HBM); grid specs / polygons are not part of
+        the regrid path and are neither written nor read. */
+    void ncio(NcIO &ncio, std::string const &vname = "m") {
+        static const std::map<std::string, int> interp = {{"Z_INTERP", 0}, {"ELEV_CLASS_INTERP", 1}};
+        if (ncio.reading()) {
+            nc::File const &f = ncio.file;
+            nc::Var const &info = f.var(vname + ".info");
+            AbbrGrid a;
+            nc::Var const &adim = f.var(vname + ".agridA.dim");
+            a.sparse_extent = (long)adim.att("sparse_extent").at<int64_t>(0);
+            a.dim_to_sparse = adim.data.as<long>();
+            a.native_area = f.var(vname + ".agridA.native_area").data.as<double>();
+            a.name = "gridA";
+            // indexingHC: dimension ids by descending stride (GCMRegridder.cpp:43): a file may carry either layout
+            nc::Var const &ix = f.var(vname + ".indexingHC");
+            std::vector<long> extent = ix.att("extent").as<long>(), order = ix.att("indices").as<long>();
+            std::array<long, 2> strides = {{0, 0}};
+            strides[(size_t)order[1]] = 1;
+            strides[(size_t)order[0]] = extent[(size_t)order[1]];
+            init(std::move(a), f.var(vname + ".hcdefs").data.as<double>(), strides, info.att("correctA").at<int>(0) != 0);
+            for (std::string const &name : nc::split_names(info.att("sheets").str())) {
+                const std::string v = vname + "." + name;
+                nc::Var const &sinfo = f.var(v + ".info");
+                const std::string style = sinfo.att("interp_style").type == nc::CHAR ? sinfo.att("interp_style").str() : std::string();
+                const int istyle = style.empty() ? sinfo.att("interp_style").at<int>(0) : interp.at(style);
+                nc::Var const &idim = f.var(v + ".agridI.dim");
+                const long nI = (long)idim.att("sparse_extent").at<int64_t>(0);
+                std::vector<long> i2s = idim.data.as<long>();
+                std::vector<double> cen_d = f.var(v + ".agridI.centroid_xy").data.as<double>(), cen;
+                bool any = false;
+                for (double c : cen_d) any = any || c != 0.0;
+                if (any) {                              // dense -> sparse ice index
+                    cen.assign((size_t)(2 * nI), 0.0);
+                    for (size_t k = 0; k < i2s.size(); ++k) { cen[2 * (size_t)i2s[k]] = cen_d[2 * k]; cen[2 * (size_t)i2s[k] + 1] = cen_d[2 * k + 1]; }
+                }
+                ExchangeGrid ex;
+                ex.indices = f.var(v + ".aexgrid.indices").data.as<int>();
+                ex.overlaps = f.var(v + ".aexgrid.overlaps").data.as<double>();
+                add_sheet(name, nI, ex, f.var(v + ".gridA_proj_area").data.as<double>(), istyle, cen);
+            }
+            return;
+        }
+        nc::File &f = ncio.file;
+        const int32_t zero = 0, ca = correctA ? 1 : 0;
+        std::vector<std::string> names;
+        for (auto const &sh : sheets_) names.push_back(sh->name());
+        f.add_var(vname + ".info", {}, nc::Array::of(&zero, 1), {{"correctA", nc::Array::of(&ca, 1)}, {"sheets", nc::Array::str(nc::join_names(names))}});
+        auto put_abbr = [&](std::string const &v, std::vector<long> const &to_sparse, long extent, std::vector<double> const &native,
+                            std::vector<double> const &centroid, std::string const &gname) {
+            f.add_var(v + ".info", {}, nc::Array::of(&zero, 1), {{"coordinates", nc::Array::str("XY")}, {"parameterization", nc::Array::str("L0")},
+                                                               {"name", nc::Array::str(gname)}, {"sproj", nc::Array::str("")}});
+            std::vector<int64_t> t64(to_sparse.begin(), to_sparse.end());
+            const std::string d = f.add_dim(v + ".dim.dense_extent", (int64_t)t64.size());
+            const int64_t ext = extent;
+            f.add_var(v + ".dim", {d}, nc::Array::of(t64), {{"sparse_extent", nc::Array::of(&ext, 1)}});
+            const std::string three = f.add_dim("three", 3), two = f.add_dim("two", 2);
+            f.add_var(v + ".ijk", {d, three}, nc::Array::of(std::vector<int32_t>(3 * t64.size(), 0)));
+            f.add_var(v + ".native_area", {d}, nc::Array::of(native));
+            f.add_var(v + ".centroid_xy", {d, two}, nc::Array::of(centroid.empty() ? std::vector<double>(2 * t64.size(), 0.0) : centroid));
+        };
+        put_abbr(vname + ".agridA", agridA_.dim_to_sparse, agridA_.sparse_extent, agridA_.native_area, {}, "gridA");
+        const int64_t base[2] = {0, 0}, extent[2] = {(int64_t)nA(), (int64_t)nhc()};
+        const int32_t order[2] = {hc_stride_HC_ >= hc_stride_A_ ? 1 : 0, hc_stride_HC_ >= hc_stride_A_ ? 0 : 1};
+        f.add_var(vname + ".indexingHC", {}, nc::Array::of(&zero, 1),
+                  {{"base", nc::Array::of(base, 2)}, {"extent", nc::Array::of(extent, 2)}, {"indices", nc::Array::of(order, 2)}});
+        f.add_var(vname + ".hcdefs", {f.add_dim(vname + ".nhc", (int64_t)_hcdefs.size())}, nc::Array::of(_hcdefs));
+        f.add_dim("agridA.ndata", (int64_t)agridA_.dim_to_sparse.size());
+        for (auto const &sh : sheets_) {
+            if (sh->aexgrid_.overlaps.empty() && sh->nX() != 0) throw Exception(IBH_EINVAL, "sheet '" + sh->name() + "': host copy was dropped, cannot be written");
+            const std::string v = vname + "." + sh->name();
+            f.add_var(v + ".info", {}, nc::Array::of(&zero, 1), {{"name", nc::Array::str(sh->name())},
+                      {"interp_style", nc::Array::str(sh->interp_style == InterpStyle::ELEV_CLASS_INTERP ? "ELEV_CLASS_INTERP" : "Z_INTERP")}});
+            f.add_var(v + ".gridA_proj_area", {"agridA.ndata"}, nc::Array::of(sh->gridA_proj_area_));
+            std::vector<long> iota((size_t)sh->nI());
+            for (size_t k = 0; k < iota.size(); ++k) iota[k] = (long)k;
+            put_abbr(v + ".agridI", iota, (long)sh->nI(), std::vector<double>(sh->nI(), 0.0), sh->gridI_centroid_xy_, "gridI");
+            f.add_var(v + ".aexgrid.indices", {f.add_dim(v + ".aexgrid.nindices", (int64_t)sh->aexgrid_.indices.size())}, nc::Array::of(sh->aexgrid_.indices));
+            f.add_var(v + ".aexgrid.overlaps", {f.add_dim(v + ".aexgrid.noverlaps", (int64_t)sh->aexgrid_.overlaps.size())}, nc::Array::of(sh->aexgrid_.overlaps));
+        }
+        ncio.touch();
     }
     /** ice_regridders().index.at(name) */
     size_t sheet_index(std::string const &name) const {

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../../icebin_amd/host/icebin_hip.hpp"
@@ -17,7 +18,7 @@ static const double NaN = std::nan("");
         if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } \
     } while (0)
 
-int main() {
+int main(int argc, char **argv) {
     // ---- a 12 x 10 ice grid (cell 1 x 1) under a 3 x 2 atmosphere block (cell 4.5 x 5.5), nA = 8 x 4
     const int nx = 12, ny = 10, im = 8, i0 = 2, j0 = 1;
     const double Wx = 4.5, Wy = 5.5;
@@ -155,6 +156,37 @@ int main() {
         for (double v : gen.overlaps) tot += v;
         for (double v : exgrid.overlaps) tot0 += v;
         REQUIRE(std::fabs(tot - tot0) < 1e-12 * tot0);
+    }
+
+    // on-disk formats from C++ (GCMRegridder.cpp:104-150, modele/global_ec.cpp:539-605): write the regridder and two matrices the
+    // way global_ec appends them, read everything back into fresh objects, rebuild and compare bitwise
+    {
+        const std::string fn = argc > 1 ? std::string(argv[1]) : std::string("/tmp/icebin_hip_host_api.nc");
+        { NcIO ncio(fn, 'w'); gcm.ncio(ncio, "m"); }
+        { NcIO ncio(fn, 'a'); AvI->ncio(ncio, "AvI", {{"dimA", "dimI"}}); }
+        { NcIO ncio(fn, 'a'); IvA->ncio(ncio, "IvA", {{"dimI", "dimA"}}); }      // shares dimA / dimI with AvI: written once
+        NcIO rd(fn, 'r');
+        GCMRegridder_Standard gcm2;
+        gcm2.ncio(rd, "m");
+        REQUIRE(gcm2.nA() == gcm.nA() && gcm2.nhc() == gcm.nhc() && gcm2.correctA == gcm.correctA && gcm2.nI(0) == gcm.nI(0));
+        std::unique_ptr<RegridMatrices_Dynamic> rm2(gcm2.regrid_matrices((int)gcm2.sheet_index("greenland"), elevmaskI, RegridParams(true, false, {{0., 0., 0.}})));
+        auto AvI2 = rm2->matrix("AvI");
+        std::vector<int> ra, ca, rb, cb; std::vector<double> va, vb;
+        AvI->M_coo(ra, ca, va); AvI2->M_coo(rb, cb, vb);
+        REQUIRE(ra == rb && ca == cb && va == vb && AvI2->wM() == AvI->wM() && AvI2->Mw() == AvI->Mw());
+        linear::Weighted L;
+        L.ncio(rd, "AvI");
+        L.M_coo(rb, cb, vb);
+        REQUIRE(ra == rb && ca == cb && va == vb && L.wM() == AvI->wM() && L.Mw() == AvI->Mw());
+        REQUIRE(L.shape() == AvI->shape() && L.dim_to_sparse(0) == AvI->dim_to_sparse(0) && L.dim_to_sparse(1) == AvI->dim_to_sparse(1));
+        REQUIRE(L.conservative == AvI->conservative && L.scaled == AvI->scaled);
+        REQUIRE(L.apply(ramp) == AvI->apply(ramp));
+        linear::Weighted L2;
+        L2.ncio(rd, "IvA");
+        REQUIRE(L2.shape() == IvA->shape() && L2.nnz() == IvA->nnz());
+        SparseSetT dA3;
+        dA3.ncio(rd, "dimA");
+        REQUIRE(dA3.dense_extent() == AvI->shape_d()[0] && dA3.to_sparse(0) == AvI->dim_to_sparse(0)[0]);
     }
 
     // errors surface as exceptions (error.hpp:28-32)

@@ -1085,16 +1085,19 @@ def test_smoothing_sigma_nonzero(name):
     # RegridMatrices_Dynamic.cpp:237-248 + smoother.cpp: M <- smoothI * M, conservative = false, and the
     # conservation correction of apply().  Structure is exact; entries agree to rounding (device exp()
     # and the neighbour order of the absent RTree are not bit-reproducible: parity unpinned at 1e-13).
-    # Both device forms are checked: the wave-per-row direct build (taken for small grids) and the triplet pipeline.
+    # All three device forms are checked: the wave-per-row direct build (small grids), the spatial tiles (larger grids) and the
+    # triplet pipeline (their fallback).
     from icebin_amd.linear import set_tuning
     g, em, mm, rg = setup("g20")
     sigma = (60e3, 60e3, 250.0)
-    for (scale, correctA), direct in (((True, True), 1), ((False, False), 0), ((True, True), 0)):
+    for (scale, correctA), direct, tile in (((True, True), 1, 0), ((False, False), 0, 0), ((True, True), 0, 0), ((True, True), 0, 1), ((False, True), 0, 1)):
         set_tuning("smooth_direct", direct)
+        set_tuning("smooth_tile", tile)           # 1: the spatial-tile form (taken by itself for grids beyond the direct form's size)
         try:
             w = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA, sigma=sigma).matrix(name)
         finally:
             set_tuning("smooth_direct", -1)
+            set_tuning("smooth_tile", -1)
         o = rg.matrix_d(name, em, scale=scale, correctA=correctA, sigma=sigma)
         plain = rg.matrix_d(name, em, scale=scale, correctA=correctA)
         assert not w.conservative and not o.conservative and w.scaled == scale

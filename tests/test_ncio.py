@@ -104,3 +104,47 @@ def test_hdf5_files_are_refused_clearly(tmp_path):
     open(p, "wb").write(b"garbage")
     with pytest.raises(ValueError, match="not a NetCDF classic"):
         ncio.Dataset.read(p)
+
+
+# ---- the C++ container (icebin_amd/host/ncio.hpp) against this one ---------------------------------------------------------
+def _ncio_exe():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe, src = os.path.join(root, "tests", "cpp", "test_ncio"), os.path.join(root, "tests", "cpp", "test_ncio.cpp")
+    hdr = os.path.join(root, "icebin_amd", "host", "ncio.hpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-o", exe, src])
+    return exe
+
+
+def test_cpp_container_is_read_by_python_and_vice_versa(tmp_path):
+    import subprocess
+    exe = _ncio_exe()
+    f1 = str(tmp_path / "from_cpp.nc")
+    assert subprocess.run([exe, "write", f1]).returncode == 0
+    ds = ncio.Dataset.read(f1)                                  # C++ wrote, Python reads
+    assert ds.attrs["title"] == "ncio.hpp round trip"
+    assert list(ds.dims.items()) == [("dimB.dense_extent", 4), ("BvA.M.nnz", 3), ("BvA.M.rank", 2), ("odd", 5)]
+    assert np.array_equal(ds.variables["dimB"].data, [5, 1 << 40, -3, 7]) and int(ds.variables["dimB"].sparse_extent) == 1234567890123
+    assert np.array_equal(ds.variables["BvA.M.indices"].data, [[0, 1], [2, 3], [4, 5]])
+    assert np.array_equal(ds.variables["BvA.M.values"].data, [1.5, -2.25e-300, 3.0e300])
+    assert ds.variables["m.info"].sheets == "greenland,antarctica" and ds.variables["odd.bytes"].data.tobytes() == b"abcde"
+    f2 = str(tmp_path / "from_python.nc")                       # Python writes the same content, C++ dumps both: identical dumps
+    ds.write(f2)
+    d1 = subprocess.run([exe, "dump", f1], capture_output=True, text=True)
+    d2 = subprocess.run([exe, "dump", f2], capture_output=True, text=True)
+    assert d1.returncode == 0 and d2.returncode == 0 and d1.stdout == d2.stdout and "wsum=9.0000000000000011e+300" in d1.stdout
+    # scipy's independent writer (CDF-1) through the C++ reader
+    from scipy.io import netcdf_file
+    f3 = str(tmp_path / "from_scipy.nc")
+    with netcdf_file(f3, "w") as nc:
+        nc.createDimension("n", 3)
+        v = nc.createVariable("x", "d", ("n",))
+        v[:] = [1.0, 2.0, 4.0]
+        v.units = "m"
+    d3 = subprocess.run([exe, "dump", f3], capture_output=True, text=True)
+    assert d3.returncode == 0 and "var x (n) type6[3] wsum=17" in d3.stdout and "att units char[1] 'm'" in d3.stdout
+    bad = str(tmp_path / "bad.nc")
+    open(bad, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    r = subprocess.run([exe, "dump", bad], capture_output=True, text=True)
+    assert r.returncode == 1 and "NetCDF-4/HDF5" in r.stdout
