@@ -1105,8 +1105,13 @@ static ShortrowPlan shortrow_plan(const ibh_weighted *w, int nvar, int nbatch = 
     ShortrowPlan p;
     p.one_entry = (double)w->nnz <= 1.5 * (double)w->nrow;
     p.big = w->nrow >= (1 << 19);
-    const int small_multi = nbatch >= 4 ? 32 : 16;
-    const int small_one = w->nrow >= 16384 ? 8 : 4;
+    // (2-3 entries, one launch of <= 32 fields: 4 fields per thread, field-major 8.2 us against 14.2 through the transposed copy)
+    const bool few_fields_once = nbatch < 4 && nvar <= 32;    // (32 fields: 13.7 against 16.0)
+    const int small_multi = nbatch >= 4 ? 32 : few_fields_once ? 4 : 16;
+    // (round 3, kernel durations by dispatch events instead of wall time: ONE launch of a one-entry matrix at 5 km is fastest
+    // field-major with 4 fields per thread -- 64 fields 13.2 us against 15.8 through the transposed copy, whose second
+    // launch costs more than its lines save; 16 fields 5.6 against 6.8; deep launches keep the transposed form: 7.0)
+    const int small_one = w->nrow >= 16384 ? (nbatch >= 4 ? 8 : nvar >= 64 ? 16 : 4) : 4;
     p.fper = get_tuning("shortrow_fper", p.big ? (p.one_entry ? 16 : 32) : (p.one_entry ? small_one : small_multi));
     if (p.fper < 1) p.fper = 1;
     p.g = get_tuning("shortrow_group", p.big ? (p.one_entry ? 8 : 4) : (p.fper >= 8 ? 8 : 4));
@@ -1116,7 +1121,7 @@ static ShortrowPlan shortrow_plan(const ibh_weighted *w, int nvar, int nbatch = 
     p.use_xt = get_tuning("shortrow_xt", -1);
     // (one-entry matrices: the extra launch costs more than it saves for tiny matrices -- EvA: 4.9 -> 8.9 us -- and for a
     // single launch of few fields -- 5 km IvA, 16 fields: 7.5 -> 9.3 us)
-    if (p.use_xt < 0) p.use_xt = (!p.one_entry || p.big || (w->nrow >= 16384 && (nbatch >= 4 || nvar >= 32))) ? 1 : 0;
+    if (p.use_xt < 0) p.use_xt = ((!p.one_entry && !(few_fields_once && !p.big)) || p.big || (w->nrow >= 16384 && nbatch >= 4)) ? 1 : 0;
     if (p.fper % p.g != 0 || (p.g & 1)) p.use_xt = 0;
     p.ldt = (nvar + 15) & ~15;
     return p;
@@ -1232,9 +1237,9 @@ static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &
 static void launch_one(const ibh_weighted *w, int kernel, const BatchPtrs &bp, int nbatch, int nvar, int64_t lda,
                        int64_t ldb, double fill, hipStream_t stream)
 {
-    // launch timing (ibh_set_launch_events): the single-kernel paths attach the events to their dispatch; the paths made of
-    // several launches (transposed input + I-row kernel, bands + combine) record them around the sequence
-    if ((kernel == 2 || kernel == 3) && g_ev_start && g_ev_stop) {
+    // launch timing (ibh_set_launch_events): the single-kernel paths attach the events to their dispatch, the I-row path
+    // to its first and last one (transposed input + row kernel); bands + combine records them around the sequence
+    if (kernel == 3 && g_ev_start && g_ev_stop) {
         hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
         g_ev_start = g_ev_stop = nullptr;
         IBH_HIP(hipEventRecord(ev0, stream));
@@ -1318,8 +1323,11 @@ static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &
             if (stream) IBH_HIP(hipStreamIsCapturing(stream, &cs));
             if (cs != hipStreamCaptureStatusNone) qmax = std::max(1, (int)(w->xt.granted / ((size_t)xt_stride * sizeof(double))));
         }
+        hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
+        g_ev_start = g_ev_stop = nullptr;
         for (int q0 = 0; q0 < nbatch; q0 += qmax) {
             const int nq = std::min(qmax, nbatch - q0);
+            hipEvent_t e_first = q0 == 0 ? ev0 : nullptr, e_last = q0 + qmax >= nbatch ? ev1 : nullptr;
             BatchPtrs bq{};
             bool misaligned = (ldb & 7) != 0;
             for (int q = 0; q < nq; ++q) {
@@ -1335,13 +1343,15 @@ static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &
             dim3 grid((unsigned)nblk, (unsigned)nq);
             long xld = (long)lda;
             if (p.use_xt) {
-                hipLaunchKernelGGL(transpose_fields_kernel, dim3((unsigned)ceil_div(w->ncol, 64), (unsigned)(p.ldt / 16), (unsigned)nq), dim3(256), 0, stream,
-                                   bq, (long)lda, nvar, w->ncol, w->xt.p, p.ldt, xt_stride);
+                hipExtLaunchKernelGGL(transpose_fields_kernel, dim3((unsigned)ceil_div(w->ncol, 64), (unsigned)(p.ldt / 16), (unsigned)nq), dim3(256), 0, stream,
+                                      e_first, nullptr, 0, bq, (long)lda, nvar, w->ncol, w->xt.p, p.ldt, xt_stride);
+                e_first = nullptr;
                 xld = p.ldt;
             }
 #define IBH_SR4(NT, GG, RA, XTT)                                                                                \
-    hipLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, RA, XTT>), grid, dim3(SR_THREADS), 0, stream, w->rowptr.p, w->colind.p, \
-                       w->val.p, bq, (const double *)w->xt.p, xt_stride, xld, (long)ldb, w->nrow, nvar, fper, w->wM.p, fill)
+    hipExtLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, RA, XTT>), grid, dim3(SR_THREADS), 0, stream, e_first, e_last, 0,    \
+                          w->rowptr.p, w->colind.p, w->val.p, bq, (const double *)w->xt.p, xt_stride, xld, (long)ldb,       \
+                          w->nrow, nvar, fper, w->wM.p, fill)
 #define IBH_SR(NT, GG)                                                                                          \
     do {                                                                                                        \
         if (realign) { if (p.use_xt) IBH_SR4(NT, GG, true, true); else IBH_SR4(NT, GG, true, false); }          \
