@@ -241,7 +241,7 @@ __device__ __forceinline__ uint32_t fa_pflag_of(const RgView &rg, const PlanView
 // ---- G-side numbering and entry counts: one workgroup per range -----------------------------------
 template <bool WITH_EP>
 __global__ __launch_bounds__(FA_T) void k_fa_count(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int g_is_row, int merge,
-                                                    uint32_t *__restrict__ err_x, uint32_t *__restrict__ flags) {
+                                                    uint32_t *__restrict__ err_x, uint32_t *__restrict__ flags, int eva_check) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     __shared__ uint32_t s_first[FA_NC], s_cn[FA_NC], s_co[FA_NC];
     stage_hc<WITH_EP>(rg, s_hc);
@@ -279,6 +279,9 @@ __global__ __launch_bounds__(FA_T) void k_fa_count(RgView rg, PlanView pl, MatSp
                 if (p.fresh) p.pflag[x] = (uint8_t)(p.key == KEY_I ? ((ifv[u] == (int32_t)x && c.unmasked) ? 1u : 0u) : fa_pflag_of<WITH_EP>(rg, pl, p, c, x));
                 if (WITH_EP && c.range_error) atomicMin(err_x, (uint32_t)x);
                 else {
+                    // EvA / AvE number the A side by "the range has entries": a cell of GvAp without an elevation-class entry
+                    // (an area so small that area * weight underflows) would be numbered without one -- general pipeline
+                    if (WITH_EP && eva_check && c.inAp && c.nep == 0) atomicOr(flags, (uint32_t)FA_ERR_MISSING);
                     long k0, k1;
                     const int n = list_entries(c, x, g.list, g.key, k0, k1);        // first-seen positions of the G keys: every cell counts
                     if (g.NC == 1) { if (n > 0) atomicMin(&s_first[0], (uint32_t)(2 * x)); }     // (one address: cheap; first hit wins quickly)
@@ -385,6 +388,7 @@ struct FaOut {
     double *val;                    // EMIT: CSR values; SUMS: scratch of the same size
     double *wM, *Mw;                // EMIT writes wM (rows = G side), SUMS writes Mw (cols = G side)
     int family, scale, correctA;
+    int g_rows;                     // SUMS only: the G side is the ROW side of the spec (EvA through the column-sum machinery)
 };
 template <bool WITH_EP, bool EMIT>
 __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, FaOut o,
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
     }
     __syncthreads();
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    const bool g_is_row = EMIT;
+    const bool g_is_row = EMIT || o.g_rows != 0;
     // FA_CPT cells per thread and pass: their loads are issued in three staged rounds (exchange cell -> mask and
     // first-seen position of its ice cell -> dense id) before anything is consumed, so a pass pays the dependent
     // round trips once instead of once per 256 cells; the ranking then walks the FA_CPT sub-chunks in x order.
@@ -751,11 +755,171 @@ __global__ void k_fa_init(uint32_t *cnt) {
     if (threadIdx.x < 8) cnt[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
 }
 
+// ---- EvA / AvE (compute_EvA, RegridMatrices_Dynamic.cpp:254-332) -----------------------------------------------
+// EpvAp = EpvG * diag(1 / rowsum(GvAp)) * GvAp is a product over the exchange cells: entry (e, a) is the sum over the
+// cells x of atmosphere cell a that touch class e, in ascending x (Eigen walks column a of GvAp, whose rows are the
+// exchange cells in first-seen = x order) -- i.e. per (range, class) exactly the sequential sum the column-sum pass of an
+// X-row matrix computes (k_fa_range<SUMS> with every exchange cell its own key: all entries "new", placed in x order).
+// So: k_fa_count numbers the classes, k_fa_range<SUMS> leaves T[e] = sum_x t(x, e) per dense class id, and one thread
+// per range writes the (at most nhc)-entry CSR piece of its atmosphere cell plus the row / column sums; weights and
+// scaling are the general pipeline's own kernels (k_weights, k_scale).  Both sets must be fresh; anything irregular
+// (a class listed only by cells that contribute nothing -- negative areas) goes back to the general pipeline.
+struct EvaOut {
+    int32_t *rowptr, *colind, *row;
+    double *val, *rs, *cs;
+    int64_t *atable;
+};
+__global__ __launch_bounds__(1024) void k_eva_ascan(const uint32_t *__restrict__ nent, int nAr, uint32_t *__restrict__ abase, uint32_t *__restrict__ tot) {
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry = 0;
+    for (int base = 0; base < nAr; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < nAr && nent[i] > 0) ? 1u : 0u;
+        uint32_t t;
+        const uint32_t ex = fa_block_excl_scan_1024(v, s_wave, t);
+        if (i < nAr) abase[i] = carry + ex;
+        carry += t;
+    }
+    if (threadIdx.x == 0) { abase[nAr] = carry; tot[0] = carry; }
+}
+__global__ void k_eva_hasa(const uint32_t *__restrict__ nent, int nAr, uint32_t *__restrict__ has) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nAr) has[i] = nent[i] > 0 ? 1u : 0u;
+}
+__global__ void k_eva_final(RgView rg, PlanView pl, FaG g, const uint32_t *__restrict__ abase, const double *__restrict__ S,
+                            int e_is_row, EvaOut o, uint32_t *__restrict__ flags) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= pl.nAr) return;
+    const uint32_t nE = g.gbase[pl.nAr];
+    if (r == pl.nAr - 1) o.rowptr[e_is_row ? nE : abase[pl.nAr]] = (int32_t)nE;       // rowptr[nrow] = nnz (one entry per class)
+    const uint32_t nc = g.r_ncls[r], ne = g.r_nent[r];
+    if (nc == 0 && ne == 0) return;
+    // (the tables the weights kernel dereferences are complete even when the build is about to be discarded)
+    if (ne > 0) o.atable[abase[r]] = (int64_t)rg.exi[2 * (long)pl.arng[r]];
+    bool ok = nc > 0 && ne > 0;
+    for (int k = 0; k < g.NC; ++k)
+        if (g.erank[(size_t)r * g.NC + k] >= 0 && g.ecntn[(size_t)r * g.NC + k] + g.ecnto[(size_t)r * g.NC + k] == 0) ok = false;
+    if (!ok) { atomicOr(flags, (uint32_t)FA_ERR_MISSING); return; }
+    const uint32_t a = abase[r], eb = g.gbase[r];
+    double sum = 0.0;                                    // over the classes of this cell by ascending dense id (= first-seen rank)
+    for (uint32_t q = 0; q < nc; ++q) {
+        const uint32_t e = eb + q;
+        const double t = S[e];
+        sum = sum + t;
+        o.val[e] = t;
+        if (e_is_row) { o.rowptr[e] = (int32_t)e; o.colind[e] = (int32_t)a; o.row[e] = (int32_t)e; o.rs[e] = 0.0 + t; }
+        else { o.colind[e] = (int32_t)e; o.row[e] = (int32_t)a; o.cs[e] = 0.0 + t; }
+    }
+    if (e_is_row) o.cs[a] = sum;
+    else { o.rs[a] = sum; o.rowptr[a] = (int32_t)eb; }
+}
+
+static bool fast_build_eva(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
+                           const RgView &rg, ibh_weighted *w, hipStream_t st) {
+    const ibh_regridder *gr = rm->rg;
+    const bool e_is_row = sp->row_key == KEY_E;
+    ibh_sparse_set *eset = dims[e_is_row ? 0 : 1], *aset = dims[e_is_row ? 1 : 0];
+    if (eset->n != 0 || aset->n != 0 || eset == aset) return false;
+    const int64_t extE = gr->nA * (int64_t)gr->nhc, extA = gr->nA;
+    Arena &A = arena();
+    A.reset();
+    const ibh_plan &P = gr->plan;
+    PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti};
+    const long nX = gr->nX;
+    const int T = FA_T, nAr = P.nAr;
+    FaG g{};
+    g.key = KEY_E; g.list = LIST_EP; g.NC = gr->nhc;
+    const size_t nrc = (size_t)nAr * g.NC;
+    g.erank = A.get<int8_t>(nrc); g.ecntn = A.get<uint32_t>(nrc); g.ecnto = A.get<uint32_t>(nrc);
+    g.r_ncls = A.get<uint32_t>((size_t)nAr); g.r_nent = A.get<uint32_t>((size_t)nAr);
+    g.gbase = A.get<uint32_t>((size_t)nAr + 1); g.ebase = A.get<uint32_t>((size_t)nAr + 1);
+    uint32_t *abase = A.get<uint32_t>((size_t)nAr + 1);
+    FaP p{};
+    p.key = KEY_X; p.list = LIST_AP; p.fresh = 0;              // every exchange cell its own key: nothing merges, everything is "new"
+    // counters: [0] first out-of-range cell, [1] fallback flags, [3] classes, [4] terms, [5] atmosphere cells
+    uint32_t *d_cnt = A.get<uint32_t>(8);
+    hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
+    hipLaunchKernelGGL(k_fa_count<true>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, e_is_row ? 1 : 0, 0, d_cnt, d_cnt + 1, 1);
+    if (nAr > 4096) {
+        exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
+        exclusive_scan_u32(g.r_nent, g.ebase, (size_t)nAr, g.ebase + nAr, st);
+        uint32_t *has = A.get<uint32_t>((size_t)nAr);
+        hipLaunchKernelGGL(k_eva_hasa, dim3(ceil_div(nAr, T)), dim3(T), 0, st, g.r_nent, nAr, has);
+        exclusive_scan_u32(has, abase, (size_t)nAr, abase + nAr, st);
+        IBH_HIP(hipMemcpyAsync(d_cnt + 3, g.gbase + nAr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        IBH_HIP(hipMemcpyAsync(d_cnt + 4, g.ebase + nAr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        IBH_HIP(hipMemcpyAsync(d_cnt + 5, abase + nAr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(k_fa_rscan, dim3(1), dim3(1024), 0, st, g.r_ncls, g.r_nent, nAr, g.gbase, g.ebase, d_cnt + 3);
+        hipLaunchKernelGGL(k_eva_ascan, dim3(1), dim3(1024), 0, st, g.r_nent, nAr, abase, d_cnt + 5);
+    }
+    IBH_HIP(hipGetLastError());
+    uint32_t h[8];
+    auto check_counters = [&]() -> bool {
+        readback_sync(h, d_cnt, sizeof(h), st);
+        if (h[0] != 0xffffffffu) {                              // message of linterp_1d_b, IceRegridder_L0.cpp:84-85
+            int32_t ij[2];
+            IBH_HIP(hipMemcpy(ij, gr->ex_indices.p + 2 * (size_t)h[0], sizeof(ij), hipMemcpyDeviceToHost));
+            double e = 0;
+            IBH_HIP(hipMemcpy(&e, rm->elevmaskI.p + ij[1], sizeof(double), hipMemcpyDeviceToHost));
+            fail(IBH_ERANGE, "Elevation %g out of bounds (%g, %g)", e < 0 ? 0.0 : e, gr->hcdefs_h.front(), gr->hcdefs_h.back());
+        }
+        return h[1] == 0;
+    };
+    if (!check_counters()) return false;
+    IBH_CHECK(h[4] < (1u << 31), "matrix too large for int32 indices");
+    const int nE = (int)h[3], nA = (int)h[5];
+    const uint32_t nterm = h[4];
+    DevBuf<int64_t> etable, atable;
+    etable.alloc((size_t)nE); atable.alloc((size_t)nA);
+    g.to_sparse = etable.p;
+    const int nrow = e_is_row ? nE : nA, ncol = e_is_row ? nA : nE;
+    const long nnz = nE;
+    w->nrow = nrow; w->ncol = ncol; w->nnz = nnz;
+    w->rowptr.alloc((size_t)nrow + 1); w->colind.alloc((size_t)nnz); w->val.alloc((size_t)nnz);
+    w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
+    uint32_t *flags = d_cnt + 1;
+    double *S = A.get<double>((size_t)nE);
+    double *rs = A.get<double>((size_t)nrow), *cs = A.get<double>((size_t)ncol);
+    double *rowmul = A.get<double>((size_t)nrow), *colmul = A.get<double>((size_t)ncol);
+    int32_t *row = A.get<int32_t>((size_t)nnz);
+    if (nE == 0) IBH_HIP(hipMemsetAsync(w->rowptr.p, 0, sizeof(int32_t), st));
+    if (nE) {
+        // T[e]: the terms go to their (class, x-order) slot of a scratch array, one wave per class adds them up in sequence
+        FaOut os{nullptr, nullptr, A.get<double>(nterm), nullptr, S, sp->family, 0, 0, e_is_row ? 1 : 0};
+        hipLaunchKernelGGL((k_fa_range<true, false>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, 0, os, flags);
+        EvaOut eo{w->rowptr.p, w->colind.p, row, w->val.p, rs, cs, atable.p};
+        hipLaunchKernelGGL(k_eva_final, dim3(ceil_div(nAr, T)), dim3(T), 0, st, rg, pl, g, abase, S, e_is_row ? 1 : 0, eo, flags);
+        IBH_HIP(hipGetLastError());
+        // the flags these two may raise are read BEFORE the weights and the scaling run: a discarded build leaves rows of
+        // the piece-wise CSR unwritten, and those kernels index through it
+        if (!check_counters()) return false;
+        FinalizeArgs fa{sp->family, scale, correctA, sp->row_key, sp->col_key, nrow, ncol, e_is_row ? etable.p : atable.p,
+                        e_is_row ? atable.p : etable.p, rs, cs, w->wM.p, w->Mw.p, rowmul, colmul};
+        hipLaunchKernelGGL(k_weights, dim3(ceil_div(std::max(nrow, ncol), T)), dim3(T), 0, st, rg, fa);
+        if (scale || correctA)
+            hipLaunchKernelGGL(k_scale, dim3(ceil_div(nnz, T)), dim3(T), 0, st, row, w->colind.p, w->val.p, nnz, rowmul, colmul, scale ? 1 : 0, correctA ? 1 : 0);
+        IBH_HIP(hipGetLastError());
+    }
+    auto commit = [&](ibh_sparse_set *set, int64_t extent, DevBuf<int64_t> &table, int n) {
+        set->sparse_extent = extent;
+        if (n == 0) return;
+        set->host.clear(); set->host_n = 0; set->inv.clear(); set->inv_n = 0;
+        set->dev = std::move(table);
+        set->dev_n = set->n = n;
+        set->identity = false;
+    };
+    commit(eset, extE, etable, nE);
+    commit(aset, extA, atable, nA);
+    IBH_HIP(hipStreamSynchronize(st));
+    return true;
+}
+
 // Batch builds (assemble_batch): everything a concurrent fast build would otherwise create lazily in shared objects --
 // the sheet's plan, the inverse table of a pre-populated column set -- is created up front on the calling thread.
 static void fast_prewarm(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], hipStream_t st) {
     const ibh_regridder *gr = rm->rg;
-    if (!get_tuning("assemble_fast", 1) || sp->family == FAM_EVA || !ensure_plan(gr, st)) return;
+    if (!get_tuning("assemble_fast", 1) || !ensure_plan(gr, st)) return;
     if (sp->family != FAM_IVAE || !dims[1] || dims[1]->n == 0 || dims[1]->identity || sp->col_key != KEY_E) return;
     (void)set_inverse_table(dims[1], gr->nA * (int64_t)gr->nhc, st);
     IBH_HIP(hipStreamSynchronize(st));
@@ -765,8 +929,9 @@ static void fast_prewarm(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
 static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
                        const RgView &rg, ibh_weighted *w, hipStream_t st) {
     const ibh_regridder *gr = rm->rg;
-    if (!get_tuning("assemble_fast", 1) || sp->family == FAM_EVA) return false;
+    if (!get_tuning("assemble_fast", 1)) return false;
     if (!ensure_plan(gr, st)) return false;
+    if (sp->family == FAM_EVA) return get_tuning("assemble_fast_eva", 1) && fast_build_eva(rm, sp, dims, scale, correctA, rg, w, st);
     const bool g_is_row = sp->family == FAM_AEVI;
     ibh_sparse_set *gset = dims[g_is_row ? 0 : 1], *pset = dims[g_is_row ? 1 : 0];
     const int gkey = g_is_row ? sp->row_key : sp->col_key, glist = g_is_row ? sp->row_list : sp->col_list;
@@ -801,8 +966,8 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     uint32_t *d_cnt = A.get<uint32_t>(8);
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     if (p.fresh) { p.pflag = A.get<uint8_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
-    if (uses_ep) hipLaunchKernelGGL(k_fa_count<true>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1);
-    else hipLaunchKernelGGL(k_fa_count<false>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1);
+    if (uses_ep) hipLaunchKernelGGL(k_fa_count<true>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
+    else hipLaunchKernelGGL(k_fa_count<false>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
     if (p.fresh) exclusive_scan_u8(p.pflag, p.poff, (size_t)nX, d_cnt + 2, st);
     if (nAr > 4096) {                                           // many ranges: the device-wide scan; few: one workgroup, one launch
         exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
@@ -845,7 +1010,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     w->nrow = nrow; w->ncol = ncol; w->nnz = nnz;
     w->rowptr.alloc((size_t)nrow + 1); w->colind.alloc(nnz); w->val.alloc(nnz);
     w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
-    FaOut o{w->rowptr.p, w->colind.p, w->val.p, w->wM.p, w->Mw.p, sp->family, scale, correctA};
+    FaOut o{w->rowptr.p, w->colind.p, w->val.p, w->wM.p, w->Mw.p, sp->family, scale, correctA, 0};
     uint32_t *flags = d_cnt + 1;
     const long np_s = p.key == KEY_I ? gr->nI : nX;             // P elements by sparse index
     const dim3 gp(ceil_div(np_s, T));

@@ -70,7 +70,7 @@ def test_assembly_bit_exact_all_matrices(variant):
 
 @pytest.mark.parametrize("config", ["g50", "g20"])
 def test_fast_and_general_assembly_paths_agree_with_the_oracle(config):
-    # sorted exchange grids take the plan-based fast path (fastasm.inl) for the A/E-row and I/X-row families; the
+    # sorted exchange grids take the plan-based fast path (fastasm.inl) for the A/E-row, I/X-row and EvA/AvE families; the
     # general pipeline (forced with assemble_fast=0) must give the same bits.  Own dims, identity I / X dims, and the
     # coupler's shared dimE (IceCoupler.cpp:361-468).
     g, em, mm, rg = setup(config)
@@ -82,7 +82,7 @@ def test_fast_and_general_assembly_paths_agree_with_the_oracle(config):
                 rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
                 for name in ALL:
                     w = rm.matrix(name)
-                    assert w.built_fast() == (bool(fast) and name not in ("EvA", "AvE")), (name, fast)
+                    assert w.built_fast() == bool(fast), (name, fast)          # EvA / AvE too (fresh sets: fast_build_eva)
                     assert_same_weighted(w, rg.matrix_d(name, em, scale=scale, correctA=correctA), "%s fast=%d" % (name, fast))
             # the coupler's step: EvI / AvI with identity dimI, then IvE / XvE on the dimE that EvI numbered
             rm = mm.regrid_matrices("greenland", em)
@@ -617,6 +617,31 @@ def test_config5_antarctica_1km_elevation_class_matrices():
     one = np.ones((1, EvI.ncol_d))
     back = IvE.apply(EvI.apply(one)[:, np.argsort(EvI.dim(0))[np.searchsorted(np.sort(EvI.dim(0)), IvE.dim(1))]])
     assert np.all(np.abs(back - 1.0) < 1e-11)
+
+
+def test_config5_antarctica_eva_ave_fast_build_is_the_general_pipeline_bitwise():
+    # EvA / AvE of the Antarctic sheet (tens of thousands of atmosphere cells: the device-wide scans of fast_build_eva, which
+    # the oracle-sized grids never reach): the plan-based build against the general pipeline (itself pinned to the oracle on
+    # the small grids), all four (scale, correctA) branches, every bit of the matrix, its weights and its dims
+    g = _big_grids("a1h")
+    em = syn.dome_elevmask(g)
+    mm = icebin_amd.from_synthetic(g)
+    try:
+        for name in ("EvA", "AvE"):
+            for scale, correctA in ((True, True), (False, False), (True, False), (False, True)):
+                rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
+                icebin_amd.set_tuning("assemble_fast_eva", 1)
+                wf = rm.matrix(name)
+                icebin_amd.set_tuning("assemble_fast_eva", 0)
+                wg = rm.matrix(name)
+                assert wf.built_fast() and not wg.built_fast()
+                assert (wf.nrow_d, wf.ncol_d, wf.nnz) == (wg.nrow_d, wg.ncol_d, wg.nnz) and wf.nnz > 4096
+                assert np.array_equal(wf.dim(0), wg.dim(0)) and np.array_equal(wf.dim(1), wg.dim(1))
+                for a, b in zip(wf.csr_dense(), wg.csr_dense()):
+                    assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, b.view(np.uint64) if b.dtype == np.float64 else b), name
+                assert np.array_equal(wf.wM.view(np.uint64), wg.wM.view(np.uint64)) and np.array_equal(wf.Mw.view(np.uint64), wg.Mw.view(np.uint64))
+    finally:
+        icebin_amd.set_tuning("assemble_fast_eva", 1)
 
 
 def test_config5_antarctica_colsweep_agrees_with_rowblock_at_64_fields():
