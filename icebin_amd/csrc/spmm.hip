@@ -474,7 +474,7 @@ struct GroupView {
     int ngrp, nslot;
 };
 constexpr unsigned RG_HAS0 = 1u << 16, RG_HAS1 = 1u << 17;
-template <int NW, int U>
+template <int NW, int U, int TW>
 __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView gv, const BatchPtrs bp, long ldx, int ncol, long ldy, int nf,
                                                                int nfc, int xcd_mode, const double *__restrict__ wM, double fill)
 {
@@ -495,8 +495,11 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView 
     double *__restrict__ Y = bp.y[blockIdx.y];
     const int beg = gv.ptr[g], end = gv.ptr[g + 1], ns = gv.ns[g];
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)f * ldx), 0, ncol * 8, 0x00020000);
-    double *tab = s_tab + (long)wave * gv.nslot * 64 + lane;
-    for (int s = 0; s < ns; ++s) tab[s * 64] = 0.0;
+    // TW = 32: lanes L and L + 32 share a table entry (half the LDS: all workgroups of a 64-field apply at 5 km are resident
+    // at once instead of in two rounds); their adds are issued as two instructions, lower half first -- LDS operations of a wave
+    // execute in issue order, so the sum of an entry is still formed in one fixed order
+    double *tab = s_tab + (long)wave * gv.nslot * TW + (lane & (TW - 1));
+    for (int s = 0; s < ns; ++s) tab[s * TW] = 0.0;
     // The group is walked in segments of SEG items staged in LDS; the loads of segment s+1 are issued before segment s is
     // processed (they fly while X streams) and written to LDS after it.
     int cc[ST];
@@ -545,10 +548,26 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView 
         __builtin_amdgcn_sched_barrier(0);
         // ... and the products go to the LDS pipe as ds_add_f64 WITHOUT return, back to back: the sums of a lane are added in
         // program order (deterministic) and the wave never waits for a read-modify-write round trip
+        if (TW == 64) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (m[u] & RG_HAS0) __hip_atomic_fetch_add(tab + (m[u] & 0xffu) * 64, w0[u] * x[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (m[u] & RG_HAS1) __hip_atomic_fetch_add(tab + ((m[u] >> 8) & 0xffu) * 64, w1[u] * x[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int u = 0; u < U; ++u) {
+                if (m[u] & RG_HAS0) __hip_atomic_fetch_add(tab + (m[u] & 0xffu) * TW, w0[u] * x[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (m[u] & RG_HAS1) __hip_atomic_fetch_add(tab + ((m[u] >> 8) & 0xffu) * TW, w1[u] * x[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double p0 = w0[u] * x[u], p1 = w1[u] * x[u];
+                const bool lo = lane < 32;
+                if ((m[u] & RG_HAS0) && lo) __hip_atomic_fetch_add(tab + (m[u] & 0xffu) * TW, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((m[u] & RG_HAS0) && !lo) __hip_atomic_fetch_add(tab + (m[u] & 0xffu) * TW, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((m[u] & RG_HAS1) && lo) __hip_atomic_fetch_add(tab + ((m[u] >> 8) & 0xffu) * TW, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((m[u] & RG_HAS1) && !lo) __hip_atomic_fetch_add(tab + ((m[u] >> 8) & 0xffu) * TW, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (more) {
             __syncthreads();                        // every wave is done reading this segment
@@ -562,9 +581,10 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView 
     const int sl = lane & 31, half = lane >> 5;
     double tot = 0.0;
     if (sl < ns) {
-        const double *row = s_tab + ((long)wave * gv.nslot + sl) * 64 + half * 32;
+        constexpr int HW = TW / 2;
+        const double *row = s_tab + ((long)wave * gv.nslot + sl) * TW + half * HW;
 #pragma unroll 8
-        for (int j = 0; j < 32; ++j) tot += row[(j + lane) & 31];
+        for (int j = 0; j < HW; ++j) tot += row[(j + lane) & (HW - 1)];
     }
     tot += __shfl_xor(tot, 32, 64);
     if (half == 0 && sl < ns && fw < nf) {
@@ -580,6 +600,10 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView 
 // 5 km, 322 at 1 km): as for the A-row kernel, extra vector-memory instructions cost more than barriers and LDS footprint.
 // Two fields per wave (the items read once per 16 fields instead of 8: 1.45 -> 1.22 x traffic at 1 km) doubles the class tables:
 // 250 against 217 us at 1 km with 8 waves, 216 with 4 (no gain), 20.3 against 17.1 us at 5 km.
+// A lean form for groups that fit one staged segment (U = 12..16 gathers per lane, slots and weights read from LDS when the
+// gathers land, no cross-segment prefetch -- what made rowone fast) does NOT carry over: 17.5 us at best (U = 14, half-width
+// tables), 24-29 with full tables (two workgroups per CU).  What bounds this kernel is the LDS pipe, not the gathers: per item
+// and field it moves ~56 bytes through LDS (col, meta, two weights, two read-modify-write adds) where the A-row kernel moves 12.
 
 constexpr int SR_THREADS = 256;
 
@@ -907,7 +931,7 @@ static void launch_rowone(const ibh_weighted *w, const double *X, double *Y, int
     IBH_HIP(hipGetLastError());
 }
 
-template <int NW, int U>
+template <int NW, int U, int TW>
 static void launch_rowgroup(const ibh_weighted *w, const BatchPtrs &bp, int nbatch, int nvar, long lda, long ldb, double fill, hipStream_t stream)
 {
     const int nfc = ceil_div(nvar, NW);
@@ -916,7 +940,7 @@ static void launch_rowgroup(const ibh_weighted *w, const BatchPtrs &bp, int nbat
     IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
     IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
     GroupView gv{w->grp_ptr.p, w->grp_ns.p, w->grp_slotrow.p, w->grp_col.p, w->grp_meta.p, w->grp_v0.p, w->grp_v1.p, w->grp_n, w->grp_nslot};
-    const size_t lds = (size_t)(3 * U * 64 + NW * w->grp_nslot * 64) * sizeof(double);
+    const size_t lds = (size_t)(3 * U * 64 + NW * w->grp_nslot * TW) * sizeof(double);
     hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
     if (lds > 64 * 1024) {                               // beyond the default dynamic-LDS limit: raise it once per device
@@ -924,11 +948,11 @@ static void launch_rowgroup(const ibh_weighted *w, const BatchPtrs &bp, int nbat
         static bool raised[64] = {};
         std::lock_guard<std::mutex> lk(mu);
         if (!raised[w->device & 63]) {
-            IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_rowgroup_kernel<NW, U>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            IBH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_rowgroup_kernel<NW, U, TW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             raised[w->device & 63] = true;
         }
     }
-    hipExtLaunchKernelGGL((spmm_rowgroup_kernel<NW, U>), dim3((unsigned)nb, (unsigned)nbatch), dim3(NW * 64), lds, stream, ev0, ev1, 0, gv, bp,
+    hipExtLaunchKernelGGL((spmm_rowgroup_kernel<NW, U, TW>), dim3((unsigned)nb, (unsigned)nbatch), dim3(NW * 64), lds, stream, ev0, ev1, 0, gv, bp,
                           lda, w->ncol, ldb, nvar, nfc, xcd_mode, w->wM.p, fill);
     IBH_HIP(hipGetLastError());
 }
@@ -1255,9 +1279,14 @@ static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &
     if (kernel == 5) {
         // 8 waves (fields) share a staged segment from 32 fields (5 km, 64 fields: 17.1 against 19.3 us with 4)
         const int u = get_tuning("rowgroup_unroll", 8), nw = get_tuning("rowgroup_waves", nvar >= 32 ? 8 : 4);
-#define IBH_RG(N, UU) launch_rowgroup<N, UU>(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream)
-        if (nw == 8) { if (u <= 8) IBH_RG(8, 8); else IBH_RG(8, 16); }
-        else { if (u <= 4) IBH_RG(4, 4); else if (u <= 8) IBH_RG(4, 8); else IBH_RG(4, 16); }
+        // class tables of half width (two lanes per entry) for the small matrices: all workgroups of a 5 km launch fit the LDS at
+        // once -- 16 applies per launch 13.5 -> 12.3 us (64 fields), 3.96 -> 3.37 (16 fields), one launch unchanged (17.6 / 17.8);
+        // at 1 km the doubled atomic instructions cost 223 -> 238 us.  By the matrix alone, so one apply and a batch agree bitwise.
+        const int tw = get_tuning("rowgroup_tw", w->nnz < (1 << 20) ? 32 : 64);
+#define IBH_RG(N, UU, TT) launch_rowgroup<N, UU, TT>(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream)
+        if (tw == 32) { if (nw == 8) { if (u <= 8) IBH_RG(8, 8, 32); else IBH_RG(8, 16, 32); } else { if (u <= 4) IBH_RG(4, 4, 32); else IBH_RG(4, 8, 32); } }
+        else if (nw == 8) { if (u <= 8) IBH_RG(8, 8, 64); else IBH_RG(8, 16, 64); }
+        else { if (u <= 4) IBH_RG(4, 4, 64); else if (u <= 8) IBH_RG(4, 8, 64); else IBH_RG(4, 16, 64); }
 #undef IBH_RG
     } else if (kernel == 4) {
         launch_sweep(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream);

@@ -1554,9 +1554,17 @@ def test_rowgroup_on_grid_variants(variant):
         for nvar in (64, 40, 130, 7, 1):
             x = syn.fields(nvar, w.ncol_d, seed=7 + nvar)
             x[nvar // 2, ::7] = np.nan              # NaN in a field must stay in the rows that use those cells
-            y = w.apply(x, fill=-1.0, force_conservation=False)
-            assert w.last_kernel() == "rowgroup", (name, nvar)
-            assert rel_linf(y, o.apply(x, fill=-1.0, force_conservation=False)) <= FIELD_RTOL, (name, nvar)
+            ref = o.apply(x, fill=-1.0, force_conservation=False)
+            # class tables of half width (two lanes per entry: the default below 2^20 entries) and of full width
+            for tw in (None, 64, 32) if nvar in (64, 7) else (None,):
+                if tw is not None:
+                    icebin_amd.set_tuning("rowgroup_tw", tw)
+                try:
+                    y = w.apply(x, fill=-1.0, force_conservation=False)
+                finally:
+                    icebin_amd.set_tuning("rowgroup_tw", -2 ** 31)
+                assert w.last_kernel() == "rowgroup", (name, nvar)
+                assert rel_linf(y, ref) <= FIELD_RTOL, (name, nvar, tw)
         if name == "EvI":
             xs = [torch.from_numpy(syn.fields(16, w.ncol_d, seed=400 + q)).cuda() for q in range(5)]
             xs[2][3, ::5] = float("nan")
