@@ -10,8 +10,8 @@ dimension / attribute names out in it.  Two things the classic data model cannot
   * attributes holding a LIST of strings (`m.info:sheets`, `BvA.info:dim_names`) become one char
     attribute with the names joined by ','  (names never contain commas);
   * nothing else: dotted names, int64 variables and scalar variables are legal in CDF-5.
-Files written by the reference's NetCDF-4 (HDF5) build are read through the `netCDF4` package when it
-is importable (guarded), or after `nccopy -k cdf5`; HDF5 itself is out of scope.
+Files written by the reference's NetCDF-4 (HDF5) build are READ through hdf5.py, this package's own
+reader of the HDF5 subset such files use (Dataset.read dispatches on the signature); writing stays classic.
 
 No regridding arithmetic lives here: arrays in, arrays out.
 """
@@ -205,13 +205,14 @@ class Dataset:
 
 
 def _read_netcdf4(path):
-    """A NetCDF-4 (HDF5) file, as the reference's build writes them: only through the optional
-    `netCDF4` package."""
-    try:
-        import netCDF4
-    except ImportError:
-        raise ImportError("%s is a NetCDF-4/HDF5 file; reading it needs the netCDF4 package (absent), or convert it "
-                          "with `nccopy -k cdf5`" % path)
+    """A NetCDF-4 (HDF5) file, as the reference's build writes them (NcIO(fname, 'w', "nc4"), global_ec.cpp:539,567):
+    through this package's own HDF5 reader (hdf5.py); ICEBIN_USE_NETCDF4=1 asks for the `netCDF4` package instead
+    (a cross-check where it is installed).  List-of-strings attributes come back as Python lists."""
+    import os
+    if os.environ.get("ICEBIN_USE_NETCDF4", "0") != "1":
+        from . import hdf5
+        return hdf5.read_netcdf4(path)[0]
+    import netCDF4
     ds = Dataset()
     with netCDF4.Dataset(path) as nc:
         for d, v in nc.dimensions.items():
