@@ -16,6 +16,17 @@ for cfg in sys.argv[1].split(","):
     b = np.linspace(0.0, 1.0, nvar_out)
     best = None
     best_batch = None
+    # an ice model that keeps its elevation mask in HBM hands over a device pointer (ibh_regrid_matrices_create_device):
+    em_dev = torch.from_numpy(em).cuda()
+    best_dev = None
+    for step in range(9):
+        em_step = em_dev + 0.01 * step
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        rm_dev = mm.regrid_matrices("greenland", em_step, scale=True, correctA=False)
+        torch.cuda.synchronize(); td = (time.perf_counter() - t0) * 1e3
+        if step >= 2:
+            best_dev = td if best_dev is None else min(best_dev, td)
+        del rm_dev
     for step in range(9):
         torch.cuda.synchronize(); t = [time.perf_counter()]
         rm = mm.regrid_matrices("greenland", em + 0.01 * step, scale=True, correctA=False)
@@ -44,6 +55,7 @@ for cfg in sys.argv[1].split(","):
         assert ws[2].nnz == IvE.nnz and ws[0].nrow_d == EvI.nrow_d
         if step >= 2:
             best_batch = tb if best_batch is None else min(best_batch, tb)
-    names = ["regrid_matrices(elevmask upload)", "EvI", "AvI", "IvE", "XvE", "(field setup)", "2 fused applies"]
-    print("%-5s nX=%d" % (cfg, nX), "  ".join("%s %.3f ms" % (n, v) for n, v in zip(names, best) if not n.startswith("(")),
+    names = ["regrid_matrices(mask from pageable host memory)", "EvI", "AvI", "IvE", "XvE", "(field setup)", "2 fused applies"]
+    print("%-5s nX=%d" % (cfg, nX), "regrid_matrices(mask already in HBM) %.3f ms " % best_dev,
+          "  ".join("%s %.3f ms" % (n, v) for n, v in zip(names, best) if not n.startswith("(")),
           " | matrices %.3f ms | batched call %.3f ms" % (best[1:5].sum(), best_batch), flush=True)
