@@ -1130,7 +1130,9 @@ static ShortrowPlan shortrow_plan(const ibh_weighted *w, int nvar, int nbatch = 
     p.one_entry = (double)w->nnz <= 1.5 * (double)w->nrow;
     p.big = w->nrow >= (1 << 19);
     // (2-3 entries, one launch of <= 32 fields: 4 fields per thread, field-major 8.2 us against 14.2 through the transposed copy)
-    const bool few_fields_once = nbatch < 4 && nvar <= 32;    // (32 fields: 13.7 against 16.0)
+    // (32 fields: 13.7 against 16.0; rows of 2-3 entries only: a smoothed IvE -- ~16 entries per row -- needs the lines of the
+    // transposed copy: 59.6 against 143 us at 16 fields)
+    const bool few_fields_once = nbatch < 4 && nvar <= 32 && (double)w->nnz <= 4.0 * (double)w->nrow;
     const int small_multi = nbatch >= 4 ? 32 : few_fields_once ? 4 : 16;
     // (round 3, kernel durations by dispatch events instead of wall time: ONE launch of a one-entry matrix at 5 km is fastest
     // field-major with 4 fields per thread -- 64 fields 13.2 us against 15.8 through the transposed copy, whose second
