@@ -36,14 +36,15 @@ enum { FA_ERR_OLDOVER = 1, FA_ERR_MISSING = 2 };
 
 struct PlanView {
     const int32_t *arng, *aidx, *ilptr, *ilist, *ifirst;
-    const uint8_t *isdup;       // bit 0 duplicate of the previous cell, bit 1 the ice cell lives in this range only
+    const uint8_t *isdup;       // bit 0 duplicate of the previous cell, bit 1 the ice cell lives in this range only, bit 2 first-seen
+                                // cell of its ice cell, bit 3 area > 0, bit 4 area != 0 and not > 0
     const int32_t *mlist;       // ice cells spread over several ranges
     int nAr, nmulti;
 };
 
 // ---- static plan ---------------------------------------------------------------------------------
-__global__ void k_plan_flags(const int32_t *__restrict__ exi, long nX, uint32_t *__restrict__ head, uint8_t *__restrict__ isdup,
-                             uint32_t *__restrict__ bad) {
+__global__ void k_plan_flags(const int32_t *__restrict__ exi, const double *__restrict__ area, long nX, uint32_t *__restrict__ head,
+                             uint8_t *__restrict__ isdup, uint32_t *__restrict__ bad) {
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= nX) return;
     const int iA = exi[2 * x], iI = exi[2 * x + 1];
@@ -55,7 +56,10 @@ __global__ void k_plan_flags(const int32_t *__restrict__ exi, long nX, uint32_t 
         if (iA < pA || (iA == pA && iI < pI)) *bad = 1u;           // not sorted by (iA, iI)
     }
     head[x] = h ? 1u : 0u;
-    isdup[x] = d ? 1 : 0;
+    // bits 3 / 4: the sign class of the (static) overlap area -- all a build without elevation classes needs of it to COUNT
+    // (GvAp wants area > 0, GvI area != 0: IceRegridder_L0.cpp:186-187,208-209), so k_fa_count<false> does not load the areas
+    const double a = area[x];
+    isdup[x] = (uint8_t)((d ? 1 : 0) | (a > 0 ? 8 : (a != 0 ? 16 : 0)));
 }
 __global__ void k_plan_ranges(const uint32_t *__restrict__ head, const uint32_t *__restrict__ hpos, const uint8_t *__restrict__ isdup,
                               long nX, int32_t *__restrict__ aidx, int32_t *__restrict__ arng, uint32_t nAr, uint32_t *__restrict__ bad) {
@@ -116,7 +120,7 @@ static bool ensure_plan(const ibh_regridder *g, hipStream_t st) {
     uint32_t *head = A.get<uint32_t>((size_t)nX), *hpos = A.get<uint32_t>((size_t)nX), *d_cnt = A.get<uint32_t>(2);
     IBH_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(uint32_t), st));
     P.isdup.alloc((size_t)nX);
-    hipLaunchKernelGGL(k_plan_flags, dim3(ceil_div(nX, T)), dim3(T), 0, st, g->ex_indices.p, nX, head, P.isdup.p, d_cnt + 1);
+    hipLaunchKernelGGL(k_plan_flags, dim3(ceil_div(nX, T)), dim3(T), 0, st, g->ex_indices.p, g->ex_area.p, nX, head, P.isdup.p, d_cnt + 1);
     exclusive_scan_u32(head, hpos, (size_t)nX, d_cnt, st);
     uint32_t h[2];
     readback_sync(h, d_cnt, sizeof(h), st);
@@ -260,11 +264,13 @@ __global__ __launch_bounds__(FA_T) void k_fa_count(RgView rg, PlanView pl, MatSp
         for (int u = 0; u < FA_CPT; ++u) {
             const long x = cb + (long)u * FA_T + threadIdx.x;
             const long xx = x < x1 ? x : x1 - 1;
-            iAv[u] = rg.exi[2 * xx]; iIv[u] = rg.exi[2 * xx + 1]; av[u] = rg.area[xx]; fl[u] = pl.isdup[xx];
+            iAv[u] = rg.exi[2 * xx]; iIv[u] = rg.exi[2 * xx + 1]; fl[u] = pl.isdup[xx];
+            if (WITH_EP) av[u] = rg.area[xx];                   // (the class weights are products with the area)
         }
 #pragma unroll
         for (int u = 0; u < FA_CPT; ++u) {
             ev[u] = rg.em[iIv[u]];
+            if (!WITH_EP) av[u] = (fl[u] & 8) ? 1.0 : (fl[u] & 16) ? -1.0 : 0.0;      // counting needs the sign class only (plan bits 3 / 4)
             const long x = cb + (long)u * FA_T + threadIdx.x;
             // first-seen position of the ice cell: this very cell for ~90 % of them (plan bit 2), a gather for the rest
             ifv[u] = p.key == KEY_I ? ((fl[u] & 4) ? (int)(x < x1 ? x : x1 - 1) : pl.ifirst[iIv[u]]) : 0;
@@ -641,8 +647,9 @@ __global__ __launch_bounds__(FA_T) void k_fa_pelem(RgView rg, PlanView pl, MatSp
     int d = -1;
     int lb = 0, le = 0;
     long pkey = q;
+    double e = 0.0;
     if (p.key == KEY_I) {
-        const double e = rg.em[q];
+        e = rg.em[q];
         const bool masked = e != e;
         if (masked && p.fresh) return;                      // not a member of the set: nothing to write
         const int f = pl.ifirst[q];
@@ -667,8 +674,14 @@ __global__ __launch_bounds__(FA_T) void k_fa_pelem(RgView rg, PlanView pl, MatSp
     auto visit = [&](auto &&fn) {
         for (int k = lb; k < le; ++k) {
             const long x = p.key == KEY_I ? (long)pl.ilist[k] : q;
-            if (merge && (pl.isdup[x] & 1)) continue;
-            const XCell c = load_cell<WITH_EP>(rg, x);
+            const unsigned fx = pl.isdup[x];
+            if (merge && (fx & 1)) continue;
+            // COUNTING the entries of an ice cell without elevation classes needs nothing of the exchange cell but the sign
+            // class of its area (plan bits 3 / 4): its ice cell is this element, the mask value is in hand -- no gather of
+            // the cell's indices and area (IvA: the count pass reads the static lists only)
+            const XCell c = (!WITH_EP && MODE == FA_PCOUNT && p.key == KEY_I)
+                                ? make_cell<false>(rg, 0, q, (fx & 8) ? 1.0 : (fx & 16) ? -1.0 : 0.0, e)
+                                : load_cell<WITH_EP>(rg, x);
             if (WITH_EP && c.range_error) continue;
             GEnt ge;
             fa_group<WITH_EP>(rg, pl, s, g_is_row, merge != 0, c, x, ge);
