@@ -243,8 +243,8 @@ __device__ __forceinline__ uint32_t fa_pflag_of(const RgView &rg, const PlanView
 }
 
 // ---- G-side numbering and entry counts: one workgroup per range -----------------------------------
-template <bool WITH_EP>
-__global__ __launch_bounds__(FA_T) void k_fa_count(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int g_is_row, int merge,
+template <bool WITH_EP, int T, int CPT>
+__global__ __launch_bounds__(T) void k_fa_count(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int g_is_row, int merge,
                                                     uint32_t *__restrict__ err_x, uint32_t *__restrict__ flags, int eva_check) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     __shared__ uint32_t s_first[FA_NC], s_cn[FA_NC], s_co[FA_NC];
@@ -253,31 +253,31 @@ __global__ __launch_bounds__(FA_T) void k_fa_count(RgView rg, PlanView pl, MatSp
     const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
     if (threadIdx.x < FA_NC) { s_first[threadIdx.x] = 0xffffffffu; s_cn[threadIdx.x] = 0; s_co[threadIdx.x] = 0; }
     __syncthreads();
-    // FA_CPT cells per thread and pass with their loads staged (exchange cell, then mask / first-seen position of the ice
+    // CPT cells per thread and pass with their loads staged (exchange cell, then mask / first-seen position of the ice
     // cell) before anything is consumed: a range of ~10^3 cells is one pass, i.e. two dependent round trips in all
     const int lane = threadIdx.x & 63;
-    for (long cb = x0; cb < x1; cb += (long)FA_T * FA_CPT) {
-        int iAv[FA_CPT], iIv[FA_CPT], ifv[FA_CPT];
-        double av[FA_CPT], ev[FA_CPT];
-        unsigned fl[FA_CPT];
+    for (long cb = x0; cb < x1; cb += (long)T * CPT) {
+        int iAv[CPT], iIv[CPT], ifv[CPT];
+        double av[CPT], ev[CPT];
+        unsigned fl[CPT];
 #pragma unroll
-        for (int u = 0; u < FA_CPT; ++u) {
-            const long x = cb + (long)u * FA_T + threadIdx.x;
+        for (int u = 0; u < CPT; ++u) {
+            const long x = cb + (long)u * T + threadIdx.x;
             const long xx = x < x1 ? x : x1 - 1;
             iAv[u] = rg.exi[2 * xx]; iIv[u] = rg.exi[2 * xx + 1]; fl[u] = pl.isdup[xx];
             if (WITH_EP) av[u] = rg.area[xx];                   // (the class weights are products with the area)
         }
 #pragma unroll
-        for (int u = 0; u < FA_CPT; ++u) {
+        for (int u = 0; u < CPT; ++u) {
             ev[u] = rg.em[iIv[u]];
             if (!WITH_EP) av[u] = (fl[u] & 8) ? 1.0 : (fl[u] & 16) ? -1.0 : 0.0;      // counting needs the sign class only (plan bits 3 / 4)
-            const long x = cb + (long)u * FA_T + threadIdx.x;
+            const long x = cb + (long)u * T + threadIdx.x;
             // first-seen position of the ice cell: this very cell for ~90 % of them (plan bit 2), a gather for the rest
             ifv[u] = p.key == KEY_I ? ((fl[u] & 4) ? (int)(x < x1 ? x : x1 - 1) : pl.ifirst[iIv[u]]) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < FA_CPT; ++u) {
-            const long x = cb + (long)u * FA_T + threadIdx.x;
+        for (int u = 0; u < CPT; ++u) {
+            const long x = cb + (long)u * T + threadIdx.x;
             const bool in = x < x1;
             uint32_t cn0 = 0, co0 = 0;                        // one-class ranges: this lane's new / old entries
             if (in) {
@@ -396,14 +396,14 @@ struct FaOut {
     int family, scale, correctA;
     int g_rows;                     // SUMS only: the G side is the ROW side of the spec (EvA through the column-sum machinery)
 };
-template <bool WITH_EP, bool EMIT>
-__global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, FaOut o,
+template <bool WITH_EP, bool EMIT, int T, int CPT>
+__global__ __launch_bounds__(T) void k_fa_range(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, FaOut o,
                                                     uint32_t *__restrict__ flags) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     __shared__ int s_rank[FA_NC];
-    __shared__ uint32_t s_start[FA_NC + 1], s_seg[FA_NC], s_nold[FA_NC], s_run[FA_NC], s_wcnt[FA_T / 64][FA_NC];
+    __shared__ uint32_t s_start[FA_NC + 1], s_seg[FA_NC], s_nold[FA_NC], s_run[FA_NC], s_wcnt[T / 64][FA_NC];
     __shared__ double s_mul[FA_NC];
-    __shared__ uint32_t s_no, s_w1[2][FA_T / 64];
+    __shared__ uint32_t s_no, s_w1[2][T / 64];
     __shared__ int o_cls[FA_OLDMAX], o_did[FA_OLDMAX];
     __shared__ double o_t[FA_OLDMAX];
     stage_hc<WITH_EP>(rg, s_hc);
@@ -431,39 +431,39 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
     __syncthreads();
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const bool g_is_row = EMIT || o.g_rows != 0;
-    // FA_CPT cells per thread and pass: their loads are issued in three staged rounds (exchange cell -> mask and
+    // CPT cells per thread and pass: their loads are issued in three staged rounds (exchange cell -> mask and
     // first-seen position of its ice cell -> dense id) before anything is consumed, so a pass pays the dependent
-    // round trips once instead of once per 256 cells; the ranking then walks the FA_CPT sub-chunks in x order.
-    for (long cb = x0; cb < x1; cb += (long)FA_T * FA_CPT) {
-        int iAv[FA_CPT], iIv[FA_CPT], ifv[FA_CPT], didv[FA_CPT];
-        double av[FA_CPT], ev[FA_CPT];
-        unsigned fl[FA_CPT], pfv[FA_CPT], pov[FA_CPT];
-        GEnt gev[FA_CPT];
-        bool newv[FA_CPT];
+    // round trips once instead of once per 256 cells; the ranking then walks the CPT sub-chunks in x order.
+    for (long cb = x0; cb < x1; cb += (long)T * CPT) {
+        int iAv[CPT], iIv[CPT], ifv[CPT], didv[CPT];
+        double av[CPT], ev[CPT];
+        unsigned fl[CPT], pfv[CPT], pov[CPT];
+        GEnt gev[CPT];
+        bool newv[CPT];
 #pragma unroll
-        for (int u = 0; u < FA_CPT; ++u) {
-            const long x = cb + (long)u * FA_T + tid;
+        for (int u = 0; u < CPT; ++u) {
+            const long x = cb + (long)u * T + tid;
             const long xx = x < x1 ? x : x1 - 1;
             iAv[u] = rg.exi[2 * xx]; iIv[u] = rg.exi[2 * xx + 1]; av[u] = rg.area[xx]; fl[u] = pl.isdup[xx];
             pfv[u] = 0; pov[u] = 0;
             if (p.fresh && (EMIT || p.key == KEY_X)) { pfv[u] = p.pflag[xx]; pov[u] = p.poff[xx]; }
         }
 #pragma unroll
-        for (int u = 0; u < FA_CPT; ++u) {
+        for (int u = 0; u < CPT; ++u) {
             ev[u] = rg.em[iIv[u]];
-            const long x = cb + (long)u * FA_T + tid;
+            const long x = cb + (long)u * T + tid;
             ifv[u] = (p.key == KEY_I && p.fresh) ? ((fl[u] & 4) ? (int)(x < x1 ? x : x1 - 1) : pl.ifirst[iIv[u]]) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < FA_CPT; ++u) {
-            const long x = cb + (long)u * FA_T + tid;
+        for (int u = 0; u < CPT; ++u) {
+            const long x = cb + (long)u * T + tid;
             // dense id of the ice cell = poff[its first-seen position]: already in hand (pov) when that is this cell
             if (p.key == KEY_I) didv[u] = p.fresh ? ((EMIT && (fl[u] & 4)) ? (int)pov[u] : (int)p.poff[ifv[u] < 0 ? 0 : ifv[u]]) : iIv[u];
             else didv[u] = p.fresh ? (int)pov[u] : (int)(x < x1 ? x : x1 - 1);
         }
 #pragma unroll
-        for (int u = 0; u < FA_CPT; ++u) {
-            const long x = cb + (long)u * FA_T + tid;
+        for (int u = 0; u < CPT; ++u) {
+            const long x = cb + (long)u * T + tid;
             const bool head = x < x1 && !(merge && (fl[u] & 1));
             GEnt &ge = gev[u];
             ge.n = 0; ge.cls0 = ge.cls1 = 0; ge.t0 = ge.t1 = 0.0; ge.gkey0 = ge.gkey1 = 0;
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
             }
         }
 #pragma unroll
-        for (int u = 0; u < FA_CPT; ++u) {
-            if (cb + (long)u * FA_T >= x1) break;          // uniform: this sub-chunk lies past the range
+        for (int u = 0; u < CPT; ++u) {
+            if (cb + (long)u * T >= x1) break;          // uniform: this sub-chunk lies past the range
             const GEnt &ge = gev[u];
             const bool isnew = newv[u];
             const int did = didv[u];
@@ -516,13 +516,13 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
                     }
                 }
                 __syncthreads();
-                if (tid == 0) s_run[0] += s_w1[par][0] + s_w1[par][1] + s_w1[par][2] + s_w1[par][3];
+                if (tid == 0) { uint32_t a = 0; for (int w = 0; w < T / 64; ++w) a += s_w1[par][w]; s_run[0] += a; }
                 continue;
             }
             // Rank of a new entry inside its class segment = entries of the same class at smaller x.  A cell holds a
             // class in at most one of its two slots, so the lanes of a wave are matched on both slots at once
             // (wave ballots, rs_scatter's scheme); every lane takes part in the ballots.
-            for (int i = tid; i < (FA_T / 64) * FA_NC; i += FA_T) (&s_wcnt[0][0])[i] = 0;
+            for (int i = tid; i < (T / 64) * FA_NC; i += T) (&s_wcnt[0][0])[i] = 0;
             __syncthreads();
             const bool has0 = ge.n > 0, has1 = ge.n > 1;
             const int c0 = has0 ? ge.cls0 : 0, c1 = has1 ? ge.cls1 : 0;
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
             __syncthreads();
             if (tid < FA_NC) {
                 uint32_t a = 0;
-                for (int w = 0; w < FA_T / 64; ++w) a += s_wcnt[w][tid];
+                for (int w = 0; w < T / 64; ++w) a += s_wcnt[w][tid];
                 s_run[tid] += a;
             }
             __syncthreads();
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
     }
     const uint32_t no = s_no < (uint32_t)FA_OLDMAX ? s_no : (uint32_t)FA_OLDMAX;
     if (s_no > (uint32_t)FA_OLDMAX && tid == 0) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
-    for (uint32_t e = tid; e < no; e += FA_T) {            // inside a class the old ids are distinct: rank by counting
+    for (uint32_t e = tid; e < no; e += T) {            // inside a class the old ids are distinct: rank by counting
         const int cls = o_cls[e], did = o_did[e];
         uint32_t cnt = 0;
         for (uint32_t q = 0; q < no; ++q) cnt += (o_cls[q] == cls && o_did[q] < did) ? 1u : 0u;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
     // Sequential sums (the order of spsparse sum()), one WAVE per segment: 64 values are loaded coalesced and the
     // chain is replayed from registers with v_readlane (every lane computes the identical sum), as k_seg_sums_wave
     // does; then the weights (k_weights) and, for the rows, the scaling.
-    for (int q = wave; q < ncls; q += FA_T / 64) {
+    for (int q = wave; q < ncls; q += T / 64) {
         const uint32_t b = eb + s_start[q], e = eb + s_start[q + 1];
         double sum = 0.0;
         for (uint32_t base = b; base < e; base += 64) {
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(FA_T) void k_fa_range(RgView rg, PlanView pl, MatSp
         __syncthreads();
         for (int q = 0; q < ncls; ++q) {
             const double mul = s_mul[q];
-            for (uint32_t k = eb + s_start[q] + tid; k < eb + s_start[q + 1]; k += FA_T) o.val[k] = mul * o.val[k];
+            for (uint32_t k = eb + s_start[q] + tid; k < eb + s_start[q + 1]; k += T) o.val[k] = mul * o.val[k];
         }
     }
 }
@@ -768,6 +768,35 @@ __global__ void k_fa_init(uint32_t *cnt) {
     if (threadIdx.x < 8) cnt[threadIdx.x] = threadIdx.x == 0 ? 0xffffffffu : 0u;
 }
 
+// Workgroup shape of the two per-range kernels, by the size of the ranges.  One workgroup owns one range; what bounds it is
+// latency (staged load rounds, ranking barriers, the sequential sums of one wave per class), so the chip wants many small
+// workgroups when there are many small ranges and few large ones otherwise.  Measured (ms per build, AvI / EvI):
+//   Antarctica 1 km x 1/2 deg (49 771 ranges of ~780 cells): 256 x 4 cells 1.53 / 2.10, 256 x 2 1.40 / 1.92, 128 x 2 1.26 / 1.74,
+//                                                            128 x 4 1.33 / 1.87, 64 x 4 1.32 / 2.12, 64 x 2 1.38 / 2.22
+//   1 km (553 ranges of ~7 900 cells):                       128 x 2 0.30 / 0.44, 256 x 4 0.24 / 0.32, 1024 x 4 0.34 / 0.37
+//   5 km (122 ranges of ~1 500: fewer workgroups than CUs):  128 x 2 0.096 / 0.142, 256 x 4 0.082 / 0.109, 1024 x 4 0.076 / 0.089
+// shape 0: 128 threads x 2 cells, 1: 256 x 4, 2: 1024 x 4 (tuning "assemble_range_shape" overrides; scratch/asm_shapes.py)
+static int fa_range_shape(long nX, int nAr) {
+    const int forced = get_tuning("assemble_range_shape", -1);
+    if (forced >= 0 && forced <= 2) return forced;
+    const long mean = nX / (nAr > 0 ? nAr : 1);
+    if (mean <= 1024 && nAr >= 2048) return 0;
+    if (mean > 1024 && nAr <= 256) return 2;            // at most one workgroup per CU: make it a big one
+    return 1;
+}
+#define FA_LAUNCH_COUNT(EP, ...)                                                                                        \
+    do {                                                                                                                \
+        if (fa_shape == 0) hipLaunchKernelGGL((k_fa_count<EP, 128, 2>), dim3(nAr), dim3(128), 0, st, __VA_ARGS__);      \
+        else if (fa_shape == 2) hipLaunchKernelGGL((k_fa_count<EP, 1024, 4>), dim3(nAr), dim3(1024), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((k_fa_count<EP, 256, 4>), dim3(nAr), dim3(256), 0, st, __VA_ARGS__);                    \
+    } while (0)
+#define FA_LAUNCH_RANGE(EP, EM, ...)                                                                                    \
+    do {                                                                                                                \
+        if (fa_shape == 0) hipLaunchKernelGGL((k_fa_range<EP, EM, 128, 2>), dim3(nAr), dim3(128), 0, st, __VA_ARGS__);  \
+        else if (fa_shape == 2) hipLaunchKernelGGL((k_fa_range<EP, EM, 1024, 4>), dim3(nAr), dim3(1024), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((k_fa_range<EP, EM, 256, 4>), dim3(nAr), dim3(256), 0, st, __VA_ARGS__);                \
+    } while (0)
+
 // ---- EvA / AvE (compute_EvA, RegridMatrices_Dynamic.cpp:254-332) -----------------------------------------------
 // EpvAp = EpvG * diag(1 / rowsum(GvAp)) * GvAp is a product over the exchange cells: entry (e, a) is the sum over the
 // cells x of atmosphere cell a that touch class e, in ascending x (Eigen walks column a of GvAp, whose rows are the
@@ -852,7 +881,8 @@ static bool fast_build_eva(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh
     // counters: [0] first out-of-range cell, [1] fallback flags, [3] classes, [4] terms, [5] atmosphere cells
     uint32_t *d_cnt = A.get<uint32_t>(8);
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
-    hipLaunchKernelGGL(k_fa_count<true>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, e_is_row ? 1 : 0, 0, d_cnt, d_cnt + 1, 1);
+    const int fa_shape = fa_range_shape(nX, nAr);
+    FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, e_is_row ? 1 : 0, 0, d_cnt, d_cnt + 1, 1);
     if (nAr > 4096) {
         exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
         exclusive_scan_u32(g.r_nent, g.ebase, (size_t)nAr, g.ebase + nAr, st);
@@ -900,7 +930,7 @@ static bool fast_build_eva(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh
     if (nE) {
         // T[e]: the terms go to their (class, x-order) slot of a scratch array, one wave per class adds them up in sequence
         FaOut os{nullptr, nullptr, A.get<double>(nterm), nullptr, S, sp->family, 0, 0, e_is_row ? 1 : 0};
-        hipLaunchKernelGGL((k_fa_range<true, false>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, 0, os, flags);
+        FA_LAUNCH_RANGE(true, false, rg, pl, *sp, g, p, 0, os, flags);
         EvaOut eo{w->rowptr.p, w->colind.p, row, w->val.p, rs, cs, atable.p};
         hipLaunchKernelGGL(k_eva_final, dim3(ceil_div(nAr, T)), dim3(T), 0, st, rg, pl, g, abase, S, e_is_row ? 1 : 0, eo, flags);
         IBH_HIP(hipGetLastError());
@@ -979,8 +1009,9 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     uint32_t *d_cnt = A.get<uint32_t>(8);
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     if (p.fresh) { p.pflag = A.get<uint8_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
-    if (uses_ep) hipLaunchKernelGGL(k_fa_count<true>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
-    else hipLaunchKernelGGL(k_fa_count<false>, dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
+    const int fa_shape = fa_range_shape(nX, nAr);
+    if (uses_ep) FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
+    else FA_LAUNCH_COUNT(false, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
     if (p.fresh) exclusive_scan_u8(p.pflag, p.poff, (size_t)nX, d_cnt + 2, st);
     if (nAr > 4096) {                                           // many ranges: the device-wide scan; few: one workgroup, one launch
         exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
@@ -1032,8 +1063,8 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         // (a set numbered by this build: every member's Mw is written by k_fa_range / k_fa_pelem<SUMS>; an identity set has
         // non-members -- masked cells -- whose Mw stays 0)
         if (ncol && !p.fresh) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
-        if (uses_ep) hipLaunchKernelGGL((k_fa_range<true, true>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, o, flags);
-        else hipLaunchKernelGGL((k_fa_range<false, true>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, o, flags);
+        if (uses_ep) FA_LAUNCH_RANGE(true, true, rg, pl, *sp, g, p, merge, o, flags);
+        else FA_LAUNCH_RANGE(false, true, rg, pl, *sp, g, p, merge, o, flags);
         if (p.key == KEY_I && P.nmulti) {                     // Mw of the ice cells that straddle ranges (a few %)
             const dim3 gm(ceil_div(P.nmulti, T));
             if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags);
@@ -1051,8 +1082,8 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         FaOut os = o;
         os.val = A.get<double>(nnz);
         if (!g_fresh && ncol) hipLaunchKernelGGL(k_fa_zero_identity, dim3(ceil_div(ncol, T)), dim3(T), 0, st, w->Mw.p, (long)ncol);   // columns of the shared set this mask does not touch
-        if (uses_ep) hipLaunchKernelGGL((k_fa_range<true, false>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, os, flags);
-        else hipLaunchKernelGGL((k_fa_range<false, false>), dim3(nAr), dim3(T), 0, st, rg, pl, *sp, g, p, merge, os, flags);
+        if (uses_ep) FA_LAUNCH_RANGE(true, false, rg, pl, *sp, g, p, merge, os, flags);
+        else FA_LAUNCH_RANGE(false, false, rg, pl, *sp, g, p, merge, os, flags);
     }
     IBH_HIP(hipGetLastError());
     if (optimistic) {                                           // the one read-back of a small build: flags and the real sizes

@@ -112,6 +112,40 @@ def test_fast_and_general_assembly_paths_agree_with_the_oracle(config):
         icebin_amd.set_tuning("assemble_fast", 1)
 
 
+@pytest.mark.parametrize("shape", [0, 1, 2])
+def test_assembly_range_kernel_shapes_are_bit_identical(shape):
+    # the per-range kernels of the plan-based build exist in three workgroup shapes (128 x 2, 256 x 4, 1024 x 4 cells per pass,
+    # chosen by the size of the ranges: fastasm.inl fa_range_shape); every shape must give the oracle's bits -- ranges shorter
+    # and longer than one pass (g50: ~20 cells, g5: ~1 500), duplicates, zero areas, both interpolation styles
+    try:
+        icebin_amd.set_tuning("assemble_range_shape", shape)
+        for config, kw, style in (("g50", {}, 0), ("g50", dict(zero_area_every=7), 0), ("g50", {}, 1), ("g20", {}, 0)):
+            g = syn.make_grids(config, **kw)
+            g["interp_style"] = style
+            em = syn.dome_elevmask(g)
+            mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+            for scale, correctA in ((True, True), (False, False)):
+                rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
+                for name in ALL:
+                    w = rm.matrix(name)
+                    assert w.built_fast(), name
+                    assert_same_weighted(w, rg.matrix_d(name, em, scale=scale, correctA=correctA), "%s shape=%d %s" % (name, shape, config))
+        # 5 km: ranges of ~1 500 cells (several passes of the small shapes), against the default shape's bits
+        g = syn.make_grids("g5")
+        em = syn.dome_elevmask(g)
+        rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em, scale=True, correctA=True)
+        for name in ("AvI", "IvA", "EvI", "IvE", "EvA", "XvE"):
+            icebin_amd.set_tuning("assemble_range_shape", shape)
+            w = rm.matrix(name)
+            icebin_amd.set_tuning("assemble_range_shape", 1)
+            w1 = rm.matrix(name)
+            assert np.array_equal(w.dim(0), w1.dim(0)) and np.array_equal(w.dim(1), w1.dim(1)), name
+            for a, b in zip(w.csr_dense() + (w.wM, w.Mw), w1.csr_dense() + (w1.wM, w1.Mw)):
+                assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, b.view(np.uint64) if b.dtype == np.float64 else b), name
+    finally:
+        icebin_amd.set_tuning("assemble_range_shape", -1)
+
+
 @pytest.mark.parametrize("fast", [1, 0])
 def test_matrix_batch_equals_sequential_builds(fast):
     # ibh_regrid_matrices_matrix_batch: the coupler's per-step set (IceCoupler.cpp:361-468) in one call; independent builds
