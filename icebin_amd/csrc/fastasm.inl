@@ -635,8 +635,11 @@ __global__ __launch_bounds__(T) void k_fa_range(RgView rg, PlanView pl, MatSpec 
 
 // ---- one thread per P element (ice cell or exchange cell): its <= 8 entries --------------------------
 enum { FA_PSUMS = 0, FA_PCOUNT = 1, FA_PEMIT = 2 };
-template <bool WITH_EP, int MODE>
-__global__ __launch_bounds__(FA_T) void k_fa_pelem(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, long np, FaOut o,
+// ANYORDER: the G set may number the columns in some other order than this build would (a pre-populated dimE): the rows then
+// take the per-row selection branch below.  A set numbered by this build cannot, and the kernel without that branch fits the
+// 64 registers of full occupancy (a1h IvE 3.15 -> 3.04 ms, IvA 2.09 -> 1.94).
+template <bool WITH_EP, int MODE, bool ANYORDER>
+__global__ __launch_bounds__(FA_T, (WITH_EP && ANYORDER) ? 1 : 8) void k_fa_pelem(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, long np, FaOut o,
                                                     uint32_t *__restrict__ rowlen, uint32_t *__restrict__ flags) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     stage_hc<WITH_EP>(rg, s_hc);
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(FA_T) void k_fa_pelem(RgView rg, PlanView pl, MatSp
         if (o.correctA) v = v * rg.ratioA[iA];
         return v;
     };
-    if (sorted) {
+    if (sorted || !ANYORDER) {
         o.wM[d] = sum;
         int a = 0;
         visit([&](int id, double t, long iA) { o.colind[b0 + a] = id; o.val[b0 + a] = finish(t, iA); ++a; });
@@ -1067,18 +1070,24 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         else FA_LAUNCH_RANGE(false, true, rg, pl, *sp, g, p, merge, o, flags);
         if (p.key == KEY_I && P.nmulti) {                     // Mw of the ice cells that straddle ranges (a few %)
             const dim3 gm(ceil_div(P.nmulti, T));
-            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags);
-            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags);
+            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags);
+            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags);
         }
     } else {
         // rows = P: count -> scan -> emit per element; Mw (G columns) from the ranges through a scratch copy of the terms
         uint32_t *rowlen = A.get<uint32_t>((size_t)nrow + 1);
         if (optimistic && p.fresh) IBH_HIP(hipMemsetAsync(rowlen, 0, sizeof(uint32_t) * ((size_t)nrow + 1), st));   // rows beyond the real count
-        if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PCOUNT>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
-        else hipLaunchKernelGGL((k_fa_pelem<false, FA_PCOUNT>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+        if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+        else hipLaunchKernelGGL((k_fa_pelem<false, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
         exclusive_scan_u32(rowlen, reinterpret_cast<uint32_t *>(w->rowptr.p), (size_t)nrow, reinterpret_cast<uint32_t *>(w->rowptr.p) + nrow, st);
-        if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
-        else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+        // (a pre-populated G set may list the columns in another order: the variant with the per-row selection branch)
+        if (!g_fresh) {
+            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, true>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, true>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+        } else {
+            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+        }
         FaOut os = o;
         os.val = A.get<double>(nnz);
         if (!g_fresh && ncol) hipLaunchKernelGGL(k_fa_zero_identity, dim3(ceil_div(ncol, T)), dim3(T), 0, st, w->Mw.p, (long)ncol);   // columns of the shared set this mask does not touch
