@@ -397,7 +397,7 @@ struct FaOut {
     int g_rows;                     // SUMS only: the G side is the ROW side of the spec (EvA through the column-sum machinery)
 };
 template <bool WITH_EP, bool EMIT, int T, int CPT>
-__global__ __launch_bounds__(T) void k_fa_range(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, FaOut o,
+__global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, FaOut o,
                                                     uint32_t *__restrict__ flags) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     __shared__ int s_rank[FA_NC];
