@@ -160,9 +160,15 @@ struct ibh_plan {
     ibh::DevBuf<int32_t> ifirst;         // [nI] first exchange cell of the ice cell with area != 0, -1: none
     ibh::DevBuf<uint8_t> isdup;          // [nX] bit 0: same (iA, iI) as the cell before; bit 1: every exchange cell of this
                                          //      cell's ice cell lies in this range (the ice cell straddles no GCM-cell edge); bit 2: this
-                                         //      cell is the first-seen exchange cell of its ice cell (ifirst[iI] == x)
+                                         //      cell is the first-seen exchange cell of its ice cell (ifirst[iI] == x); bits 3 / 4: area > 0 /
+                                         //      area != 0 and not > 0
     ibh::DevBuf<int32_t> mlist;          // [nmulti] ice cells with exchange cells in more than one range
     int32_t nmulti = 0;
+    // [nI] matrix entries an UNMASKED ice cell has per elevation-class slot: groups of duplicate exchange cells (same (iA, iI))
+    // with a member of area > 0 (IvA: rows of GvAp) / area != 0 (IvE: rows of GvI); static, so the I-row builds count their
+    // rows without visiting the exchange cells.  Empty when an area is so small that area * weight could underflow
+    // (the count would then depend on the elevation): the builds count by visiting, as before.
+    ibh::DevBuf<uint8_t> icnt_pos, icnt_nz;
 };
 
 struct ibh_regridder {

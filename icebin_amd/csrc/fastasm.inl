@@ -40,6 +40,7 @@ struct PlanView {
                                 // cell of its ice cell, bit 3 area > 0, bit 4 area != 0 and not > 0
     const int32_t *mlist;       // ice cells spread over several ranges
     int nAr, nmulti;
+    const uint8_t *icnt_pos, *icnt_nz;      // static entry counts per ice cell (nullptr: count by visiting), see ibh_plan
 };
 
 // ---- static plan ---------------------------------------------------------------------------------
@@ -81,17 +82,27 @@ __global__ void k_plan_ikeys(const int32_t *__restrict__ exi, long nX, uint64_t 
 }
 __global__ void k_plan_ifirst(const int32_t *__restrict__ ilptr, const int32_t *__restrict__ ilist, const double *__restrict__ area,
                               const int32_t *__restrict__ aidx, long nI, int32_t *__restrict__ ifirst, uint8_t *__restrict__ isdup,
-                              uint32_t *__restrict__ multi, uint32_t *__restrict__ bad) {
+                              uint32_t *__restrict__ multi, uint32_t *__restrict__ bad, uint8_t *__restrict__ icnt_pos,
+                              uint8_t *__restrict__ icnt_nz, uint32_t *__restrict__ tiny) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nI) return;
     const int b = ilptr[i], e = ilptr[i + 1];
     if (e - b > FA_ILMAX) *bad = 1u;
     int f = -1;
     bool one = true;
+    int npos = 0, nnz = 0;
+    bool gpos = false, gnz = false;             // the current group of duplicates has a member with area > 0 / != 0
     for (int k = b; k < e; ++k) {
-        if (f < 0 && area[ilist[k]] != 0) f = ilist[k];
+        const double a = area[ilist[k]];
+        if (f < 0 && a != 0) f = ilist[k];
         one = one && aidx[ilist[k]] == aidx[ilist[b]];
+        if (!(isdup[ilist[k]] & 1)) { npos += gpos ? 1 : 0; nnz += gnz ? 1 : 0; gpos = gnz = false; }     // a new group starts
+        gpos = gpos || a > 0;
+        gnz = gnz || a != 0;
+        if (a != 0 && fabs(a) < 1e-290) *tiny = 1u;           // area * class weight could underflow to zero: no static count
     }
+    npos += gpos ? 1 : 0; nnz += gnz ? 1 : 0;
+    icnt_pos[i] = (uint8_t)npos; icnt_nz[i] = (uint8_t)nnz;
     ifirst[i] = f;
     if (f >= 0) isdup[f] |= 4;                                     // "this exchange cell is the first-seen one of its ice cell": spares the builds the ifirst gather
     if (one) for (int k = b; k < e; ++k) isdup[ilist[k]] |= 2;     // exchange cells of one ice cell: no two threads share a byte's bits... (own cells only)
@@ -141,12 +152,18 @@ static bool ensure_plan(const ibh_regridder *g, hipStream_t st) {
     rowptr_from_rows(srow, nX, (int)nI, P.ilptr.p, st);
     hipLaunchKernelGGL(k_u32_to_i32, dim3(ceil_div(nX, T)), dim3(T), 0, st, v, nX, P.ilist.p);
     uint32_t *multi = A.get<uint32_t>((size_t)nI), *mpos = A.get<uint32_t>((size_t)nI);
+    uint32_t *d_tiny = A.get<uint32_t>(1);
+    IBH_HIP(hipMemsetAsync(d_tiny, 0, sizeof(uint32_t), st));
+    P.icnt_pos.alloc((size_t)nI); P.icnt_nz.alloc((size_t)nI);
     hipLaunchKernelGGL(k_plan_ifirst, dim3(ceil_div(nI, T)), dim3(T), 0, st, P.ilptr.p, P.ilist.p, g->ex_area.p, P.aidx.p, nI, P.ifirst.p,
-                       P.isdup.p, multi, d_cnt + 1);
+                       P.isdup.p, multi, d_cnt + 1, P.icnt_pos.p, P.icnt_nz.p, d_tiny);
     exclusive_scan_u32(multi, mpos, (size_t)nI, d_cnt, st);
     IBH_HIP(hipGetLastError());
     readback_sync(h, d_cnt, sizeof(h), st);
     if (h[1]) return false;
+    uint32_t h_tiny = 0;
+    IBH_HIP(hipMemcpy(&h_tiny, d_tiny, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (h_tiny) { P.icnt_pos.release(); P.icnt_nz.release(); }
     P.nmulti = (int32_t)h[0];
     P.mlist.alloc((size_t)P.nmulti);
     if (P.nmulti) hipLaunchKernelGGL(k_plan_mlist, dim3(ceil_div(nI, T)), dim3(T), 0, st, multi, mpos, nI, P.mlist.p);
@@ -665,6 +682,19 @@ __global__ __launch_bounds__(FA_T, (WITH_EP && ANYORDER) ? 1 : 8) void k_fa_pele
     }
     if (d < 0) return;
     (void)flags;
+    if (MODE == FA_PCOUNT && p.key == KEY_I && pl.icnt_pos) {
+        // entries of an ice cell's row: one per group of duplicate exchange cells that contributes, times the elevation
+        // classes its elevation lies between -- the groups are static (plan), the classes a function of the mask value
+        uint32_t n = 0;
+        if (lb < le) {                                        // (unmasked)
+            if (WITH_EP) {
+                const XCell c = make_cell<WITH_EP>(rg, 0, q, 1.0, e);
+                n = c.range_error ? 0u : (uint32_t)c.nep * pl.icnt_nz[q];
+            } else n = pl.icnt_pos[q];
+        }
+        rowlen[d] = n;
+        return;
+    }
     const bool g_is_row = MODE == FA_PSUMS;                  // SUMS: the matrix has G rows (AEvI); COUNT / EMIT: G columns (IvAE)
     // The element's entries are visited group by group (ascending x = ascending range = ascending G dense id when
     // the G set was numbered by this build; inside a group the two classes go by their rank).  No private arrays:
@@ -869,7 +899,8 @@ static bool fast_build_eva(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh
     Arena &A = arena();
     A.reset();
     const ibh_plan &P = gr->plan;
-    PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti};
+    PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti,
+                get_tuning("assemble_static_count", 1) ? P.icnt_pos.p : nullptr, P.icnt_nz.p};
     const long nX = gr->nX;
     const int T = FA_T, nAr = P.nAr;
     FaG g{};
@@ -995,7 +1026,8 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     Arena &A = arena();
     A.reset();
     const ibh_plan &P = gr->plan;
-    PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti};
+    PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti,
+                get_tuning("assemble_static_count", 1) ? P.icnt_pos.p : nullptr, P.icnt_nz.p};
     const long nX = gr->nX;
     const int T = FA_T, nAr = P.nAr;
     FaG g{};
