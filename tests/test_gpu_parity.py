@@ -119,6 +119,9 @@ def test_assembly_range_kernel_shapes_are_bit_identical(shape):
     # and longer than one pass (g50: ~20 cells, g5: ~1 500), duplicates, zero areas, both interpolation styles
     try:
         icebin_amd.set_tuning("assemble_range_shape", shape)
+        # (shape 1 also with the row counts of the I-row builds taken by VISITING the exchange cells instead of from the plan's
+        # static per-ice-cell counts: the path a grid with underflow-sized areas takes)
+        icebin_amd.set_tuning("assemble_static_count", 0 if shape == 1 else 1)
         for config, kw, style in (("g50", {}, 0), ("g50", dict(zero_area_every=7), 0), ("g50", {}, 1), ("g20", {}, 0)):
             g = syn.make_grids(config, **kw)
             g["interp_style"] = style
@@ -144,6 +147,7 @@ def test_assembly_range_kernel_shapes_are_bit_identical(shape):
                 assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, b.view(np.uint64) if b.dtype == np.float64 else b), name
     finally:
         icebin_amd.set_tuning("assemble_range_shape", -1)
+        icebin_amd.set_tuning("assemble_static_count", 1)
 
 
 @pytest.mark.parametrize("fast", [1, 0])
