@@ -355,6 +355,82 @@ __global__ __launch_bounds__(T) void k_fa_count(RgView rg, PlanView pl, MatSpec 
         if (no > (uint32_t)FA_OLDMAX) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
     }
 }
+// ---- the same counts for ONE-class matrices (AvI, AvX, IvA, XvA: the G side is the atmosphere grid, no elevation classes),
+// streamed: a thread owns exchange cells, not a range.  k_fa_count gives every range a workgroup that walks it pass by pass --
+// two dependent load rounds per pass, a barrier-fenced epilogue -- which is latency, not bytes (2.8 TB/s at best; at 1 km only
+// 553 workgroups exist at all).  Here every wave takes 64 consecutive cells, reads them once, and adds what it found to the
+// range's counters: lanes are sorted by range (the grid is sorted by (iA, iI)), so a wave holds a few runs and the first lane
+// of each run issues the run's integer atomics (sums of integers: the result does not depend on the order).
+__global__ void k_fa_zero_counts(uint32_t *__restrict__ a, uint32_t *__restrict__ b, uint32_t *__restrict__ c, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = 0; b[i] = 0; c[i] = 0; }
+}
+template <int CPT>
+__global__ __launch_bounds__(256) void k_fa_count_stream(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int g_is_row, int merge) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1);
+    const long cb = (long)blockIdx.x * (256 * CPT);
+    int iAv[CPT], iIv[CPT], rv[CPT];
+    unsigned fl[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const long x = cb + (long)u * 256 + threadIdx.x;
+        const long xx = x < rg.nX ? x : rg.nX - 1;
+        iAv[u] = rg.exi[2 * xx]; iIv[u] = rg.exi[2 * xx + 1]; fl[u] = pl.isdup[xx]; rv[u] = pl.aidx[xx];
+    }
+    double ev[CPT];
+    int ifv[CPT], x0v[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const long x = cb + (long)u * 256 + threadIdx.x;
+        ev[u] = rg.em[iIv[u]];
+        ifv[u] = p.key == KEY_I ? ((fl[u] & 4) ? (int)(x < rg.nX ? x : rg.nX - 1) : pl.ifirst[iIv[u]]) : 0;
+        x0v[u] = pl.arng[rv[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const long x = cb + (long)u * 256 + threadIdx.x;
+        const bool in = x < rg.nX;
+        bool member = false, cnew = false, cold = false;
+        if (in) {
+            const XCell c = make_cell<false>(rg, iAv[u], iIv[u], (fl[u] & 8) ? 1.0 : (fl[u] & 16) ? -1.0 : 0.0, ev[u]);
+            if (p.fresh) p.pflag[x] = (uint8_t)(p.key == KEY_I ? ((ifv[u] == (int32_t)x && c.unmasked) ? 1u : 0u) : fa_pflag_of<false>(rg, pl, p, c, x));
+            long k0, k1;
+            member = list_entries(c, x, g.list, g.key, k0, k1) > 0;
+            if (!(merge && (fl[u] & 1))) {
+                GEnt ge;
+                fa_group<false>(rg, pl, s, g_is_row != 0, merge != 0, c, x, ge);
+                const bool isnew = p.key != KEY_I || !p.fresh || ifv[u] >= x0v[u];
+                cnew = ge.n > 0 && isnew;
+                cold = ge.n > 0 && !isnew;
+            }
+        }
+        // runs of equal range inside the wave (lanes past the end form a run of their own: range id -1)
+        const int r = in ? rv[u] : -1;
+        const int rp = __shfl_up(r, 1, 64);
+        const unsigned long long heads = __ballot(lane == 0 || r != rp);
+        const unsigned long long bm = __ballot(member), bn = __ballot(cnew), bo = __ballot(cold);
+        if (in && ((heads >> lane) & 1)) {
+            const unsigned long long rest = lane == 63 ? 0ull : (heads >> (lane + 1));
+            const int end = rest ? lane + 1 + __builtin_ctzll(rest) : 64;
+            const unsigned long long run = (end == 64 ? ~0ull : ((1ull << end) - 1)) & ~(le_mask >> 1);
+            const unsigned nm = (unsigned)__popcll(bm & run), nn = (unsigned)__popcll(bn & run), no = (unsigned)__popcll(bo & run);
+            if (nm) atomicOr(&g.r_ncls[r], 1u);
+            if (nn) atomicAdd(&g.ecntn[r], nn);
+            if (no) atomicAdd(&g.ecnto[r], no);
+        }
+    }
+}
+__global__ void k_fa_count_fin(FaG g, int nAr, uint32_t *__restrict__ flags) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nAr) return;
+    const uint32_t memb = g.r_ncls[r], cn = g.ecntn[r], co = g.ecnto[r];
+    g.r_nent[r] = cn + co;
+    g.erank[r] = memb ? 0 : -1;
+    if (!memb && (cn + co)) atomicOr(flags, (uint32_t)FA_ERR_MISSING);       // entries of a class that was never listed: cannot happen
+    if (co > (uint32_t)FA_OLDMAX) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
+}
+
 // exclusive scans over the ranges (one workgroup: there are 10^2..10^5 ranges); tot[0] = classes, tot[1] = entries
 __device__ __forceinline__ uint32_t fa_block_excl_scan_1024(uint32_t v, uint32_t *s_wave, uint32_t &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1045,7 +1121,13 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     if (p.fresh) { p.pflag = A.get<uint8_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
     const int fa_shape = fa_range_shape(nX, nAr);
-    if (uses_ep) FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
+    const bool stream_count = !uses_ep && g.NC == 1 && !g.tab && get_tuning("assemble_stream_count", nX >= (1l << 20) ? 1 : 0);
+    if (stream_count) {
+        // one-class matrices of large grids: cells streamed, counts by integer atomics (three launches, all short)
+        hipLaunchKernelGGL(k_fa_zero_counts, dim3(ceil_div(nAr, 256)), dim3(256), 0, st, g.r_ncls, g.ecntn, g.ecnto, nAr);
+        hipLaunchKernelGGL(k_fa_count_stream<4>, dim3(ceil_div(nX, 1024)), dim3(256), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge);
+        hipLaunchKernelGGL(k_fa_count_fin, dim3(ceil_div(nAr, 256)), dim3(256), 0, st, g, nAr, d_cnt + 1);
+    } else if (uses_ep) FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
     else FA_LAUNCH_COUNT(false, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
     if (p.fresh) exclusive_scan_u8(p.pflag, p.poff, (size_t)nX, d_cnt + 2, st);
     if (nAr > 4096) {                                           // many ranges: the device-wide scan; few: one workgroup, one launch

@@ -122,6 +122,9 @@ def test_assembly_range_kernel_shapes_are_bit_identical(shape):
         # (shape 1 also with the row counts of the I-row builds taken by VISITING the exchange cells instead of from the plan's
         # static per-ice-cell counts: the path a grid with underflow-sized areas takes)
         icebin_amd.set_tuning("assemble_static_count", 0 if shape == 1 else 1)
+        # (shape 2 also with the STREAMED count of the one-class matrices -- k_fa_count_stream, the default from 2^20 exchange
+        # cells on -- forced on these small grids)
+        icebin_amd.set_tuning("assemble_stream_count", 1 if shape == 2 else -2 ** 31)
         for config, kw, style in (("g50", {}, 0), ("g50", dict(zero_area_every=7), 0), ("g50", {}, 1), ("g20", {}, 0)):
             g = syn.make_grids(config, **kw)
             g["interp_style"] = style
@@ -148,6 +151,7 @@ def test_assembly_range_kernel_shapes_are_bit_identical(shape):
     finally:
         icebin_amd.set_tuning("assemble_range_shape", -1)
         icebin_amd.set_tuning("assemble_static_count", 1)
+        icebin_amd.set_tuning("assemble_stream_count", -2 ** 31)
 
 
 @pytest.mark.parametrize("fast", [1, 0])
