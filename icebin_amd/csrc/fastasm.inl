@@ -431,6 +431,13 @@ __global__ void k_fa_count_fin(FaG g, int nAr, uint32_t *__restrict__ flags) {
     if (co > (uint32_t)FA_OLDMAX) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
 }
 
+// Tried on top and dropped (measured on MI355X): the same streaming for the matrices WITH elevation classes -- counters per
+// (range, class), the lanes of a wave matched by key, atomicMin for the first-seen positions -- is correct (the suite passed)
+// but slower than the per-range workgroups: a1h EvI 1.72 -> 1.83 ms, 1 km EvI 0.32 -> 0.42 (the counters of a class take
+// thousands of global atomics each); letting the streamed count also add up the tiles of the flag scan that follows (one
+// atomic per wave, saving the scan's first pass) lost too (a1h AvI 1.04 -> 1.10); so did one chunked single-workgroup scan
+// over the ranges in place of two device-wide ones (a1h AvI 1.22 -> 1.27: 49 strided elements per thread).
+
 // exclusive scans over the ranges (one workgroup: there are 10^2..10^5 ranges); tot[0] = classes, tot[1] = entries
 __device__ __forceinline__ uint32_t fa_block_excl_scan_1024(uint32_t v, uint32_t *s_wave, uint32_t &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
