@@ -479,6 +479,58 @@ __global__ __launch_bounds__(1024) void k_fa_rscan(const uint32_t *__restrict__ 
         __syncthreads();
     }
 }
+// the same for MANY ranges (the Antarctic sheet: 49 771): three short launches for all channels together -- tile sums (one
+// range per thread), the scan of the <= 1024 tile sums, the tile-local scans -- in place of one device-wide scan per channel
+// plus a copy of each total (six kernels and three copies, ~45 us, for two channels).  Channel 2 (EvA / AvE: ranges that have
+// entries) is optional.
+__global__ __launch_bounds__(1024) void k_fa_rscan_tiles(const uint32_t *__restrict__ ncls, const uint32_t *__restrict__ nent, int nAr,
+                                                          int nch, uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_wave[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    for (int ch = 0; ch < nch; ++ch) {
+        const uint32_t v = i < nAr ? (ch == 0 ? ncls[i] : ch == 1 ? nent[i] : (nent[i] > 0 ? 1u : 0u)) : 0u;
+        uint32_t t;
+        (void)fa_block_excl_scan_1024(v, s_wave, t);
+        if (threadIdx.x == 0) sums[ch * gridDim.x + blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_fa_rscan_sums(uint32_t *__restrict__ sums, int nb, int nch, uint32_t *__restrict__ tot, uint32_t *__restrict__ tot_a) {
+    __shared__ uint32_t s_wave[16];
+    for (int ch = 0; ch < nch; ++ch) {
+        const uint32_t v = (int)threadIdx.x < nb ? sums[ch * nb + threadIdx.x] : 0u;
+        uint32_t t;
+        const uint32_t ex = fa_block_excl_scan_1024(v, s_wave, t);
+        if ((int)threadIdx.x < nb) sums[ch * nb + threadIdx.x] = ex;
+        if (threadIdx.x == 0) (ch == 2 ? tot_a : tot + ch)[0] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_fa_rscan_apply(const uint32_t *__restrict__ ncls, const uint32_t *__restrict__ nent, int nAr, int nch,
+                                                          const uint32_t *__restrict__ sums, const uint32_t *__restrict__ tot,
+                                                          const uint32_t *__restrict__ tot_a, uint32_t *__restrict__ gbase,
+                                                          uint32_t *__restrict__ ebase, uint32_t *__restrict__ abase) {
+    __shared__ uint32_t s_wave[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    for (int ch = 0; ch < nch; ++ch) {
+        const uint32_t v = i < nAr ? (ch == 0 ? ncls[i] : ch == 1 ? nent[i] : (nent[i] > 0 ? 1u : 0u)) : 0u;
+        uint32_t t;
+        const uint32_t ex = fa_block_excl_scan_1024(v, s_wave, t) + sums[ch * gridDim.x + blockIdx.x];
+        uint32_t *out = ch == 0 ? gbase : ch == 1 ? ebase : abase;
+        if (i < nAr) out[i] = ex;
+        if (i == nAr - 1) out[nAr] = (ch == 2 ? tot_a : tot + ch)[0];
+    }
+}
+// launches the three; false when there are too many ranges for one workgroup of tile sums (the caller scans channel by channel)
+static bool fa_rscan_many(const FaG &g, int nAr, uint32_t *abase, uint32_t *tot, uint32_t *tot_a, hipStream_t st) {
+    const int nb = ceil_div(nAr, 1024);
+    if (nb > 1024) return false;
+    const int nch = abase ? 3 : 2;
+    uint32_t *sums = arena().get<uint32_t>((size_t)nch * nb);
+    hipLaunchKernelGGL(k_fa_rscan_tiles, dim3(nb), dim3(1024), 0, st, g.r_ncls, g.r_nent, nAr, nch, sums);
+    hipLaunchKernelGGL(k_fa_rscan_sums, dim3(1), dim3(1024), 0, st, sums, nb, nch, tot, tot_a);
+    hipLaunchKernelGGL(k_fa_rscan_apply, dim3(nb), dim3(1024), 0, st, g.r_ncls, g.r_nent, nAr, nch, (const uint32_t *)sums, (const uint32_t *)tot,
+                       (const uint32_t *)tot_a, g.gbase, g.ebase, abase);
+    return true;
+}
 __device__ __forceinline__ int fa_gdense(const FaG &g, int r, int cls, long gkey) {
     if (g.tab) return g.tab[gkey];
     return (int)g.gbase[r] + (int)g.erank[(size_t)r * g.NC + cls];
@@ -1000,7 +1052,9 @@ static bool fast_build_eva(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     const int fa_shape = fa_range_shape(nX, nAr);
     FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, e_is_row ? 1 : 0, 0, d_cnt, d_cnt + 1, 1);
-    if (nAr > 4096) {
+    if (nAr > 4096 && fa_rscan_many(g, nAr, abase, d_cnt + 3, d_cnt + 5, st)) {
+        // (three short launches for the three channels)
+    } else if (nAr > 4096) {
         exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
         exclusive_scan_u32(g.r_nent, g.ebase, (size_t)nAr, g.ebase + nAr, st);
         uint32_t *has = A.get<uint32_t>((size_t)nAr);
@@ -1137,7 +1191,9 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     } else if (uses_ep) FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
     else FA_LAUNCH_COUNT(false, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
     if (p.fresh) exclusive_scan_u8(p.pflag, p.poff, (size_t)nX, d_cnt + 2, st);
-    if (nAr > 4096) {                                           // many ranges: the device-wide scan; few: one workgroup, one launch
+    if (nAr > 4096 && fa_rscan_many(g, nAr, nullptr, d_cnt + 3, nullptr, st)) {
+        // (many ranges: three short launches for both channels)
+    } else if (nAr > 4096) {                                    // very many: the device-wide scan; few: one workgroup, one launch
         exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
         exclusive_scan_u32(g.r_nent, g.ebase, (size_t)nAr, g.ebase + nAr, st);
         IBH_HIP(hipMemcpyAsync(d_cnt + 3, g.gbase + nAr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
