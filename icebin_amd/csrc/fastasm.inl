@@ -847,8 +847,11 @@ __global__ __launch_bounds__(FA_T, (WITH_EP && ANYORDER) ? 1 : 8) void k_fa_pele
             // COUNTING the entries of an ice cell without elevation classes needs nothing of the exchange cell but the sign
             // class of its area (plan bits 3 / 4): its ice cell is this element, the mask value is in hand -- no gather of
             // the cell's indices and area (IvA: the count pass reads the static lists only)
+            // (the column sums of an ice cell -- SUMS, one-class matrices -- need the area itself, still no indices / mask gathers)
             const XCell c = (!WITH_EP && MODE == FA_PCOUNT && p.key == KEY_I)
                                 ? make_cell<false>(rg, 0, q, (fx & 8) ? 1.0 : (fx & 16) ? -1.0 : 0.0, e)
+                            : (!WITH_EP && MODE == FA_PSUMS && p.key == KEY_I && !g.tab)
+                                ? make_cell<false>(rg, 0, q, rg.area[x], e)
                                 : load_cell<WITH_EP>(rg, x);
             if (WITH_EP && c.range_error) continue;
             GEnt ge;
