@@ -169,6 +169,9 @@ struct ibh_plan {
     // rows without visiting the exchange cells.  Empty when an area is so small that area * weight could underflow
     // (the count would then depend on the elevation): the builds count by visiting, as before.
     ibh::DevBuf<uint8_t> icnt_pos, icnt_nz;
+    // [nX] the ice-cell index of every exchange cell on its own (ex_indices interleaves it with the atmosphere index, which is
+    // constant over a range): the per-range kernels and the streamed count read 4 bytes per cell instead of 8
+    ibh::DevBuf<int32_t> exI;
 };
 
 struct ibh_regridder {

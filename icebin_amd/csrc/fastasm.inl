@@ -41,14 +41,16 @@ struct PlanView {
     const int32_t *mlist;       // ice cells spread over several ranges
     int nAr, nmulti;
     const uint8_t *icnt_pos, *icnt_nz;      // static entry counts per ice cell (nullptr: count by visiting), see ibh_plan
+    const int32_t *exI;                     // ice-cell index per exchange cell (compact copy of ex_indices[:, 1])
 };
 
 // ---- static plan ---------------------------------------------------------------------------------
 __global__ void k_plan_flags(const int32_t *__restrict__ exi, const double *__restrict__ area, long nX, uint32_t *__restrict__ head,
-                             uint8_t *__restrict__ isdup, uint32_t *__restrict__ bad) {
+                             uint8_t *__restrict__ isdup, uint32_t *__restrict__ bad, int32_t *__restrict__ exI) {
     const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= nX) return;
     const int iA = exi[2 * x], iI = exi[2 * x + 1];
+    exI[x] = iI;
     bool h = true, d = false;
     if (x > 0) {
         const int pA = exi[2 * x - 2], pI = exi[2 * x - 1];
@@ -131,7 +133,8 @@ static bool ensure_plan(const ibh_regridder *g, hipStream_t st) {
     uint32_t *head = A.get<uint32_t>((size_t)nX), *hpos = A.get<uint32_t>((size_t)nX), *d_cnt = A.get<uint32_t>(2);
     IBH_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(uint32_t), st));
     P.isdup.alloc((size_t)nX);
-    hipLaunchKernelGGL(k_plan_flags, dim3(ceil_div(nX, T)), dim3(T), 0, st, g->ex_indices.p, g->ex_area.p, nX, head, P.isdup.p, d_cnt + 1);
+    P.exI.alloc((size_t)nX);
+    hipLaunchKernelGGL(k_plan_flags, dim3(ceil_div(nX, T)), dim3(T), 0, st, g->ex_indices.p, g->ex_area.p, nX, head, P.isdup.p, d_cnt + 1, P.exI.p);
     exclusive_scan_u32(head, hpos, (size_t)nX, d_cnt, st);
     uint32_t h[2];
     readback_sync(h, d_cnt, sizeof(h), st);
@@ -268,6 +271,7 @@ __global__ __launch_bounds__(T) void k_fa_count(RgView rg, PlanView pl, MatSpec 
     stage_hc<WITH_EP>(rg, s_hc);
     const int r = blockIdx.x;
     const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
+    const int iA_r = rg.exi[2 * x0];                          // the atmosphere cell of the whole range
     if (threadIdx.x < FA_NC) { s_first[threadIdx.x] = 0xffffffffu; s_cn[threadIdx.x] = 0; s_co[threadIdx.x] = 0; }
     __syncthreads();
     // CPT cells per thread and pass with their loads staged (exchange cell, then mask / first-seen position of the ice
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(T) void k_fa_count(RgView rg, PlanView pl, MatSpec 
         for (int u = 0; u < CPT; ++u) {
             const long x = cb + (long)u * T + threadIdx.x;
             const long xx = x < x1 ? x : x1 - 1;
-            iAv[u] = rg.exi[2 * xx]; iIv[u] = rg.exi[2 * xx + 1]; fl[u] = pl.isdup[xx];
+            iAv[u] = iA_r; iIv[u] = pl.exI[xx]; fl[u] = pl.isdup[xx];
             if (WITH_EP) av[u] = rg.area[xx];                   // (the class weights are products with the area)
         }
 #pragma unroll
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256) void k_fa_count_stream(RgView rg, PlanView pl,
     for (int u = 0; u < CPT; ++u) {
         const long x = cb + (long)u * 256 + threadIdx.x;
         const long xx = x < rg.nX ? x : rg.nX - 1;
-        iAv[u] = rg.exi[2 * xx]; iIv[u] = rg.exi[2 * xx + 1]; fl[u] = pl.isdup[xx]; rv[u] = pl.aidx[xx];
+        iAv[u] = 0; iIv[u] = pl.exI[xx]; fl[u] = pl.isdup[xx]; rv[u] = pl.aidx[xx];      // (the atmosphere index plays no part in a count)
     }
     double ev[CPT];
     int ifv[CPT], x0v[CPT];
@@ -561,6 +565,7 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
     stage_hc<WITH_EP>(rg, s_hc);
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
+    const int iA_r = rg.exi[2 * x0];                          // the atmosphere cell of the whole range
     const uint32_t eb = g.ebase[r];
     if (tid < FA_NC) {
         const bool in = tid < g.NC;
@@ -596,9 +601,11 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
         for (int u = 0; u < CPT; ++u) {
             const long x = cb + (long)u * T + tid;
             const long xx = x < x1 ? x : x1 - 1;
-            iAv[u] = rg.exi[2 * xx]; iIv[u] = rg.exi[2 * xx + 1]; av[u] = rg.area[xx]; fl[u] = pl.isdup[xx];
+            iAv[u] = iA_r; iIv[u] = pl.exI[xx]; av[u] = rg.area[xx]; fl[u] = pl.isdup[xx];
             pfv[u] = 0; pov[u] = 0;
-            if (p.fresh && (EMIT || p.key == KEY_X)) { pfv[u] = p.pflag[xx]; pov[u] = p.poff[xx]; }
+            // (ice keys: the first-occurrence flag is "first-seen cell of its ice cell (plan bit 2) and unmasked" -- no need to read
+            // it back -- and the dense id is fetched in the third round, for unmasked cells only)
+            if (p.fresh && p.key == KEY_X) { pfv[u] = p.pflag[xx]; pov[u] = p.poff[xx]; }
         }
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
@@ -609,9 +616,15 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
             const long x = cb + (long)u * T + tid;
-            // dense id of the ice cell = poff[its first-seen position]: already in hand (pov) when that is this cell
-            if (p.key == KEY_I) didv[u] = p.fresh ? ((EMIT && (fl[u] & 4)) ? (int)pov[u] : (int)p.poff[ifv[u] < 0 ? 0 : ifv[u]]) : iIv[u];
-            else didv[u] = p.fresh ? (int)pov[u] : (int)(x < x1 ? x : x1 - 1);
+            // dense id of the ice cell = poff[its first-seen position] (that is this cell itself for ~90 % of them)
+            if (p.key == KEY_I) {
+                const bool unm = !(ev[u] != ev[u]);
+                if (p.fresh) {
+                    const long at = (fl[u] & 4) ? (x < x1 ? x : x1 - 1) : (long)(ifv[u] < 0 ? 0 : ifv[u]);
+                    didv[u] = unm ? (int)p.poff[at] : 0;              // (a masked cell has no entries and is no member: its id is never used)
+                    if (EMIT && (fl[u] & 4) && unm && x < x1) { pfv[u] = 1; pov[u] = (unsigned)didv[u]; }
+                } else didv[u] = iIv[u];
+            } else didv[u] = p.fresh ? (int)pov[u] : (int)(x < x1 ? x : x1 - 1);
         }
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
@@ -1038,7 +1051,7 @@ static bool fast_build_eva(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh
     A.reset();
     const ibh_plan &P = gr->plan;
     PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti,
-                get_tuning("assemble_static_count", 1) ? P.icnt_pos.p : nullptr, P.icnt_nz.p};
+                get_tuning("assemble_static_count", 1) ? P.icnt_pos.p : nullptr, P.icnt_nz.p, P.exI.p};
     const long nX = gr->nX;
     const int T = FA_T, nAr = P.nAr;
     FaG g{};
@@ -1167,7 +1180,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     A.reset();
     const ibh_plan &P = gr->plan;
     PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti,
-                get_tuning("assemble_static_count", 1) ? P.icnt_pos.p : nullptr, P.icnt_nz.p};
+                get_tuning("assemble_static_count", 1) ? P.icnt_pos.p : nullptr, P.icnt_nz.p, P.exI.p};
     const long nX = gr->nX;
     const int T = FA_T, nAr = P.nAr;
     FaG g{};
