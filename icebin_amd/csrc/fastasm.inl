@@ -13,7 +13,8 @@
 // A build is then a handful of streaming kernels instead of three generator passes + scan + ordering +
 // segment sums + column slots (~45 launches):
 //   numbering  first-occurrence flags (written by k_fa_count) -> scan       (ice / exchange keys; skipped for identity dims)
-//              k_fa_count (one workgroup per range) -> k_fa_rscan    (A / E keys, entry counts)
+//              k_fa_count (one workgroup per range; one-class matrices of large grids: k_fa_count_stream, a thread per
+//              cell) -> k_fa_rscan / fa_rscan_many                          (A / E keys, entry counts)
 //   A/E rows   k_fa_range<EMIT>: every entry is written straight to its CSR slot -- inside a row the
 //              columns first seen in this range ascend in x order (rank = a per-class running count),
 //              only the ice cells that straddle in from an earlier range (a few %) are ranked in LDS --
@@ -24,14 +25,14 @@
 // Every sum runs in the order the general pipeline (and the oracle) uses -- duplicates in emission
 // order with the first term assigned, row sums by ascending column, column sums by ascending row -- so
 // the results are bit-identical; the general pipeline remains the fallback for unsorted grids,
-// partially pre-populated dims, EvA / AvE, and anything a limit below excludes.
+// partially pre-populated dims, EvA / AvE on pre-populated sets, and anything a limit below excludes.
+// EvA / AvE on fresh sets: fast_build_eva (count -> range sums -> one thread per range).
 
 constexpr int FA_NC = 64;           // elevation classes per range (nhc <= 64)
 constexpr int FA_ILMAX = 8;         // exchange cells per ice cell
 constexpr int FA_DUPMAX = 4;        // consecutive cells with the same (iA, iI)
 constexpr int FA_OLDMAX = 512;      // straddling entries of one range ranked in LDS
-constexpr int FA_T = 256;
-constexpr int FA_CPT = 4;          // exchange cells per thread and pass of the range kernel
+constexpr int FA_T = 256;          // threads per workgroup of the per-element kernels (the per-range kernels: fa_range_shape)
 enum { FA_ERR_OLDOVER = 1, FA_ERR_MISSING = 2 };
 
 struct PlanView {
