@@ -97,6 +97,9 @@ _SIGS = {
                                 C.c_void_p]),
     "ibh_weighted_reserve": (C.c_int, [C.c_void_p, C.c_int32]),
     "ibh_weighted_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "ibh_weighted_pair_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "ibh_weighted_apply_pair_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
+                                               C.c_void_p, C.c_int64, C.c_double, C.c_void_p]),
     "ibh_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ibh_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "ibh_comm_create_custom": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -537,6 +537,23 @@ int ibh_weighted_prepare(const ibh_weighted *w, int32_t nvar, int32_t nbatch) {
         weighted_prepare(w, nvar, nbatch);
     });
 }
+int ibh_weighted_pair_prepare(const ibh_weighted *first, const ibh_weighted *second, int32_t nvar) {
+    return guarded([&] {
+        check_weighted_device(first);
+        check_weighted_device(second);
+        IBH_CHECK(nvar >= 0, "bad arguments");
+        weighted_pair_prepare(first, second, nvar);
+    });
+}
+int ibh_weighted_apply_pair_device(const ibh_weighted *first, const ibh_weighted *second, const double *dA, int32_t nvar, int64_t lda,
+                                   double *dB1, int64_t ldb1, double *dB2, int64_t ldb2, double fill, void *stream) {
+    return guarded([&] {
+        check_weighted_device(first);
+        check_weighted_device(second);
+        IBH_CHECK(nvar >= 0 && (nvar == 0 || (dA && dB1 && dB2)), "bad arguments");
+        spmm_launch_pair(first, second, dA, nvar, lda, dB1, ldb1, dB2, ldb2, fill, static_cast<hipStream_t>(stream));
+    });
+}
 int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nvar, int64_t lda, double *B_b,
                             int64_t ldb, double fill, int force_conservation) {
     return guarded([&] {

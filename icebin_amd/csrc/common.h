@@ -243,6 +243,14 @@ struct ibh_weighted {
     // set of a group is the AvI row of its GCM cell, so X is gathered once per (GCM cell, ice cell) instead of once per class;
     // slot s of group g is row grp_slotrow[g * IBH_GSLOTS + s].  Built from the CSR (assemble.hip build_groups_from_csr).
     mutable int grp_tried = 0;
+    // fused pair (ibh_weighted_pair_prepare): a second matrix whose every row reads rows of ONE group of this matrix only (AvE
+    // after EvI: a GCM cell's value is a combination of that cell's elevation classes) rides in the row-group kernel's epilogue.
+    // pair_w[g * IBH_GSLOTS + s]: the second matrix's weight of slot s of group g (pair_mask[g] bit s: it has one);
+    // pair_row[g]: the second matrix's row fed by group g, -1 none.
+    mutable const ibh_weighted *pair_second = nullptr;
+    mutable ibh::DevBuf<double> pair_w;
+    mutable ibh::DevBuf<uint32_t> pair_mask;
+    mutable ibh::DevBuf<int32_t> pair_row;
     mutable int32_t grp_n = 0, grp_nslot = 0, grp_nitems = 0;          // groups (0: not built), most rows in a group, items
     mutable ibh::DevBuf<int32_t> grp_ptr, grp_ns, grp_slotrow, grp_col; // [grp_n+1] items of a group; [grp_n] rows of a group; [grp_n*IBH_GSLOTS]; [nitems]
     mutable ibh::DevBuf<uint32_t> grp_meta;
@@ -270,6 +278,9 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
                       double *const *dB, int64_t ldb, double fill, int force_conservation, hipStream_t stream);
 void weighted_reserve(const ibh_weighted *w, int nvar);
 void weighted_prepare(const ibh_weighted *w, int nvar, int nbatch);
+void weighted_pair_prepare(const ibh_weighted *first, const ibh_weighted *second, int nvar);
+void spmm_launch_pair(const ibh_weighted *first, const ibh_weighted *second, const double *dA, int nvar, int64_t lda, double *dB1,
+                      int64_t ldb1, double *dB2, int64_t ldb2, double fill, hipStream_t stream);
 // assemble.hip: the band structure of an E-row matrix from its CSR (same result as building it with the matrix)
 void build_bands_from_csr(const ibh_weighted *w, hipStream_t st);
 // assemble.hip: the column-sweep structure of an E-row matrix from its CSR (sweep_kernel.inl); false: not representable

@@ -474,9 +474,19 @@ struct GroupView {
     int ngrp, nslot;
 };
 constexpr unsigned RG_HAS0 = 1u << 16, RG_HAS1 = 1u << 17;
-template <int NW, int U, int TW>
+// PAIR: a second matrix applied to this one's result in the epilogue (ibh_weighted_apply_pair_device; see ibh_weighted::pair_*)
+struct PairView {
+    const double *w;
+    const unsigned *mask;
+    const int *row;
+    const double *wM2;
+    double *Y2;
+    long ldy2;
+};
+template <int NW, int U, int TW, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView gv, const BatchPtrs bp, long ldx, int ncol, long ldy, int nf,
-                                                               int nfc, int xcd_mode, const double *__restrict__ wM, double fill)
+                                                               int nfc, int xcd_mode, const double *__restrict__ wM, double fill,
+                                                               const PairView pv = PairView{})
 {
     constexpr int T = NW * 64, SEG = U * 64, ST = SEG / T;
     static_assert(SEG % T == 0, "segment is a multiple of the workgroup");
@@ -587,9 +597,23 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView 
         for (int j = 0; j < HW; ++j) tot += row[(j + lane) & (HW - 1)];
     }
     tot += __shfl_xor(tot, 32, 64);
-    if (half == 0 && sl < ns && fw < nf) {
+    double y1 = 0.0;
+    if (half == 0 && sl < ns) {
         const int r = gv.slotrow[g * IBH_GSLOTS + sl];
-        Y[(long)fw * ldy + r] = wM[r] == 0.0 ? fill : tot;      // mask_result, IceCoupler.cpp:186-201
+        y1 = wM[r] == 0.0 ? fill : tot;                         // mask_result, IceCoupler.cpp:186-201
+        if (fw < nf) Y[(long)fw * ldy + r] = y1;
+    }
+    if (PAIR) {
+        // the second matrix's row of this group: lane s holds weight x (the value just stored for slot s), summed over the wave
+        // in the fixed order of wave_sum -- entry k of the row in lane k, as the row kernel holds it when the second matrix's
+        // columns are this group's rows in slot order
+        const int a2 = pv.row[g];
+        if (a2 >= 0) {
+            double v = 0.0;
+            if (half == 0 && sl < ns && ((pv.mask[g] >> sl) & 1u)) v = pv.w[g * IBH_GSLOTS + sl] * y1;
+            const double s2 = wave_sum(v);
+            if (lane == 0 && fw < nf) pv.Y2[(long)fw * pv.ldy2 + a2] = pv.wM2[a2] == 0.0 ? fill : s2;
+        }
     }
 }
 
@@ -932,7 +956,8 @@ static void launch_rowone(const ibh_weighted *w, const double *X, double *Y, int
 }
 
 template <int NW, int U, int TW>
-static void launch_rowgroup(const ibh_weighted *w, const BatchPtrs &bp, int nbatch, int nvar, long lda, long ldb, double fill, hipStream_t stream)
+static void launch_rowgroup(const ibh_weighted *w, const BatchPtrs &bp, int nbatch, int nvar, long lda, long ldb, double fill, hipStream_t stream,
+                            const PairView *pair = nullptr)
 {
     const int nfc = ceil_div(nvar, NW);
     int xcd_mode;
@@ -952,8 +977,13 @@ static void launch_rowgroup(const ibh_weighted *w, const BatchPtrs &bp, int nbat
             raised[w->device & 63] = true;
         }
     }
-    hipExtLaunchKernelGGL((spmm_rowgroup_kernel<NW, U, TW>), dim3((unsigned)nb, (unsigned)nbatch), dim3(NW * 64), lds, stream, ev0, ev1, 0, gv, bp,
-                          lda, w->ncol, ldb, nvar, nfc, xcd_mode, w->wM.p, fill);
+    if (pair) {
+        IBH_CHECK(lds <= 64 * 1024 && nbatch == 1, "fused pair apply: %zu bytes of LDS / %d batches not supported", lds, nbatch);
+        hipExtLaunchKernelGGL((spmm_rowgroup_kernel<NW, U, TW, true>), dim3((unsigned)nb, 1u), dim3(NW * 64), lds, stream, ev0, ev1, 0, gv, bp,
+                              lda, w->ncol, ldb, nvar, nfc, xcd_mode, w->wM.p, fill, *pair);
+    } else
+        hipExtLaunchKernelGGL((spmm_rowgroup_kernel<NW, U, TW>), dim3((unsigned)nb, (unsigned)nbatch), dim3(NW * 64), lds, stream, ev0, ev1, 0, gv, bp,
+                              lda, w->ncol, ldb, nvar, nfc, xcd_mode, w->wM.p, fill, PairView{});
     IBH_HIP(hipGetLastError());
 }
 
@@ -1256,6 +1286,103 @@ void weighted_prepare(const ibh_weighted *w, int nvar, int nbatch) {
     build_structures(w, nvar, nb, true, nullptr);
     size_scratch(w, nvar, nb);
     IBH_HIP(hipStreamSynchronize(nullptr));
+}
+
+// ---- fused pair: B1 = first * A, B2 = second * B1 in one launch (BASELINE config 3: EvI then AvE) --------------------------------
+// Possible when every row of `second` reads rows of ONE row group of `first` only -- AvE after EvI: the value of a GCM cell is a
+// combination of that cell's own elevation classes -- so the group's workgroup has all inputs of the second row in hand when
+// it has its class sums.  The pairing is worked out on the host (the second matrix is tiny: one entry per class) through the
+// SPARSE indices of the two matrices' shared dimension, so the two need not share a SparseSet object or a numbering.
+void weighted_pair_prepare(const ibh_weighted *first, const ibh_weighted *second, int nvar) {
+    IBH_CHECK(first && second && first != second, "pair: two different matrices expected");
+    IBH_CHECK(first->device == second->device, "pair: matrices live on different devices");
+    IBH_CHECK(second->ncol == first->nrow || second->dims[1], "pair: the second matrix's columns are not the first one's rows");
+    IBH_CHECK(second->nnz <= (1 << 22), "pair: the second matrix is too large (%ld entries) to be paired on the host", (long)second->nnz);
+    first->pair_second = nullptr;
+    if (first->grp_n == 0) {                                  // row groups first (small matrices get them from an explicit request only)
+        const int keep = first->kernel_override;
+        const_cast<ibh_weighted *>(first)->kernel_override = 5;
+        try { weighted_prepare(first, nvar > 0 ? nvar : 16, 1); } catch (...) { const_cast<ibh_weighted *>(first)->kernel_override = keep; throw; }
+        const_cast<ibh_weighted *>(first)->kernel_override = keep;
+    }
+    if (first->grp_n == 0) fail(IBH_ENOTIMPL, "pair: the first matrix has no row groups (not an elevation-class-row matrix, or its structure was declined)");
+    const int ngrp = first->grp_n;
+    std::vector<int32_t> slotrow((size_t)ngrp * IBH_GSLOTS), gns((size_t)ngrp), rp2((size_t)second->nrow + 1), ci2((size_t)second->nnz);
+    std::vector<double> v2((size_t)second->nnz);
+    IBH_HIP(hipMemcpy(slotrow.data(), first->grp_slotrow.p, slotrow.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    IBH_HIP(hipMemcpy(gns.data(), first->grp_ns.p, gns.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    IBH_HIP(hipMemcpy(rp2.data(), second->rowptr.p, rp2.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (second->nnz) {
+        IBH_HIP(hipMemcpy(ci2.data(), second->colind.p, ci2.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        IBH_HIP(hipMemcpy(v2.data(), second->val.p, v2.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    // first row (dense) -> (group, slot)
+    std::vector<int32_t> where_g((size_t)first->nrow, -1), where_s((size_t)first->nrow, -1);
+    for (int g = 0; g < ngrp; ++g)
+        for (int sl = 0; sl < gns[(size_t)g]; ++sl) {
+            const int r = slotrow[(size_t)g * IBH_GSLOTS + sl];
+            IBH_CHECK(r >= 0 && r < first->nrow, "pair: corrupt group table");
+            where_g[(size_t)r] = g; where_s[(size_t)r] = sl;
+        }
+    // second column (dense) -> first row (dense), through the sparse indices of the shared dimension
+    const ibh_sparse_set *d1 = first->dims[0], *d2 = second->dims[1];
+    const bool same_numbering = d1 == d2 || !d1 || !d2;
+    if (same_numbering) IBH_CHECK(second->ncol == first->nrow, "pair: extents differ (%d columns, %d rows)", second->ncol, first->nrow);
+    else {
+        if (d1->sparse_extent != d2->sparse_extent)
+            fail(IBH_ENOTIMPL, "pair: the second matrix's columns (extent %ld) are not the first one's rows (extent %ld)",
+                 (long)d2->sparse_extent, (long)d1->sparse_extent);
+        d1->ensure_inverse(); d2->ensure_host();
+    }
+    std::vector<double> pw((size_t)ngrp * IBH_GSLOTS, 0.0);
+    std::vector<uint32_t> pm((size_t)ngrp, 0u);
+    std::vector<int32_t> pr((size_t)ngrp, -1);
+    for (int a = 0; a < second->nrow; ++a) {
+        if (rp2[(size_t)a] == rp2[(size_t)a + 1]) fail(IBH_ENOTIMPL, "pair: row %d of the second matrix has no entries", a);
+        int grp = -1;
+        for (int k = rp2[(size_t)a]; k < rp2[(size_t)a + 1]; ++k) {
+            int r1 = ci2[(size_t)k];
+            if (!same_numbering) {
+                const auto it = d1->inv.find(d2->host[(size_t)r1]);
+                if (it == d1->inv.end()) fail(IBH_ENOTIMPL, "pair: a column of the second matrix is no row of the first");
+                r1 = it->second;
+            }
+            IBH_CHECK(r1 >= 0 && r1 < first->nrow, "pair: column out of range");
+            const int g = where_g[(size_t)r1], sl = where_s[(size_t)r1];
+            if (g < 0 || (grp >= 0 && g != grp)) fail(IBH_ENOTIMPL, "pair: row %d of the second matrix reads rows of more than one group of the first", a);
+            grp = g;
+            pw[(size_t)g * IBH_GSLOTS + sl] = v2[(size_t)k];
+            pm[(size_t)g] |= 1u << sl;
+        }
+        if (pr[(size_t)grp] >= 0) fail(IBH_ENOTIMPL, "pair: two rows of the second matrix read the same group of the first");
+        pr[(size_t)grp] = a;
+    }
+    first->pair_w.alloc(pw.size()); first->pair_mask.alloc(pm.size()); first->pair_row.alloc(pr.size());
+    IBH_HIP(hipMemcpy(first->pair_w.p, pw.data(), pw.size() * sizeof(double), hipMemcpyHostToDevice));
+    IBH_HIP(hipMemcpy(first->pair_mask.p, pm.data(), pm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    IBH_HIP(hipMemcpy(first->pair_row.p, pr.data(), pr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    first->pair_second = second;
+}
+
+void spmm_launch_pair(const ibh_weighted *first, const ibh_weighted *second, const double *dA, int nvar, int64_t lda, double *dB1,
+                      int64_t ldb1, double *dB2, int64_t ldb2, double fill, hipStream_t stream)
+{
+    IBH_CHECK(first->pair_second == second && first->grp_n > 0, "pair apply: call ibh_weighted_pair_prepare(first, second, nvar) first");
+    if (nvar <= 0 || first->nrow == 0) return;
+    IBH_CHECK(lda >= first->ncol && ldb1 >= first->nrow && ldb2 >= second->nrow, "pair apply: leading dimensions (%ld, %ld, %ld) too small",
+              (long)lda, (long)ldb1, (long)ldb2);
+    IBH_CHECK(first->conservative && second->conservative, "pair apply: smoothed (non-conservative) matrices take separate applies");
+    BatchPtrs bp{};
+    bp.x[0] = dA; bp.y[0] = dB1;
+    const PairView pv{first->pair_w.p, first->pair_mask.p, first->pair_row.p, second->wM.p, dB2, (long)ldb2};
+    const int nw = get_tuning("rowgroup_waves", nvar >= 32 ? 8 : 4), tw = get_tuning("rowgroup_tw", first->nnz < (1 << 20) ? 32 : 64);
+#define IBH_RGP(N, TT) launch_rowgroup<N, 8, TT>(first, bp, 1, nvar, (long)lda, (long)ldb1, fill, stream, &pv)
+    if (nw == 8) { if (tw == 32) IBH_RGP(8, 32); else IBH_RGP(8, 64); }
+    else { if (tw == 32) IBH_RGP(4, 32); else IBH_RGP(4, 64); }
+#undef IBH_RGP
+    first->last_kernel = 5;
+    second->last_kernel = 5;
+    ++first->napply; ++second->napply;
 }
 
 static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &bp, int nbatch, int nvar, int64_t lda,

@@ -333,6 +333,14 @@ public:
         only enqueue work (ibh_weighted_prepare).  Once per matrix, e.g. right after matrix_d() in a coupler that
         applies the matrix more than once per step, and before capturing applies into a hipGraph. */
     void prepare(int nvar, int nbatch = 1) const { check(ibh_weighted_prepare(h_, nvar, nbatch)); }
+    /** Fused pair B1 = (*this) * A, B2 = second * B1 in one launch (EvI then AvE; ibh_weighted_pair_prepare /
+        ibh_weighted_apply_pair_device).  pair_prepare throws Exception(IBH_ENOTIMPL) when the matrices do not pair: make the two
+        apply() calls of the reference then. */
+    void pair_prepare(Weighted const &second, int nvar = 16) const { check(ibh_weighted_pair_prepare(h_, second.h_, nvar)); }
+    void apply_pair_device(Weighted const &second, const double *dA_b, int nvar, long lda, double *dB1_b, long ldb1, double *dB2_b,
+                           long ldb2, double fill, void *stream) const {
+        check(ibh_weighted_apply_pair_device(h_, second.h_, dA_b, nvar, lda, dB1_b, ldb1, dB2_b, ldb2, fill, stream));
+    }
     /** apply() of world x nvar_local fields sharded by field over the ranks of `comm`: this rank's dA_local (nvar_local x lda)
         -> dB_all (world*nvar_local x ldb, the same on every rank once comm.wait(stream) has been honoured).  The SpMM runs on
         `stream`, the peer-to-peer exchange on the communicator's own stream, block_fields fields at a time (0: by size). */

@@ -273,6 +273,31 @@ class linear_Weighted:
         hipGraph or when the latency of the first applies matters."""
         check(lib().ibh_weighted_prepare(self._h, int(nvar), int(nbatch)))
 
+    def pair_prepare(self, second, nvar=16):
+        """Prepare the fused pair  B1 = self * A,  B2 = second * B1  (ibh_weighted_pair_prepare): EvI followed by AvE.
+        Raises IcebinHipError (IBH_ENOTIMPL) when the two matrices do not pair; then make two applies."""
+        check(lib().ibh_weighted_pair_prepare(self._h, second._h, int(nvar)))
+        self._pair = second          # (keeps the second handle alive as long as the pairing)
+
+    def apply_pair_device(self, second, dA, out1=None, out2=None, fill=float("nan"), stream=None):
+        """One launch for both products (ibh_weighted_apply_pair_device); returns (B1, B2).  B1 is bitwise apply_device's
+        result, B2 = second.apply_device(B1, force_conservation=False) to 1e-12."""
+        import torch
+        assert dA.is_cuda and dA.dtype == torch.float64 and dA.dim() == 2 and dA.stride(1) == 1 and dA.shape[1] == self.ncol_d
+        nvar = dA.shape[0]
+        if out1 is None:
+            out1 = _aligned_planes(torch, nvar, self.nrow_d, dA.device)
+        if out2 is None:
+            out2 = _aligned_planes(torch, nvar, second.nrow_d, dA.device)
+        for o, n in ((out1, self.nrow_d), (out2, second.nrow_d)):
+            assert o.is_cuda and o.dtype == torch.float64 and o.shape == (nvar, n) and o.stride(1) == 1
+        s = torch.cuda.current_stream(dA.device).cuda_stream if stream is None else stream
+        ld = lambda t, n: t.stride(0) if nvar > 1 else max(t.stride(0), n)
+        check(lib().ibh_weighted_apply_pair_device(self._h, second._h, C.c_void_p(dA.data_ptr()), nvar, ld(dA, self.ncol_d),
+                                                  C.c_void_p(out1.data_ptr()), ld(out1, self.nrow_d), C.c_void_p(out2.data_ptr()),
+                                                  ld(out2, second.nrow_d), float(fill), C.c_void_p(s)))
+        return out1, out2
+
     def apply_transformed_device(self, dV, T, b, out=None, fill=float("nan"), stream=None):
         """The coupler's fused product  M * (V*T + b)  on HBM-resident fields (IceCoupler.cpp:203-252,
         :445): dV torch.float64 CUDA [nvar_in, ncol_d]; T [nvar_in, nvar_out] (the sparse variable

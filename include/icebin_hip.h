@@ -246,6 +246,20 @@ int ibh_weighted_apply_many_device(const ibh_weighted *w, int32_t nbatch, const 
  * applies of a prepared handle run the same kernels and are bitwise equal.
  * ibh_weighted_reserve(w, nvar) only sizes scratch for single applies (nbatch = 1) and builds nothing. */
 int ibh_weighted_prepare(const ibh_weighted *w, int32_t nvar, int32_t nbatch);
+
+/* Fused pair: B1 = first * A and B2 = second * B1 in ONE launch -- the step "ice -> elevation classes -> atmosphere" of a
+ * coupler (E = EvI * I, A = AvE * E; the reference makes two Weighted_Eigen::apply calls, ibmisc linear/eigen.cpp, one per
+ * matrix: RegridMatrices_Dynamic.cpp:354-390 hands out the two matrices).  Possible when every row of `second` reads rows of one
+ * row group of `first` only, which AvE after EvI does by construction (a GCM cell's value combines that cell's own elevation
+ * classes); the rows need not be numbered alike (the pairing goes through the sparse indices of the shared dimension).
+ * ibh_weighted_pair_prepare builds `first`'s row groups if it has none, works the pairing out on the host (synchronises) and
+ * returns IBH_ENOTIMPL when the two matrices do not pair -- the caller then makes two applies.  ibh_weighted_apply_pair_device is
+ * a pure enqueue (graph-capturable); B1 is bitwise what ibh_weighted_apply_device(first) writes, B2 is the second matrix's
+ * result with the same fill / wM == 0 rule, summed in a fixed order (1e-12 of the separate apply, bitwise when `second` lists
+ * its columns in the order of `first`'s rows).  Conservative matrices only (no smoothing). */
+int ibh_weighted_pair_prepare(const ibh_weighted *first, const ibh_weighted *second, int32_t nvar);
+int ibh_weighted_apply_pair_device(const ibh_weighted *first, const ibh_weighted *second, const double *dA_b, int32_t nvar, int64_t lda,
+                                   double *dB1_b, int64_t ldb1, double *dB2_b, int64_t ldb2, double fill, void *stream);
 int ibh_weighted_reserve(const ibh_weighted *w, int32_t nvar);
 /* The coupler's fused product B = M * (A*T + b) (IceCoupler.cpp:203-252 construct_ice_ivalsI and
  * :445 gcm_ivalsX = M * (ice_ovalsI*T + b)): dA_b [nvar_in x ncol_d] field-major device pointer,

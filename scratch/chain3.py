@@ -61,6 +61,41 @@ e1.record(); torch.cuda.synchronize()
 graph_us = e0.elapsed_time(e1) * 1e3 / N
 same = bool(torch.equal(yI.view(torch.int64), ref.view(torch.int64)))
 B = sum(12 * w.nnz + 4 * (w.nrow_d + 1) + 8 * nf * (w.ncol_d + w.nrow_d) for w in W.values())
+# (c) EvI and AvE as ONE launch (ibh_weighted_apply_pair_device: AvE rides in the row-group kernel's epilogue), then IvA
+W["EvI"].pair_prepare(W["AvE"], nf)
+
+
+def chain_fused(x):
+    W["EvI"].apply_pair_device(W["AvE"], x, out1=yE, out2=yA)
+    W["IvA"].apply_device(yA, out=yI, force_conservation=False)
+
+
+for x in X[:4]:
+    chain_fused(x)
+torch.cuda.synchronize()
+e0.record()
+for i in range(N):
+    chain_fused(X[i % len(X)])
+e1.record(); torch.cuda.synchronize()
+fused_eager_us = e0.elapsed_time(e1) * 1e3 / N
+fgraphs = []
+for x in X:
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        chain_fused(x)
+    fgraphs.append(gr)
+for gr in fgraphs[:4]:
+    gr.replay()
+torch.cuda.synchronize()
+e0.record()
+for i in range(N):
+    fgraphs[i % len(fgraphs)].replay()
+e1.record(); torch.cuda.synchronize()
+fused_graph_us = e0.elapsed_time(e1) * 1e3 / N
+fused_same = bool(torch.equal(yI.view(torch.int64), ref.view(torch.int64)))
+fused_close = float(((yI - ref).abs().max() / ref.abs().max()).item())
 print("%s chain EvI->AvE->IvA, %d fields: kernels %s; %.1f MB algorithmic per chain; eager %.2f us per chain, hipGraph replay %.2f us per chain "
       "(%.1f %% of 8 TB/s); graph result == eager result bitwise: %s" %
       (cfg, nf, "/".join(W[n].last_kernel() for n in ("EvI", "AvE", "IvA")), B / 1e6, eager_us, graph_us, B / graph_us / 1e3 / 8000 * 100, same), flush=True)
+print("   EvI+AvE fused into one launch (apply_pair_device) + IvA: eager %.2f us per chain, hipGraph replay %.2f us (%.1f %% of 8 TB/s); final field bitwise "
+      "the three-launch chain's: %s (max rel diff %.1e)" % (fused_eager_us, fused_graph_us, B / fused_graph_us / 1e3 / 8000 * 100, fused_same, fused_close), flush=True)

@@ -112,6 +112,67 @@ def test_fast_and_general_assembly_paths_agree_with_the_oracle(config):
         icebin_amd.set_tuning("assemble_fast", 1)
 
 
+@pytest.mark.parametrize("config,kw", [("g5", {}), ("g20", {}), ("g20", dict(x_fastest=True))])
+def test_fused_pair_evi_then_ave_is_the_two_applies(config, kw):
+    """ibh_weighted_apply_pair_device: E = EvI * I and A = AvE * E in one launch (BASELINE config 3's chain) against the two
+    separate applies and the oracle: B1 bitwise the EvI apply, B2 within 1e-12 of AvE applied to it; NaN fields, fill for rows
+    without weight, 1..40 fields, matrices with their own dims (different numberings of E: paired through sparse indices) and
+    with a shared dimE; graph capture; matrices that do not pair are refused."""
+    import torch
+    g = syn.make_grids(config, **kw)
+    em = syn.dome_elevmask(g)
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    nE = g["nA"] * len(g["hcdefs"])
+    for shared in (False, True):
+        if shared:
+            dimE = icebin_amd.SparseSet(nE)
+            EvI = rm.matrix_d("EvI", (dimE, None), scale=True, correctA=True)
+            AvE = rm.matrix_d("AvE", (None, dimE), scale=True, correctA=True)
+        else:
+            EvI, AvE = rm.matrix("EvI"), rm.matrix("AvE")
+        oE, oA = rg.matrix_d("EvI", em, scale=True, correctA=True), rg.matrix_d("AvE", em, scale=True, correctA=True)
+        EvI.pair_prepare(AvE, 16)
+        for nvar in (16, 1, 7, 40):
+            x = torch.from_numpy(syn.fields(nvar, EvI.ncol_d, seed=90 + nvar)).cuda()
+            x[nvar // 2, ::9] = float("nan")
+            EvI.set_kernel("rowgroup")
+            e_sep = EvI.apply_device(x, fill=-1.0, force_conservation=False).clone()
+            EvI.set_kernel("auto")
+            perm = np.argsort(EvI.dim(0))[np.searchsorted(np.sort(EvI.dim(0)), AvE.dim(1))]        # AvE's column order of E
+            a_sep = AvE.apply_device(e_sep[:, torch.from_numpy(perm).cuda()].contiguous(), fill=-1.0, force_conservation=False)
+            b1, b2 = EvI.apply_pair_device(AvE, x, fill=-1.0)
+            torch.cuda.synchronize()
+            assert EvI.last_kernel() == "rowgroup"
+            assert np.array_equal(b1.cpu().numpy().view(np.uint64), e_sep.cpu().numpy().view(np.uint64)), (config, shared, nvar)
+            assert rel_linf(b2.cpu().numpy(), a_sep.cpu().numpy()) <= FIELD_RTOL, (config, shared, nvar)
+            # ... and the oracle's two applies
+            ref_e = oE.apply(x.cpu().numpy(), fill=-1.0, force_conservation=False)
+            operm = np.argsort(oE.dims[0])[np.searchsorted(np.sort(oE.dims[0]), oA.dims[1])]
+            ref_a = oA.apply(ref_e[:, operm], fill=-1.0, force_conservation=False)
+            order_a = np.argsort(AvE.dim(0))[np.searchsorted(np.sort(AvE.dim(0)), oA.dims[0])]
+            assert rel_linf(b2.cpu().numpy()[:, order_a], ref_a) <= FIELD_RTOL, (config, shared, nvar)
+        # inside a hipGraph
+        x = torch.from_numpy(syn.fields(16, EvI.ncol_d, seed=5)).cuda()
+        o1, o2 = EvI.apply_pair_device(AvE, x, fill=-1.0)
+        keep1, keep2 = o1.clone(), o2.clone()
+        o1.zero_(); o2.zero_()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            EvI.apply_pair_device(AvE, x, out1=o1, out2=o2, fill=-1.0)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o1.view(torch.int64), keep1.view(torch.int64)) and torch.equal(o2.view(torch.int64), keep2.view(torch.int64))
+    # matrices that do not pair: IvE's rows are ice cells (no row groups); AvI after EvI reads ice cells, not classes
+    with pytest.raises(icebin_amd.IcebinHipError):
+        rm.matrix("IvE").pair_prepare(rm.matrix("AvE"))
+    with pytest.raises(icebin_amd.IcebinHipError):
+        rm.matrix("EvI").pair_prepare(rm.matrix("AvI"))
+    with pytest.raises(icebin_amd.IcebinHipError, match="pair_prepare"):
+        a, b = rm.matrix("EvI"), rm.matrix("AvE")
+        a.apply_pair_device(b, torch.zeros((2, a.ncol_d), dtype=torch.float64, device="cuda"))
+
+
 @pytest.mark.parametrize("shape", [0, 1, 2])
 def test_assembly_range_kernel_shapes_are_bit_identical(shape):
     # the per-range kernels of the plan-based build exist in three workgroup shapes (128 x 2, 256 x 4, 1024 x 4 cells per pass,
