@@ -1,5 +1,6 @@
 // common.h -- internal helpers of libicebin_hip.so (error channel, device buffers, handle layouts).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -199,7 +200,14 @@ struct ibh_regrid_matrices {
     double sigma[3] = {0, 0, 0};
 };
 
+namespace ibh {
+inline uint64_t next_weighted_uid() {
+    static std::atomic<uint64_t> n{0};
+    return ++n;
+}
+}  // namespace ibh
 struct ibh_weighted {
+    const uint64_t uid = ibh::next_weighted_uid();     // never reused: a pairing names its second matrix by (address, uid)
     int device = 0;
     int32_t nrow = 0, ncol = 0;
     int64_t nnz = 0;
@@ -248,6 +256,7 @@ struct ibh_weighted {
     // pair_w[g * IBH_GSLOTS + s]: the second matrix's weight of slot s of group g (pair_mask[g] bit s: it has one);
     // pair_row[g]: the second matrix's row fed by group g, -1 none.
     mutable const ibh_weighted *pair_second = nullptr;
+    mutable uint64_t pair_uid = 0;
     mutable ibh::DevBuf<double> pair_w;
     mutable ibh::DevBuf<uint32_t> pair_mask;
     mutable ibh::DevBuf<int32_t> pair_row;

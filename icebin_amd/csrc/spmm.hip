@@ -1218,6 +1218,7 @@ static bool wants_groups(const ibh_weighted *w, int nvar, int nbatch, long seen)
 }
 static void drop_groups(const ibh_weighted *w) {
     w->grp_n = 0;
+    w->pair_second = nullptr;                                 // (a pairing indexes the group table)
     w->grp_ptr.release(); w->grp_ns.release(); w->grp_slotrow.release(); w->grp_col.release(); w->grp_meta.release();
     w->grp_v0.release(); w->grp_v1.release();
 }
@@ -1362,12 +1363,14 @@ void weighted_pair_prepare(const ibh_weighted *first, const ibh_weighted *second
     IBH_HIP(hipMemcpy(first->pair_mask.p, pm.data(), pm.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     IBH_HIP(hipMemcpy(first->pair_row.p, pr.data(), pr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     first->pair_second = second;
+    first->pair_uid = second->uid;
 }
 
 void spmm_launch_pair(const ibh_weighted *first, const ibh_weighted *second, const double *dA, int nvar, int64_t lda, double *dB1,
                       int64_t ldb1, double *dB2, int64_t ldb2, double fill, hipStream_t stream)
 {
-    IBH_CHECK(first->pair_second == second && first->grp_n > 0, "pair apply: call ibh_weighted_pair_prepare(first, second, nvar) first");
+    IBH_CHECK(first->pair_second == second && first->pair_uid == second->uid && first->grp_n > 0,
+              "pair apply: call ibh_weighted_pair_prepare(first, second, nvar) first");
     if (nvar <= 0 || first->nrow == 0) return;
     IBH_CHECK(lda >= first->ncol && ldb1 >= first->nrow && ldb2 >= second->nrow, "pair apply: leading dimensions (%ld, %ld, %ld) too small",
               (long)lda, (long)ldb1, (long)ldb2);
