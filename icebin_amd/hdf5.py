@@ -836,7 +836,15 @@ def _py_attr(v):
 
 
 def read_netcdf4(path_or_bytes):
-    """-> (ncio.Dataset, hdf5.File).  Root group only (the reference's files have no sub-groups)."""
+    """-> (ncio.Dataset, hdf5.File).  Root group only (the reference's files have no sub-groups).  A truncated or corrupt file
+    raises H5Error, whatever the place the damage shows up in."""
+    try:
+        return _read_netcdf4(path_or_bytes)
+    except (IndexError, struct.error, zlib.error, UnicodeDecodeError, OverflowError, MemoryError) as e:
+        raise H5Error("truncated or corrupt HDF5 file (%s: %s)" % (type(e).__name__, e))
+
+
+def _read_netcdf4(path_or_bytes):
     from .ncio import Dataset, Var
     f = File(path_or_bytes)
     ds = Dataset()

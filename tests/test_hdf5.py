@@ -134,6 +134,23 @@ def test_matlab73_file_of_scipy_old_style_structures():
     assert bytes(np.asarray(o.attrs["MATLAB_class"]).reshape(-1)[0]) == b"double"
 
 
+@needs_reference
+def test_truncated_and_damaged_files_raise_h5error():
+    path = os.path.join(REF, "130516-Regrid_examples_e4f40-hc40-g5_JUL1956.aije4f40-hc40-prec.nc")
+    raw = open(path, "rb").read()
+    for cut in (len(raw) // 2, len(raw) - 1000, 200, 60):
+        with pytest.raises(hdf5.H5Error):
+            hdf5.read_netcdf4(raw[:cut])
+    # a damaged chunk (the deflate stream of the data, not the checksummed metadata)
+    ds, f = hdf5.read_netcdf4(raw)
+    prec = [o for n, o in f.walk() if n == "prec"][0]
+    addr = next(f._chunks(prec.layout[1], 2))[1]
+    bad = bytearray(raw)
+    bad[addr + 10:addr + 60] = b"\xff" * 50
+    with pytest.raises(hdf5.H5Error):
+        hdf5.read_netcdf4(bytes(bad))
+
+
 def test_not_hdf5_and_truncated_files_fail_loudly(tmp_path):
     with pytest.raises(hdf5.H5Error, match="not an HDF5 file"):
         hdf5.File(b"CDF\x05" + b"\0" * 600)
