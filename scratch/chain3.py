@@ -94,8 +94,20 @@ e1.record(); torch.cuda.synchronize()
 fused_graph_us = e0.elapsed_time(e1) * 1e3 / N
 fused_same = bool(torch.equal(yI.view(torch.int64), ref.view(torch.int64)))
 fused_close = float(((yI - ref).abs().max() / ref.abs().max()).item())
+# (d) 16 consecutive fused chains (16 time steps' worth, rotating inputs) captured as ONE graph: one submission per 16 chains
+big = torch.cuda.CUDAGraph()
+with torch.cuda.graph(big):
+    for j in range(16):
+        chain_fused(X[j % len(X)])
+big.replay(); torch.cuda.synchronize()
+e0.record()
+for i in range(N // 16):
+    big.replay()
+e1.record(); torch.cuda.synchronize()
+big_us = e0.elapsed_time(e1) * 1e3 / (N // 16 * 16)
 print("%s chain EvI->AvE->IvA, %d fields: kernels %s; %.1f MB algorithmic per chain; eager %.2f us per chain, hipGraph replay %.2f us per chain "
       "(%.1f %% of 8 TB/s); graph result == eager result bitwise: %s" %
       (cfg, nf, "/".join(W[n].last_kernel() for n in ("EvI", "AvE", "IvA")), B / 1e6, eager_us, graph_us, B / graph_us / 1e3 / 8000 * 100, same), flush=True)
 print("   EvI+AvE fused into one launch (apply_pair_device) + IvA: eager %.2f us per chain, hipGraph replay %.2f us (%.1f %% of 8 TB/s); final field bitwise "
-      "the three-launch chain's: %s (max rel diff %.1e)" % (fused_eager_us, fused_graph_us, B / fused_graph_us / 1e3 / 8000 * 100, fused_same, fused_close), flush=True)
+      "the three-launch chain's: %s (max rel diff %.1e); 16 fused chains in one graph: %.2f us per chain" %
+      (fused_eager_us, fused_graph_us, B / fused_graph_us / 1e3 / 8000 * 100, fused_same, fused_close, big_us), flush=True)
