@@ -805,7 +805,7 @@ enum { FA_PSUMS = 0, FA_PCOUNT = 1, FA_PEMIT = 2 };
 // take the per-row selection branch below.  A set numbered by this build cannot, and the kernel without that branch fits the
 // 64 registers of full occupancy (a1h IvE 3.15 -> 3.04 ms, IvA 2.09 -> 1.94).
 template <bool WITH_EP, int MODE, bool ANYORDER>
-__global__ __launch_bounds__(FA_T, (WITH_EP && ANYORDER) ? 1 : 8) void k_fa_pelem(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, long np, FaOut o,
+__global__ __launch_bounds__(FA_T, (WITH_EP && MODE == 2) ? (ANYORDER ? 1 : 6) : 8) void k_fa_pelem(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, long np, FaOut o,
                                                     uint32_t *__restrict__ rowlen, uint32_t *__restrict__ flags) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     stage_hc<WITH_EP>(rg, s_hc);
@@ -879,11 +879,11 @@ __global__ __launch_bounds__(FA_T, (WITH_EP && ANYORDER) ? 1 : 8) void k_fa_pele
             else { fn(id1, ge.t1, c.iA); fn(id0, ge.t0, c.iA); }
         }
     };
-    // EMIT with columns known to ascend: the first FA_KEEP entries of the row are parked in LDS (a private slot per thread, no
+    // EMIT with columns that ascend (known, or found so by the first visit): the first FA_KEEP entries of the row are parked in LDS (a private slot per thread, no
     // registers), so a row of that many entries -- an ice cell under one or two GCM cells: ~99 % of them -- is written after ONE
     // visit of its exchange cells instead of two (row sum first, scaled values second)
     constexpr int FA_KEEP = 4;
-    constexpr bool KEEP = MODE == FA_PEMIT && !ANYORDER;
+    constexpr bool KEEP = MODE == FA_PEMIT;
     __shared__ double s_kt[KEEP ? FA_KEEP : 1][KEEP ? FA_T : 1];
     __shared__ int s_kid[KEEP ? FA_KEEP : 1][KEEP ? FA_T : 1], s_ka[KEEP ? FA_KEEP : 1][KEEP ? FA_T : 1];
     visit([&](int id, double t, long iA) {
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(FA_T, (WITH_EP && ANYORDER) ? 1 : 8) void k_fa_pele
         if (o.correctA) v = v * rg.ratioA[iA];
         return v;
     };
-    if (KEEP && ne <= FA_KEEP) {
+    if (KEEP && ne <= FA_KEEP && (sorted || !ANYORDER)) {
         o.wM[d] = sum;
         for (int a = 0; a < ne; ++a) {
             o.colind[b0 + a] = s_kid[a][threadIdx.x];
