@@ -1933,12 +1933,7 @@ def test_colsweep_on_random_structures(seed):
         assert rel_linf(outs[q].cpu().numpy(), o.apply(xs[q].cpu().numpy(), fill=-3.0, force_conservation=False)) <= FIELD_RTOL
 
 
-@pytest.mark.parametrize("seed", list(range(10)))
-def test_random_exchange_grids_bit_exact(seed):
-    """Randomised differential test of the whole assembly against the oracle: arbitrary (iA, iI) pairs
-    (duplicates, any order, ice cells under many atmosphere cells), random masks, zero / negative
-    overlaps, both interpolation styles, both indexingHC layouts -- every ordering path (in order,
-    pieces, radix, optimistic row-only sort and its failed check), both column-sum paths."""
+def _random_grid(seed, force_sorted=False):
     rng = np.random.default_rng(1000 + seed)
     nA_real, nI, nhc = int(rng.integers(3, 40)), int(rng.integers(20, 600)), int(rng.integers(2, 12))
     im, jm = 12, 8
@@ -1947,7 +1942,17 @@ def test_random_exchange_grids_bit_exact(seed):
     nX = int(rng.integers(50, 3000))
     iA = rng.choice(A_to_sparse, nX)
     iI = rng.integers(0, nI, nX)
-    if seed % 3 == 0:                    # a sorted grid (the reference's normal case), else arbitrary order
+    if force_sorted:
+        # inside the limits of the plan-based build: <= 8 exchange cells per ice cell, <= 3 cells with the same (iA, iI)
+        o = np.lexsort((iA, iI)); iA, iI = iA[o], iI[o]
+        first = np.r_[True, iI[1:] != iI[:-1]]
+        rank_in_ice = np.arange(nX) - np.maximum.accumulate(np.where(first, np.arange(nX), 0))
+        firstp = np.r_[True, (iI[1:] != iI[:-1]) | (iA[1:] != iA[:-1])]
+        rank_in_pair = np.arange(nX) - np.maximum.accumulate(np.where(firstp, np.arange(nX), 0))
+        keep = (rank_in_ice < 8) & (rank_in_pair < 3)
+        iA, iI = iA[keep], iI[keep]
+        nX = len(iA)
+    if seed % 3 == 0 or force_sorted:    # a sorted grid (the reference's normal case), else arbitrary order
         o = np.lexsort((iI, iA)); iA, iI = iA[o], iI[o]
     area = 1e6 * (0.5 + rng.random(nX))
     area[rng.random(nX) < 0.03] = 0.0
@@ -1964,6 +1969,16 @@ def test_random_exchange_grids_bit_exact(seed):
              A_native_area=proj * (1.0 + 0.05 * rng.random(nA_real)), A_proj_area=proj, hcdefs=hcdefs,
              hc_stride_A=1 if seed % 2 == 0 else nhc, hc_stride_HC=nA if seed % 2 == 0 else 1,
              interp_style=1 if seed % 5 == 4 else 0, I_centroid_xy=np.zeros((nI, 2)))
+    return g, em
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_exchange_grids_bit_exact(seed):
+    """Randomised differential test of the whole assembly against the oracle: arbitrary (iA, iI) pairs
+    (duplicates, any order, ice cells under many atmosphere cells), random masks, zero / negative
+    overlaps, both interpolation styles, both indexingHC layouts -- every ordering path (in order,
+    pieces, radix, optimistic row-only sort and its failed check), both column-sum paths."""
+    g, em = _random_grid(seed)
     mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
     rm = mm.regrid_matrices("greenland", em)
     for name in ALL:
@@ -1974,6 +1989,31 @@ def test_random_exchange_grids_bit_exact(seed):
             if w.nnz and name in ("AvI", "IvE", "EvI"):
                 x = syn.fields(3, w.ncol_d, seed=seed)
                 assert rel_linf(w.apply(x, fill=-9.0), o.apply(x, fill=-9.0)) <= FIELD_RTOL
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_sorted_grids_on_every_variant_of_the_plan_based_build(seed):
+    """The same random grids, sorted (so the plan-based build takes them when its limits allow: duplicates, ice cells under many
+    atmosphere cells, zero / negative areas, masks, cells exactly on a class boundary), with the variants that large grids
+    select forced on: the streamed count of the one-class matrices, every workgroup shape of the per-range kernels, the static
+    and the visiting row count -- all against the oracle's bits."""
+    g, em = _random_grid(seed, force_sorted=True)
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    rm = mm.regrid_matrices("greenland", em)
+    try:
+        icebin_amd.set_tuning("assemble_stream_count", 1)
+        icebin_amd.set_tuning("assemble_range_shape", seed % 3)
+        icebin_amd.set_tuning("assemble_static_count", seed % 2)
+        fast = 0
+        for name in ALL:
+            for scale, correctA in ((True, True), (False, False)):
+                w = rm.matrix_d(name, scale=scale, correctA=correctA)
+                fast += int(w.built_fast())
+                assert_same_weighted(w, rg.matrix_d(name, em, scale=scale, correctA=correctA), "%s seed=%d" % (name, seed))
+        assert fast >= 12, fast                 # (EvA / AvE with negative areas, and little else, go to the general pipeline)
+    finally:
+        for k in ("assemble_stream_count", "assemble_range_shape", "assemble_static_count"):
+            icebin_amd.set_tuning(k, -2 ** 31)
 
 
 @pytest.mark.parametrize("nA_real,nX", [(12, 150000), (60, 200000)])
