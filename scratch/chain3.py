@@ -105,9 +105,33 @@ for i in range(N // 16):
     big.replay()
 e1.record(); torch.cuda.synchronize()
 big_us = e0.elapsed_time(e1) * 1e3 / (N // 16 * 16)
+# (e) 16 INDEPENDENT field batches through the chain (e.g. 16 tracer groups): three batched launches for all of them
+nb = min(16, len(X))
+W["EvI"].prepare(nf, nb); W["AvE"].prepare(nf, nb); W["IvA"].prepare(nf, nb)
+yEs = [torch.zeros_like(yE) for _ in range(nb)]
+yAs = [torch.zeros_like(yA) for _ in range(nb)]
+yIs = [torch.zeros((nf, ld), dtype=torch.float64, device="cuda")[:, :W["IvA"].nrow_d] for _ in range(nb)]
+
+
+def chains_batched():
+    W["EvI"].apply_many_device(X[:nb], yEs, force_conservation=False)
+    W["AvE"].apply_many_device(yEs, yAs, force_conservation=False)
+    W["IvA"].apply_many_device(yAs, yIs, force_conservation=False)
+
+
+for _ in range(3):
+    chains_batched()
+torch.cuda.synchronize()
+e0.record()
+for i in range(N // nb):
+    chains_batched()
+e1.record(); torch.cuda.synchronize()
+batched_us = e0.elapsed_time(e1) * 1e3 / (N // nb * nb)
 print("%s chain EvI->AvE->IvA, %d fields: kernels %s; %.1f MB algorithmic per chain; eager %.2f us per chain, hipGraph replay %.2f us per chain "
       "(%.1f %% of 8 TB/s); graph result == eager result bitwise: %s" %
       (cfg, nf, "/".join(W[n].last_kernel() for n in ("EvI", "AvE", "IvA")), B / 1e6, eager_us, graph_us, B / graph_us / 1e3 / 8000 * 100, same), flush=True)
 print("   EvI+AvE fused into one launch (apply_pair_device) + IvA: eager %.2f us per chain, hipGraph replay %.2f us (%.1f %% of 8 TB/s); final field bitwise "
       "the three-launch chain's: %s (max rel diff %.1e); 16 fused chains in one graph: %.2f us per chain" %
       (fused_eager_us, fused_graph_us, B / fused_graph_us / 1e3 / 8000 * 100, fused_same, fused_close, big_us), flush=True)
+print("   %d independent %d-field batches through the chain, three batched launches (apply_many_device): %.2f us per chain (%.1f %% of 8 TB/s)"
+      % (nb, nf, batched_us, B / batched_us / 1e3 / 8000 * 100), flush=True)
