@@ -45,6 +45,24 @@ for seed in range(first, first + count):
             except icebin_amd.IcebinHipError as e:
                 print("refused", seed, name, k, str(e)[:80], flush=True)
         w.set_kernel("auto")
+    # the fused pair EvI -> AvE where the two matrices pair (own dims: paired through sparse indices)
+    EvI, AvE = rm.matrix("EvI"), rm.matrix("AvE")
+    if EvI.nnz and AvE.nnz:
+        try:
+            EvI.pair_prepare(AvE, 8)
+            xx = torch.from_numpy(syn.fields(5, EvI.ncol_d, seed=seed + 1)).cuda()
+            xx[2, ::3] = float("nan")
+            b1, b2 = EvI.apply_pair_device(AvE, xx, fill=-7.0)
+            EvI.set_kernel("rowgroup")
+            e = EvI.apply_device(xx, fill=-7.0, force_conservation=False)
+            perm = np.argsort(EvI.dim(0))[np.searchsorted(np.sort(EvI.dim(0)), AvE.dim(1))]
+            a = AvE.apply_device(e[:, torch.from_numpy(perm).cuda()].contiguous(), fill=-7.0, force_conservation=False)
+            torch.cuda.synchronize()
+            n += 1; npair = globals().get("npair", 0) + 1; globals()["npair"] = npair
+            if not torch.equal(b1.view(torch.int64), e.view(torch.int64)) or T.rel_linf(b2.cpu().numpy(), a.cpu().numpy()) > T.FIELD_RTOL:
+                bad += 1; print("PAIR MISMATCH", seed, flush=True)
+        except icebin_amd.IcebinHipError as ex:
+            print("pair refused", seed, str(ex)[:90], flush=True)
     print("seed %d done (%d applies so far)" % (seed, n), flush=True)
-print("applies checked:", n, "mismatches:", bad)
+print("applies checked:", n, "of them fused pairs:", globals().get("npair", 0), "mismatches:", bad)
 sys.exit(1 if bad else 0)
