@@ -345,7 +345,11 @@ int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
 /* 1 when the matrix was assembled by the plan-based fast path for sorted exchange grids (fastasm.inl), 0 when the
  * general pipeline built it (ibh_set_tuning("assemble_fast", 0) forces the latter).  Results are bit-identical. */
 int ibh_weighted_built_fast(const ibh_weighted *w, int *out);
-int ibh_set_tuning(const char *key, int value);      /* value INT32_MIN: back to the built-in default */
+/* Launch-heuristic overrides for measurements and tests (README.md lists the keys: assemble_fast, assemble_fast_eva,
+ * assemble_range_shape, assemble_stream_count, assemble_static_count, rowgroup_*, rowone*, rowblock_*, shortrow_*, sweep_*,
+ * lazy_structures ...).  No key changes a result beyond the documented tolerance of the kernel it selects; the assembly keys
+ * change no bit.  value INT32_MIN: back to the built-in default. */
+int ibh_set_tuning(const char *key, int value);
 /* DIAGNOSTIC measurement hooks (bench.py only; not for product code: ibh_set_launch_events is thread-local
  * one-shot state that changes which launch API the calling thread's next apply uses): HIP events owned by
  * the library, and a one-shot request to attach a pair of them to the NEXT SpMM launch of the calling thread (hipExtLaunchKernel: start = the
