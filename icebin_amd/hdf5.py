@@ -852,7 +852,7 @@ def _read_netcdf4(path_or_bytes):
     for k, v in root.attrs.items():
         if k not in _HIDDEN:
             ds.attrs[k] = _py_attr(v)
-    members = [(name, f.obj(addr)) for name, addr in root.links.items()]
+    members = [(name, f.obj(addr)) for name, addr in (root.links or {}).items()]
     datasets = [(n, o) for n, o in members if o.is_dataset]
     # dimensions: the dimension scales, in _Netcdf4Dimid order (creation order otherwise)
     scales = []

@@ -151,6 +151,57 @@ def test_truncated_and_damaged_files_raise_h5error():
         hdf5.read_netcdf4(bytes(bad))
 
 
+def _handmade_file_with_string_list_attributes():
+    """A minimal HDF5 image assembled by hand from the format specification: superblock 0, a version-1 object header (root
+    group without members) carrying three version-1 attribute messages -- a LIST of variable-length strings (what
+    `m.info:sheets` / `BvA.info:dim_names` are in the reference's nc4 files), a fixed-length string and an int32 array -- and the
+    global heap collection the variable-length strings live in."""
+    import struct
+    U = 0xFFFFFFFFFFFFFFFF
+
+    def pad8(b):
+        return b + b"\0" * (-len(b) % 8)
+
+    names = [b"greenland", b"antarctica", b""]
+    gcol_at = 1024
+    heap = b""
+    for i, nm in enumerate(names, 1):
+        heap += struct.pack("<HHIQ", i, 1, 0, len(nm)) + pad8(nm)
+    heap += struct.pack("<HHIQ", 0, 0, 0, 0)
+    gcol = b"GCOL" + bytes([1, 0, 0, 0]) + struct.pack("<Q", 16 + len(heap)) + heap
+
+    def attr(name, dtype, space, data):
+        nm = name + b"\0"
+        return bytes([1, 0]) + struct.pack("<HHH", len(nm), len(dtype), len(space)) + pad8(nm) + pad8(dtype) + pad8(space) + data
+
+    vstr = bytes([0x19, 0x01, 0, 0]) + struct.pack("<I", 16) + bytes([0x13, 0, 0, 0]) + struct.pack("<I", 1)
+    space1 = lambda n: bytes([1, 1, 0, 0, 0, 0, 0, 0]) + struct.pack("<Q", n)
+    scalar = bytes([1, 0, 0, 0, 0, 0, 0, 0])
+    vdata = b"".join(struct.pack("<IQI", len(nm), gcol_at, i) for i, nm in enumerate(names, 1))
+    fixed = bytes([0x13, 0, 0, 0]) + struct.pack("<I", 8)
+    i32 = bytes([0x10, 0x08, 0, 0]) + struct.pack("<I", 4) + struct.pack("<HH", 0, 32)
+    msgs = [attr(b"sheets", vstr, space1(3), vdata), attr(b"type", fixed, scalar, b"EIGEN\0\0\0"),
+            attr(b"shape", i32, space1(2), struct.pack("<ii", 122, 76611))]
+    body = b"".join(struct.pack("<HHBBH", 0x0C, len(pad8(m)), 0, 0, 0) + pad8(m) for m in msgs)
+    ohdr = bytes([1, 0]) + struct.pack("<HII", len(msgs), 1, len(body)) + b"\0" * 4 + body
+    root_at = 96
+    sb = (hdf5.SIGNATURE + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack("<HHI", 4, 16, 0) + struct.pack("<QQQQ", 0, U, gcol_at + len(gcol), U) +
+          struct.pack("<QQII", 0, root_at, 0, 0) + b"\0" * 16)
+    assert len(sb) == root_at
+    img = sb + ohdr
+    assert len(img) <= gcol_at
+    return img + b"\0" * (gcol_at - len(img)) + gcol
+
+
+def test_handmade_image_string_list_attributes():
+    ds, f = hdf5.read_netcdf4(_handmade_file_with_string_list_attributes())
+    assert f.sb_version == 0 and not ds.variables and not ds.dims
+    assert ds.attrs["sheets"] == ["greenland", "antarctica", ""]          # a Python list, not a comma-joined string
+    assert ncio._strlist(ds.attrs["sheets"]) == ["greenland", "antarctica", ""]
+    assert ds.attrs["type"] == "EIGEN"
+    assert np.array_equal(ds.attrs["shape"], [122, 76611]) and ds.attrs["shape"].dtype == np.int32
+
+
 def test_not_hdf5_and_truncated_files_fail_loudly(tmp_path):
     with pytest.raises(hdf5.H5Error, match="not an HDF5 file"):
         hdf5.File(b"CDF\x05" + b"\0" * 600)
