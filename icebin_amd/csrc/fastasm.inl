@@ -265,7 +265,7 @@ __device__ __forceinline__ uint32_t fa_pflag_of(const RgView &rg, const PlanView
 
 // ---- G-side numbering and entry counts: one workgroup per range -----------------------------------
 template <bool WITH_EP, int T, int CPT>
-__global__ __launch_bounds__(T) void k_fa_count(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int g_is_row, int merge,
+__global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int g_is_row, int merge,
                                                     uint32_t *__restrict__ err_x, uint32_t *__restrict__ flags, int eva_check) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     __shared__ uint32_t s_first[FA_NC], s_cn[FA_NC], s_co[FA_NC];
