@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libicebin_hip.so")
 SOURCES = ["capi.hip", "spmm.hip", "prims.hip", "assemble.hip", "gridgen.hip", "comm.hip"]
-HEADERS = ["common.h", "prims.h", "assemble.h", "fastasm.inl", "sweep_kernel.inl", os.path.join("..", "..", "include", "icebin_hip.h")]
+HEADERS = ["common.h", "prims.h", "assemble.h", "fastasm.inl", "streamasm.inl", "sweep_kernel.inl", os.path.join("..", "..", "include", "icebin_hip.h")]
 # -ffp-contract=off: the bookkeeping kernels must round every multiply and add separately
 # (bit-exact weights); the SpMM kernels ask for FMA explicitly with fma().
 # -amdgpu-kernarg-preload-count=16: the first 16 dwords of the kernel arguments arrive in SGPRs with the wave instead of

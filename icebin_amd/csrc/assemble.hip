@@ -1986,6 +1986,7 @@ bool build_groups_from_csr(const ibh_weighted *cw, hipStream_t st) {
 }
 
 #include "fastasm.inl"
+#include "streamasm.inl"
 
 // ---- RegridMatrices_Dynamic::matrix_d ----------------------------------------------------------
 static const MatSpec *find_spec(const char *spec_name) {
@@ -2035,7 +2036,7 @@ bool assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     // band structure work on intermediates of the general pipeline
     const bool bands_wanted = sp->row_key == KEY_E && (sp->col_key == KEY_I || sp->col_key == KEY_X) && get_tuning("assemble_bands", 0);
     if (!smooth && !bands_wanted && fast_build(rm, sp, dims, scale, correctA, rg, w.get(), st)) {
-        w->built_fast = 1;
+        if (!w->built_fast) w->built_fast = 1;          // (2: the streamed build, set by stream_build)
         *out = w.release();
         return true;
     }

@@ -44,8 +44,11 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        // the copy already in the process first (a PyTorch process has loaded its bundled librccl: one RCCL per process)
-        const char *names[] = {getenv("ICEBIN_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        // the copy already in the process first (a PyTorch process has loaded its bundled librccl: one RCCL per process).
+        // ICEBIN_RCCL_LIB, when set, is the ONLY candidate: a caller who names a library gets that one or an error.
+        const char *env = getenv("ICEBIN_RCCL_LIB");
+        const bool pinned = env && *env;
+        const char *names[] = {env, pinned ? nullptr : "librccl.so", pinned ? nullptr : "librccl.so.1", pinned ? nullptr : "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) {
             if (!n || !*n) continue;
             r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
@@ -56,7 +59,11 @@ Rccl &rccl() {
             if (!n || !*n) continue;
             r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
-        if (!r.h) { r.err = std::string("librccl not found (") + (dlerror() ? dlerror() : "?") + "); set ICEBIN_RCCL_LIB"; return; }
+        if (!r.h) {
+            const char *e = dlerror();           // (dlerror() clears the message it returns: read it once)
+            r.err = std::string("librccl not found (") + (e ? e : "?") + "); set ICEBIN_RCCL_LIB";
+            return;
+        }
         auto sym = [&](const char *name) { void *p = dlsym(r.h, name); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + name; return p; };
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
@@ -93,7 +100,9 @@ struct ibh_comm {
     // results overlap such a range is ordered behind THAT exchange only -- so with two alternating result arrays the SpMM of
     // apply k+1 overlaps the exchange of apply k.
     static constexpr int RING = 8;
-    struct Flight { const char *lo = nullptr, *hi = nullptr; hipEvent_t ev = nullptr; bool live = false; } ring[RING];
+    // A flight stays live until its ring slot is reused: ANY stream that later touches the range is ordered behind it, not
+    // only the first one (`waited` remembers the last stream that did, which need not wait twice: stream order).
+    struct Flight { const char *lo = nullptr, *hi = nullptr; hipEvent_t ev = nullptr; bool live = false; bool has_waiter = false; hipStream_t waited = nullptr; } ring[RING];
     int next = 0;
 };
 
@@ -108,39 +117,54 @@ static void comm_common_init(ibh_comm *c) {
 // the SpMM about to write [lo, hi) on stream st must not overtake an exchange that still reads / writes that range
 static void order_behind_flights(ibh_comm *c, const void *lo, const void *hi, hipStream_t st) {
     for (auto &f : c->ring)
-        if (f.live && static_cast<const char *>(lo) < f.hi && f.lo < static_cast<const char *>(hi)) {
+        if (f.live && static_cast<const char *>(lo) < f.hi && f.lo < static_cast<const char *>(hi) && !(f.has_waiter && f.waited == st)) {
             IBH_HIP(hipStreamWaitEvent(st, f.ev, 0));
-            f.live = false;
+            f.has_waiter = true; f.waited = st;
         }
 }
 // the exchange just enqueued on c->xs covers [lo, hi)
 static void record_flight(ibh_comm *c, const void *lo, const void *hi, hipStream_t st) {
     ibh_comm::Flight &f = c->ring[c->next];
     c->next = (c->next + 1) % ibh_comm::RING;
-    if (f.live) IBH_HIP(hipStreamWaitEvent(st, f.ev, 0));      // the ring is full: the oldest exchange becomes a dependency of the stream
+    // the slot is reused.  If its old exchange has not finished, the new flight takes over its range as well (the hull): the
+    // exchange stream runs in order, so whoever waits for the new event has waited for the old one too -- no stream loses a
+    // dependency, at the price of a wider range while eight exchanges are still running
+    const char *nlo = static_cast<const char *>(lo), *nhi = static_cast<const char *>(hi);
+    if (f.live && hipEventQuery(f.ev) != hipSuccess) { nlo = std::min(nlo, f.lo); nhi = std::max(nhi, f.hi); }
+    (void)st;
     IBH_HIP(hipEventRecord(f.ev, c->xs));
-    f.lo = static_cast<const char *>(lo); f.hi = static_cast<const char *>(hi); f.live = true;
+    lo = nlo; hi = nhi;
+    f.lo = static_cast<const char *>(lo); f.hi = static_cast<const char *>(hi); f.live = true; f.has_waiter = false; f.waited = nullptr;
 }
 
-// for every base of the list: every rank's `count` doubles at base + rank*stride reach base + rank*stride on every peer; enqueued
-// on the exchange stream as ONE group (one RCCL launch however many results travel)
-static void exchange(ibh_comm *c, double *const *d_bases, int nbase, int64_t count, int64_t stride) {
-    if (c->world == 1 || count == 0 || nbase == 0) return;
+// for every base of the list: every rank's block of `nplane` planes (nrow doubles each, ldb apart) at base + rank*stride
+// reaches base + rank*stride on every peer; enqueued on the exchange stream as ONE group (one RCCL launch however many
+// results travel).  Rows [nrow, ldb) of a plane travel along only when they are the library's own kind of padding (planes
+// rounded up to 512 bytes: at most 63 doubles) -- the header gives those to the call; a wider gap means ldb is a true
+// leading dimension (a column view of a larger array whose other columns are live data) and every plane travels by itself.
+static void exchange(ibh_comm *c, double *const *d_bases, int nbase, int nplane, int64_t nrow, int64_t ldb, int64_t stride) {
+    if (c->world == 1 || nplane <= 0 || nrow <= 0 || nbase == 0) return;
+    const bool whole = (ldb - nrow) < 64 || nplane == 1;
+    const int npiece = whole ? 1 : nplane;
+    const int64_t count = whole ? (int64_t)(nplane - 1) * ldb + nrow : nrow;
     if (c->custom) {
-        for (int q = 0; q < nbase; ++q) {
-            const int rc = c->custom(c->custom_user, d_bases[q], count, stride, c->world, c->rank, c->xs);
-            if (rc != 0) fail(IBH_EHIP, "custom exchange callback failed (%d)", rc);
-        }
+        for (int q = 0; q < nbase; ++q)
+            for (int p = 0; p < npiece; ++p) {
+                const int rc = c->custom(c->custom_user, d_bases[q] + (int64_t)p * ldb, count, stride, c->world, c->rank, c->xs);
+                if (rc != 0) fail(IBH_EHIP, "custom exchange callback failed (%d)", rc);
+            }
         return;
     }
     Rccl &r = need_rccl();
     IBH_NCCL(r.GroupStart());
     for (int k = 1; k < c->world; ++k) {             // peers in a rotated order: at step k everybody talks to a different partner
         const int to = (c->rank + k) % c->world, from = (c->rank - k + c->world) % c->world;
-        for (int q = 0; q < nbase; ++q) {
-            IBH_NCCL(r.Send(d_bases[q] + (int64_t)c->rank * stride, (size_t)count, kNcclFloat64, to, c->nccl, c->xs));
-            IBH_NCCL(r.Recv(d_bases[q] + (int64_t)from * stride, (size_t)count, kNcclFloat64, from, c->nccl, c->xs));
-        }
+        for (int q = 0; q < nbase; ++q)
+            for (int p = 0; p < npiece; ++p) {
+                double *b = d_bases[q] + (int64_t)p * ldb;
+                IBH_NCCL(r.Send(b + (int64_t)c->rank * stride, (size_t)count, kNcclFloat64, to, c->nccl, c->xs));
+                IBH_NCCL(r.Recv(b + (int64_t)from * stride, (size_t)count, kNcclFloat64, from, c->nccl, c->xs));
+            }
     }
     IBH_NCCL(r.GroupEnd());
 }
@@ -210,7 +234,10 @@ int ibh_comm_wait(ibh_comm *c, void *stream) {
     return guarded([&] {
         IBH_CHECK(c != nullptr, "null argument");
         for (auto &f : c->ring)
-            if (f.live) { IBH_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), f.ev, 0)); f.live = false; }
+            if (f.live && !(f.has_waiter && f.waited == static_cast<hipStream_t>(stream))) {
+                IBH_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), f.ev, 0));
+                f.has_waiter = true; f.waited = static_cast<hipStream_t>(stream);
+            }
     });
 }
 
@@ -246,9 +273,8 @@ int ibh_weighted_apply_sharded_device(const ibh_weighted *w, ibh_comm *c, const 
             if (c->world > 1) {
                 IBH_HIP(hipEventRecord(c->ready, st));
                 IBH_HIP(hipStreamWaitEvent(c->xs, c->ready, 0));
-                // the last field of a block ends at row nrow of its plane: the padding up to ldb of that last plane is not sent
                 double *base = dB_all + (int64_t)f0 * ldb;
-                exchange(c, &base, 1, (int64_t)(nb - 1) * ldb + w->nrow, stride);
+                exchange(c, &base, 1, nb, w->nrow, ldb, stride);
             }
         }
         if (c->world > 1) record_flight(c, dB_all, dB_all + (int64_t)c->world * stride, st);
@@ -279,7 +305,7 @@ int ibh_weighted_apply_many_sharded_device(const ibh_weighted *w, ibh_comm *c, i
         if (c->world > 1) {
             IBH_HIP(hipEventRecord(c->ready, st));
             IBH_HIP(hipStreamWaitEvent(c->xs, c->ready, 0));
-            exchange(c, dB_all, nbatch, (int64_t)(nvar_local - 1) * ldb + w->nrow, stride);
+            exchange(c, dB_all, nbatch, nvar_local, w->nrow, ldb, stride);
             record_flight(c, lo, hi, st);
         }
     });

@@ -159,11 +159,11 @@ struct ibh_plan {
     ibh::DevBuf<int32_t> aidx;           // [nX] range of every exchange cell
     ibh::DevBuf<int32_t> ilptr, ilist;   // [nI+1], [nX] exchange cells of every ice cell, ascending
     ibh::DevBuf<int32_t> ifirst;         // [nI] first exchange cell of the ice cell with area != 0, -1: none
-    ibh::DevBuf<uint8_t> isdup;          // [nX] bit 0: same (iA, iI) as the cell before; bit 1: every exchange cell of this
-                                         //      cell's ice cell lies in this range (the ice cell straddles no GCM-cell edge); bit 2: this
+    ibh::DevBuf<uint8_t> isdup;          // [nX] bit 0: same (iA, iI) as the cell before; bit 1: this is the ONLY exchange cell of
+                                         //      its ice cell (the ice cell straddles no GCM-cell edge and has no duplicates); bit 2: this
                                          //      cell is the first-seen exchange cell of its ice cell (ifirst[iI] == x); bits 3 / 4: area > 0 /
                                          //      area != 0 and not > 0
-    ibh::DevBuf<int32_t> mlist;          // [nmulti] ice cells with exchange cells in more than one range
+    ibh::DevBuf<int32_t> mlist;          // [nmulti] ice cells with more than one exchange cell (several ranges, or duplicates)
     int32_t nmulti = 0;
     // [nI] matrix entries an UNMASKED ice cell has per elevation-class slot: groups of duplicate exchange cells (same (iA, iI))
     // with a member of area > 0 (IvA: rows of GvAp) / area != 0 (IvE: rows of GvI); static, so the I-row builds count their
@@ -173,6 +173,13 @@ struct ibh_plan {
     // [nX] the ice-cell index of every exchange cell on its own (ex_indices interleaves it with the atmosphere index, which is
     // constant over a range): the per-range kernels and the streamed count read 4 bytes per cell instead of 8
     ibh::DevBuf<int32_t> exI;
+    // for the streamed build (streamasm.inl): isdup bits 5 (first cell of its range), 6 (its ice cell was first seen in an
+    // EARLIER range: a straddler) and 7 (the next cell is a duplicate of this one); the atmosphere cell of every range; the
+    // longest range (positions inside a range's block of entries are stored in 16 bits when they fit); an area so small that
+    // area * class weight could underflow was seen (the streamed elevation-class builds count by sign classes: not for it)
+    ibh::DevBuf<int32_t> riA;
+    int32_t maxrange = 0;
+    bool tiny = false;
 };
 
 struct ibh_regridder {

@@ -37,12 +37,14 @@ enum { FA_ERR_OLDOVER = 1, FA_ERR_MISSING = 2 };
 
 struct PlanView {
     const int32_t *arng, *aidx, *ilptr, *ilist, *ifirst;
-    const uint8_t *isdup;       // bit 0 duplicate of the previous cell, bit 1 the ice cell lives in this range only, bit 2 first-seen
-                                // cell of its ice cell, bit 3 area > 0, bit 4 area != 0 and not > 0
-    const int32_t *mlist;       // ice cells spread over several ranges
+    const uint8_t *isdup;       // bit 0 duplicate of the previous cell, bit 1 the only exchange cell of its ice cell, bit 2 first-seen
+                                // cell of its ice cell, bit 3 area > 0, bit 4 area != 0 and not > 0, bit 5 first cell of its range,
+                                // bit 6 its ice cell was first seen in an earlier range, bit 7 the next cell is a duplicate of this one
+    const int32_t *mlist;       // ice cells with more than one exchange cell
     int nAr, nmulti;
     const uint8_t *icnt_pos, *icnt_nz;      // static entry counts per ice cell (nullptr: count by visiting), see ibh_plan
     const int32_t *exI;                     // ice-cell index per exchange cell (compact copy of ex_indices[:, 1])
+    const int32_t *riA;                     // atmosphere cell of every range (streamasm.inl)
 };
 
 // ---- static plan ---------------------------------------------------------------------------------
@@ -92,13 +94,11 @@ __global__ void k_plan_ifirst(const int32_t *__restrict__ ilptr, const int32_t *
     const int b = ilptr[i], e = ilptr[i + 1];
     if (e - b > FA_ILMAX) *bad = 1u;
     int f = -1;
-    bool one = true;
     int npos = 0, nnz = 0;
     bool gpos = false, gnz = false;             // the current group of duplicates has a member with area > 0 / != 0
     for (int k = b; k < e; ++k) {
         const double a = area[ilist[k]];
         if (f < 0 && a != 0) f = ilist[k];
-        one = one && aidx[ilist[k]] == aidx[ilist[b]];
         if (!(isdup[ilist[k]] & 1)) { npos += gpos ? 1 : 0; nnz += gnz ? 1 : 0; gpos = gnz = false; }     // a new group starts
         gpos = gpos || a > 0;
         gnz = gnz || a != 0;
@@ -108,8 +108,24 @@ __global__ void k_plan_ifirst(const int32_t *__restrict__ ilptr, const int32_t *
     icnt_pos[i] = (uint8_t)npos; icnt_nz[i] = (uint8_t)nnz;
     ifirst[i] = f;
     if (f >= 0) isdup[f] |= 4;                                     // "this exchange cell is the first-seen one of its ice cell": spares the builds the ifirst gather
-    if (one) for (int k = b; k < e; ++k) isdup[ilist[k]] |= 2;     // exchange cells of one ice cell: no two threads share a byte's bits... (own cells only)
-    multi[i] = (e > b && !one) ? 1u : 0u;
+    (void)aidx;
+    if (e - b == 1) isdup[ilist[b]] |= 2;                          // the only exchange cell of its ice cell (own cell only: no two threads share a byte)
+    multi[i] = (e - b > 1) ? 1u : 0u;
+}
+// bits 5..7 and the atmosphere cell of every range (the streamed build, streamasm.inl); after k_plan_ifirst
+__global__ void k_plan_bits2(const int32_t *__restrict__ exi, const int32_t *__restrict__ aidx, const int32_t *__restrict__ arng,
+                             const int32_t *__restrict__ ifirst, long nX, uint8_t *__restrict__ isdup, int32_t *__restrict__ riA,
+                             uint32_t *__restrict__ maxrange) {
+    const long x = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nX) return;
+    const int r = aidx[x];
+    const int x0 = arng[r];
+    const int f = ifirst[exi[2 * x + 1]];
+    uint8_t b = isdup[x];
+    if (x == x0) { b |= 32; riA[r] = exi[2 * x]; atomicMax(maxrange, (uint32_t)(arng[r + 1] - x0)); }
+    if (f >= 0 && f < x0) b |= 64;
+    if (x + 1 < nX && (isdup[x + 1] & 1)) b |= 128;              // (bit 0 of the neighbour is final since k_plan_flags)
+    isdup[x] = b;
 }
 __global__ void k_plan_mlist(const uint32_t *__restrict__ multi, const uint32_t *__restrict__ mpos, long nI, int32_t *__restrict__ mlist) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -168,7 +184,17 @@ static bool ensure_plan(const ibh_regridder *g, hipStream_t st) {
     uint32_t h_tiny = 0;
     IBH_HIP(hipMemcpy(&h_tiny, d_tiny, sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (h_tiny) { P.icnt_pos.release(); P.icnt_nz.release(); }
+    P.tiny = h_tiny != 0;
     P.nmulti = (int32_t)h[0];
+    P.riA.alloc((size_t)P.nAr);
+    IBH_HIP(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_plan_bits2, dim3(ceil_div(nX, T)), dim3(T), 0, st, g->ex_indices.p, P.aidx.p, P.arng.p, P.ifirst.p, nX, P.isdup.p,
+                       P.riA.p, d_cnt);
+    {
+        uint32_t mr = 0;
+        readback_sync(&mr, d_cnt, sizeof(mr), st);
+        P.maxrange = (int32_t)mr;
+    }
     P.mlist.alloc((size_t)P.nmulti);
     if (P.nmulti) hipLaunchKernelGGL(k_plan_mlist, dim3(ceil_div(nI, T)), dim3(T), 0, st, multi, mpos, nI, P.mlist.p);
     IBH_HIP(hipGetLastError());
@@ -197,7 +223,29 @@ struct FaP {
     uint32_t *poff;             // [nX] their exclusive scan: the dense id of a new key is
                                 //      poff[its first-seen position] -- for an ice cell poff[ifirst[iI]], no table needed
     int64_t *to_sparse;
+    // the streamed build (streamasm.inl) keeps no per-cell table of dense ids: Pw = new keys before every 64 cells, code = one
+    // byte per cell whose bit 0 says "a key is first seen here" -- the id at cell f is two small reads (sa_prank_at)
+    const uint32_t *Pw;
+    const uint8_t *code;
 };
+// number of P keys first seen before exchange cell f = dense id of the key first seen AT f
+__device__ __forceinline__ uint32_t sa_prank_at(const uint32_t *__restrict__ Pw, const uint8_t *__restrict__ code, long f) {
+    const long w = f >> 6;
+    const int k = (int)(f & 63);
+    uint32_t rnk = Pw[w];
+    const unsigned long long *__restrict__ q = reinterpret_cast<const unsigned long long *>(code + (w << 6));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int nb = k - 8 * j;                                     // bytes of this word that lie before f
+        if (nb <= 0) break;
+        const unsigned long long word = q[j] & 0x0101010101010101ull;
+        rnk += (uint32_t)__popcll(nb >= 8 ? word : (word & ((1ull << (8 * nb)) - 1)));
+    }
+    return rnk;
+}
+__device__ __forceinline__ uint32_t fa_poff_at(const uint32_t *__restrict__ poff, const uint32_t *__restrict__ Pw, const uint8_t *__restrict__ code, long f) {
+    return Pw ? sa_prank_at(Pw, code, f) : poff[f];
+}
 __device__ __forceinline__ int fa_class(const RgView &rg, int gkey_kind, long key) {
     if (gkey_kind != KEY_E) return 0;
     long a, hc;
@@ -205,8 +253,8 @@ __device__ __forceinline__ int fa_class(const RgView &rg, int gkey_kind, long ke
     return (int)hc;
 }
 __device__ __forceinline__ int fa_pdense(const FaP &p, const PlanView &pl, long iI, long x) {
-    if (p.key == KEY_I) return p.fresh ? (int)p.poff[pl.ifirst[iI]] : (int)iI;
-    return p.fresh ? (int)p.poff[x] : (int)x;
+    if (p.key == KEY_I) return p.fresh ? (int)fa_poff_at(p.poff, p.Pw, p.code, pl.ifirst[iI]) : (int)iI;
+    return p.fresh ? (int)fa_poff_at(p.poff, p.Pw, p.code, x) : (int)x;
 }
 // is the P key of this entry numbered inside range [x0, ...)?  (then its dense ids ascend along x)
 __device__ __forceinline__ bool fa_pnew(const FaP &p, const PlanView &pl, long iI, long x0) {
@@ -806,12 +854,12 @@ enum { FA_PSUMS = 0, FA_PCOUNT = 1, FA_PEMIT = 2 };
 // 64 registers of full occupancy (a1h IvE 3.15 -> 3.04 ms, IvA 2.09 -> 1.94).
 template <bool WITH_EP, int MODE, bool ANYORDER>
 __global__ __launch_bounds__(FA_T, (WITH_EP && MODE == 2) ? (ANYORDER ? 1 : 6) : 8) void k_fa_pelem(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, long np, FaOut o,
-                                                    uint32_t *__restrict__ rowlen, uint32_t *__restrict__ flags) {
+                                                    uint32_t *__restrict__ rowlen, uint32_t *__restrict__ flags, int only_multi) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     stage_hc<WITH_EP>(rg, s_hc);
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= np) return;
-    if (MODE == FA_PSUMS) q = pl.mlist[q];                    // only the ice cells spread over several ranges (the others: k_fa_range)
+    if (MODE == FA_PSUMS || only_multi) q = pl.mlist[q];      // only the ice cells with several exchange cells (the others: k_fa_range / k_sa_emit)
     // dense id of this element, -1: not a member of the set
     int d = -1;
     int lb = 0, le = 0;
@@ -823,7 +871,7 @@ __global__ __launch_bounds__(FA_T, (WITH_EP && MODE == 2) ? (ANYORDER ? 1 : 6) :
         if (masked && p.fresh) return;                      // not a member of the set: nothing to write
         const int f = pl.ifirst[q];
         if (!p.fresh) d = (int)q;
-        else if (f >= 0) d = (int)p.poff[f];
+        else if (f >= 0) d = (int)fa_poff_at(p.poff, p.Pw, p.code, f);
         if (!masked) { lb = pl.ilptr[q]; le = pl.ilptr[q + 1]; }      // a masked cell has no entries (identity dims: an empty row / column)
     } else {
         d = p.fresh ? (p.pflag[q] ? (int)p.poff[q] : -1) : (int)q;
@@ -1172,6 +1220,8 @@ static void fast_prewarm(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     IBH_HIP(hipStreamSynchronize(st));
 }
 
+static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
+                         const RgView &rg, ibh_weighted *w, hipStream_t st);          // streamasm.inl
 // returns false when the fast path does not apply (nothing has been touched: the caller runs the general pipeline)
 static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
                        const RgView &rg, ibh_weighted *w, hipStream_t st) {
@@ -1179,6 +1229,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     if (!get_tuning("assemble_fast", 1)) return false;
     if (!ensure_plan(gr, st)) return false;
     if (sp->family == FAM_EVA) return get_tuning("assemble_fast_eva", 1) && fast_build_eva(rm, sp, dims, scale, correctA, rg, w, st);
+    if (stream_build(rm, sp, dims, scale, correctA, rg, w, st)) return true;       // large grids: the streamed build
     const bool g_is_row = sp->family == FAM_AEVI;
     ibh_sparse_set *gset = dims[g_is_row ? 0 : 1], *pset = dims[g_is_row ? 1 : 0];
     const int gkey = g_is_row ? sp->row_key : sp->col_key, glist = g_is_row ? sp->row_list : sp->col_list;
@@ -1280,23 +1331,23 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         else FA_LAUNCH_RANGE(false, true, rg, pl, *sp, g, p, merge, o, flags);
         if (p.key == KEY_I && P.nmulti) {                     // Mw of the ice cells that straddle ranges (a few %)
             const dim3 gm(ceil_div(P.nmulti, T));
-            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags);
-            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags);
+            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 0);
+            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 0);
         }
     } else {
         // rows = P: count -> scan -> emit per element; Mw (G columns) from the ranges through a scratch copy of the terms
         uint32_t *rowlen = A.get<uint32_t>((size_t)nrow + 1);
         if (optimistic && p.fresh) IBH_HIP(hipMemsetAsync(rowlen, 0, sizeof(uint32_t) * ((size_t)nrow + 1), st));   // rows beyond the real count
-        if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
-        else hipLaunchKernelGGL((k_fa_pelem<false, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+        if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
+        else hipLaunchKernelGGL((k_fa_pelem<false, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
         exclusive_scan_u32(rowlen, reinterpret_cast<uint32_t *>(w->rowptr.p), (size_t)nrow, reinterpret_cast<uint32_t *>(w->rowptr.p) + nrow, st);
         // (a pre-populated G set may list the columns in another order: the variant with the per-row selection branch)
         if (!g_fresh) {
-            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, true>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
-            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, true>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, true>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
+            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, true>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
         } else {
-            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
-            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags);
+            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
+            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
         }
         FaOut os = o;
         os.val = A.get<double>(nnz);

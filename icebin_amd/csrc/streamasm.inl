@@ -1,0 +1,643 @@
+// streamasm.inl -- the STREAMED build for sorted exchange grids (textually included after fastasm.inl, inside namespace ibh).
+//
+// fastasm.inl gives every range (the exchange cells of one atmosphere cell) a workgroup that walks it pass by pass: dependent
+// load rounds (cell -> mask -> dense id), ranking barriers and the sequential sums all sit in one latency chain per range, and
+// both big kernels read every exchange cell in full (measured on the Antarctic sheet: 2.8-3.5 x the algorithmic traffic at
+// 0.15 / 0.075 of the HBM peak).  Here the heavy reads are STREAMS -- a thread owns a cell, nothing in a thread's load chain
+// depends on another cell -- and everything that is sequential by nature runs on compact per-cell BYTES:
+//
+//   S1  k_sa_flags   stream: per cell one CODE byte {P key first seen here, head of a group with entries, straddler, unmasked}
+//                    and (elevation classes) one CLASS byte {first class, number of classes}; per 64 cells the number of new
+//                    P keys (and, I/X-row matrices, of row entries).  Reads 4 + 1 bytes per cell and the mask gather.
+//   S2  k_sa_ranges  one wave per range, over the bytes only: first-seen order of the classes, entries per class (new /
+//                    straddling), and for every entry its POSITION inside the range's block of entries (16 bits when the
+//                    longest range allows).  What k_fa_count's workgroups computed from full cells.
+//       scans        new P keys per 64 cells -> dense ids (id = prefix of the wave + popcount of the code bits before: no
+//                    per-cell table, an id at any cell f is two small reads); classes / entries per range -> row ids, offsets
+//   S3  k_sa_emit    stream: the cells with entries are evaluated ONCE (area, mask value) and every entry goes straight to
+//                    ebase[range] + position; the dims table, Mw of the one-cell ice cells (A/E-row matrices) or the whole
+//                    row with its weight and scaling (I/X-row matrices: rows come out in x order) from the same pass
+//   S4  k_fa_pelem   the ice cells with several exchange cells (a few %): their Mw / their rows, from the static lists
+//   S5  k_sa_rows    one wave per range: straddlers sorted into place, the sequential sums (spsparse sum() order), weights,
+//                    scaling
+// Same sums in the same order as fastasm.inl, the general pipeline and the oracle: bit-identical (tests force either path).
+// Not served here (fastasm.inl's kernels take them): I-row matrices on an identity I set, plans with underflowing areas (the
+// elevation-class builds count by the sign of the area), EvA / AvE (fast_build_eva).
+
+constexpr int SA_T = 256, SA_CPT = 4, SA_TILE = SA_T * SA_CPT;
+enum { SA_P = 1, SA_ENT = 2, SA_OLD = 4, SA_UNM = 8 };
+
+struct SaBuf {
+    uint8_t *code;          // [nW * 64]
+    uint8_t *cls;           // [nW * 64]   elevation classes: first class | number of classes << 6 (heads of groups only)
+    uint8_t *rl;            // [nW * 64]   I/X-row matrices: entries of the row owned by this cell
+    void *rel;              // [nX * S]    position of every entry inside its range's block (uint16_t / uint32_t)
+    uint8_t *cntP;          // [nW]        new P keys per 64 cells
+    uint32_t *cntL;         // [nW]        row entries per 64 cells (I/X-row matrices)
+    uint32_t *Pw, *Lw;      // their exclusive scans
+};
+
+__device__ __forceinline__ uint32_t sa_wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t sa_wave_excl_u32(uint32_t v, int lane) {
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    return inc - v;
+}
+__device__ __forceinline__ unsigned long long sa_wave_or64(unsigned long long v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { lo |= __shfl_xor(lo, off, 64); hi |= __shfl_xor(hi, off, 64); }
+    lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---- S1: one byte (two) per cell -------------------------------------------------------------------------------------------------
+// The class pattern of an elevation: the classes it lies between and which of the two weights are non-zero
+// (IceRegridder_L0.cpp:127-150).  With no area below 1e-290 in the plan, area * weight != 0 <=> area != 0 and weight != 0.
+struct SaCls { int c0, ncls; bool err; };
+__device__ __forceinline__ SaCls sa_classes(const RgView &rg, double e) {
+    SaCls k{0, 0, false};
+    const double elevation = e < 0.0 ? 0.0 : e;
+    if (rg.interp == 0) {
+        int i1 = dev_lower_bound(rg.hc, rg.nhc, elevation);
+        if (i1 <= 0) i1 = 1;
+        if (i1 >= rg.nhc) { k.err = true; return k; }
+        const int i0 = i1 - 1;
+        const double ratio = (elevation - rg.hc[i0]) / (rg.hc[i1] - rg.hc[i0]);
+        const double w0 = 1.0 - ratio, w1 = ratio;
+        const bool h0 = w0 != 0, h1 = w1 != 0;
+        k.ncls = (h0 ? 1 : 0) + (h1 ? 1 : 0);
+        k.c0 = h0 ? i0 : i1;
+    } else {
+        const int n = rg.nhc;
+        const int i1 = dev_lower_bound(rg.hc, n, elevation);
+        int ih;
+        if (i1 <= 0) ih = 0;
+        else if (i1 >= n) ih = n - 1;
+        else {
+            const int i0 = i1 - 1;
+            const double d0 = fabs(elevation - rg.hc[i0]), d1 = fabs(rg.hc[i1] - elevation);
+            ih = d0 <= d1 ? i0 : i1;
+        }
+        k.ncls = 1; k.c0 = ih;
+    }
+    return k;
+}
+
+// pkey_x: the P side is keyed by exchange cells (nothing merges); p_list: the list that makes an exchange cell a member of an X
+// set (LIST_AP / LIST_EP); prows: I/X-row matrix (row lengths wanted)
+template <bool WITH_EP>
+__global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf sb, int pkey_x, int p_fresh, int p_list, int prows,
+                                                   uint32_t *__restrict__ err_x) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    stage_hc<WITH_EP>(rg, s_hc);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long cb = (long)blockIdx.x * SA_TILE;
+    int iIv[SA_CPT];
+    unsigned fl[SA_CPT];
+    double ev[SA_CPT];
+#pragma unroll
+    for (int u = 0; u < SA_CPT; ++u) {
+        const long x = cb + (long)u * SA_T + tid;
+        const long xx = x < rg.nX ? x : rg.nX - 1;
+        iIv[u] = pl.exI[xx]; fl[u] = pl.isdup[xx];
+    }
+#pragma unroll
+    for (int u = 0; u < SA_CPT; ++u) ev[u] = rg.em[iIv[u]];
+#pragma unroll
+    for (int u = 0; u < SA_CPT; ++u) {
+        const long x = cb + (long)u * SA_T + tid;
+        const bool in = x < rg.nX;
+        const bool unm = in && !(ev[u] != ev[u]);
+        const bool head = pkey_x || !(fl[u] & 1);
+        unsigned ga = fl[u] & 24;                                  // sign classes of the areas of the group this cell heads
+        if (!pkey_x && head && (fl[u] & 128))
+            for (long k = x + 1; k < rg.nX && (pl.isdup[k] & 1); ++k) ga |= pl.isdup[k] & 24;
+        const bool gpos = (ga & 8) != 0, gnz = ga != 0;
+        int n = 0, c0 = 0, ncls_e = 0;
+        if (WITH_EP && unm) {
+            const SaCls k = sa_classes(rg, ev[u]);
+            if (k.err) atomicMin(err_x, (uint32_t)x);
+            else { ncls_e = k.ncls; c0 = k.c0; n = (head && gnz) ? k.ncls : 0; }
+        }
+        const bool ent = head && unm && (WITH_EP ? n > 0 : gpos);
+        bool P;
+        if (!pkey_x) P = unm && (fl[u] & 4);
+        else if (p_list == LIST_AP) P = unm && (fl[u] & 8);
+        else P = n > 0;
+        const bool old = ent && !pkey_x && p_fresh && (fl[u] & 64);
+        if (in) {
+            sb.code[x] = (uint8_t)((P ? SA_P : 0) | (ent ? SA_ENT : 0) | (old ? SA_OLD : 0) | (unm ? SA_UNM : 0));
+            if (WITH_EP) sb.cls[x] = (uint8_t)(c0 | (n << 6));
+        }
+        const unsigned long long bp = __ballot(P);
+        const long xw = cb + (long)u * SA_T + (tid & ~63);
+        if (lane == 0 && xw < rg.nX) sb.cntP[xw >> 6] = (uint8_t)__popcll(bp);
+        if (prows) {
+            // entries of the row this cell owns: a one-cell ice cell / an exchange cell -> its own entries; an ice cell with
+            // several exchange cells -> (groups of duplicates with a contributing member: static, plan) x (classes)
+            uint32_t len = 0;
+            if (P) {
+                if (pkey_x || (fl[u] & 2)) len = ent ? (WITH_EP ? (uint32_t)n : 1u) : 0u;
+                else len = WITH_EP ? (uint32_t)ncls_e * pl.icnt_nz[iIv[u]] : (uint32_t)pl.icnt_pos[iIv[u]];
+            }
+            if (in) sb.rl[x] = (uint8_t)len;
+            const uint32_t tot = sa_wave_sum_u32(len);
+            if (lane == 0 && xw < rg.nX) sb.cntL[xw >> 6] = tot;
+        }
+    }
+}
+
+// ---- S2: one wave per range, over the bytes ------------------------------------------------------------------------------------
+template <bool WITH_EP, typename REL>
+__global__ __launch_bounds__(256) void k_sa_ranges(RgView rg, PlanView pl, SaBuf sb, FaG g, uint32_t *__restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= pl.nAr) return;
+    const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
+    REL *__restrict__ rel = static_cast<REL *>(sb.rel);
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (!WITH_EP) {
+        uint32_t cn = 0, co = 0;
+        for (long cb = x0; cb < x1; cb += 64) {
+            const long x = cb + lane;
+            const unsigned cd = x < x1 ? sb.code[x] : 0u;
+            cn += (uint32_t)__popcll(__ballot((cd & SA_ENT) && !(cd & SA_OLD)));
+            co += (uint32_t)__popcll(__ballot((cd & SA_OLD) != 0));
+        }
+        if (lane == 0) {
+            const bool member = cn + co > 0;
+            g.erank[r] = member ? 0 : -1;
+            g.ecntn[r] = cn; g.ecnto[r] = co;
+            g.r_ncls[r] = member ? 1u : 0u; g.r_nent[r] = cn + co;
+            if (co > (uint32_t)FA_OLDMAX) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
+        }
+        uint32_t runn = 0, runo = 0;
+        for (long cb = x0; cb < x1; cb += 64) {
+            const long x = cb + lane;
+            const unsigned cd = x < x1 ? sb.code[x] : 0u;
+            const bool en = (cd & SA_ENT) && !(cd & SA_OLD), eo = (cd & SA_OLD) != 0;
+            const unsigned long long mn = __ballot(en), mo = __ballot(eo);
+            if (en) rel[x] = (REL)(co + runn + (uint32_t)__popcll(mn & lt));
+            if (eo) rel[x] = (REL)(runo + (uint32_t)__popcll(mo & lt));
+            runn += (uint32_t)__popcll(mn); runo += (uint32_t)__popcll(mo);
+        }
+        return;
+    }
+    // elevation classes: lane c holds the table entry of class c
+    uint32_t first = 0xffffffffu, cn = 0, co = 0;
+    for (long cb = x0; cb < x1; cb += 64) {
+        const long x = cb + lane;
+        const unsigned cd = x < x1 ? sb.code[x] : 0u, cb8 = x < x1 ? sb.cls[x] : 0u;
+        const int n = (int)(cb8 >> 6), c0 = (int)(cb8 & 63);
+        unsigned long long bits = sa_wave_or64(n > 0 ? ((1ull << c0) | (n == 2 ? (2ull << c0) : 0ull)) : 0ull);
+        const unsigned long long men = __ballot((cd & SA_ENT) && !(cd & SA_OLD)), meo = __ballot((cd & SA_OLD) != 0);
+        while (bits) {
+            const int c = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const unsigned long long m0 = __ballot(n > 0 && c0 == c), m1 = __ballot(n == 2 && c0 + 1 == c), mem = m0 | m1;
+            const int l = __builtin_ctzll(mem);
+            const uint32_t pos = 2u * (uint32_t)(cb + l) + (((m0 >> l) & 1) ? 0u : 1u);
+            if (lane == c) {
+                if (first == 0xffffffffu) first = pos;
+                cn += (uint32_t)__popcll(men & mem); co += (uint32_t)__popcll(meo & mem);
+            }
+        }
+    }
+    // first-seen rank of every class of the range, start of its segment inside the range's block of entries
+    const unsigned long long present = __ballot(first != 0xffffffffu);
+    int rank = 0;
+    for (unsigned long long m = present; m; m &= m - 1) {
+        const int k = __builtin_ctzll(m);
+        const uint32_t fk = (uint32_t)__builtin_amdgcn_readlane((int)first, k);
+        rank += fk < first ? 1 : 0;
+    }
+    const uint32_t seg = cn + co;
+    uint32_t start = 0, nent = 0, nold = 0;
+    for (unsigned long long m = present; m; m &= m - 1) {
+        const int k = __builtin_ctzll(m);
+        const int rk = __builtin_amdgcn_readlane(rank, k);
+        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)seg, k), ok = (uint32_t)__builtin_amdgcn_readlane((int)co, k);
+        start += rk < rank ? sk : 0u;
+        nent += sk; nold += ok;
+    }
+    const bool mine = first != 0xffffffffu;
+    if (lane < g.NC) {
+        g.erank[(size_t)r * g.NC + lane] = (int8_t)(mine ? rank : -1);
+        g.ecntn[(size_t)r * g.NC + lane] = cn;
+        g.ecnto[(size_t)r * g.NC + lane] = co;
+        if (mine && g.tab) {                                       // pre-populated set: every key must already be there
+            const long key = (long)pl.riA[r] * rg.sA + (long)lane * rg.sHC;
+            if (g.tab[key] < 0) atomicOr(flags, (uint32_t)FA_ERR_MISSING);
+        }
+        if (!mine && seg) atomicOr(flags, (uint32_t)FA_ERR_MISSING);           // entries of a class that was never listed: cannot happen
+    }
+    if (lane == 0) {
+        g.r_ncls[r] = (uint32_t)__popcll(present); g.r_nent[r] = nent;
+        if (nold > (uint32_t)FA_OLDMAX) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
+    }
+    uint32_t runn = 0, runo = 0;
+    for (long cb = x0; cb < x1; cb += 64) {
+        const long x = cb + lane;
+        const unsigned cd = x < x1 ? sb.code[x] : 0u, cb8 = x < x1 ? sb.cls[x] : 0u;
+        const int n = (int)(cb8 >> 6), c0 = (int)(cb8 & 63);
+        const bool en = (cd & SA_ENT) && !(cd & SA_OLD), eo = (cd & SA_OLD) != 0;
+        unsigned long long bits = sa_wave_or64((en || eo) ? ((1ull << c0) | (n == 2 ? (2ull << c0) : 0ull)) : 0ull);
+        while (bits) {
+            const int c = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const bool s0 = (en || eo) && c0 == c, s1 = (en || eo) && n == 2 && c0 + 1 == c;
+            const unsigned long long mn = __ballot((s0 || s1) && en), mo = __ballot((s0 || s1) && eo);
+            const uint32_t st_c = (uint32_t)__builtin_amdgcn_readlane((int)start, c), co_c = (uint32_t)__builtin_amdgcn_readlane((int)co, c);
+            const uint32_t rn = (uint32_t)__builtin_amdgcn_readlane((int)runn, c), ro = (uint32_t)__builtin_amdgcn_readlane((int)runo, c);
+            if (s0 || s1) {
+                const uint32_t v = en ? st_c + co_c + rn + (uint32_t)__popcll(mn & lt) : st_c + ro + (uint32_t)__popcll(mo & lt);
+                rel[2 * x + (s1 ? 1 : 0)] = (REL)v;
+            }
+            if (lane == c) { runn += (uint32_t)__popcll(mn); runo += (uint32_t)__popcll(mo); }
+        }
+    }
+}
+
+// ---- S3: the entries, the dims table, Mw / the rows -----------------------------------------------------------------------------
+// G_ROWS: A/E-row matrix -- o is the matrix (CSR in place), Mw of the P side.  Otherwise I/X-row matrix -- o is the matrix (rows
+// written here, one per P key), sval / sdid the scratch copy of the terms in (range, class) order for the column sums.
+template <bool WITH_EP, bool G_ROWS, typename REL>
+__global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, SaBuf sb, int merge, FaOut o,
+                                                  double *__restrict__ sval, int32_t *__restrict__ sdid) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    stage_hc<WITH_EP>(rg, s_hc);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const long cb = (long)blockIdx.x * SA_TILE;
+    const REL *__restrict__ rel = static_cast<const REL *>(sb.rel);
+    constexpr int S = WITH_EP ? 2 : 1;
+    const bool pkey_x = p.key == KEY_X;
+    unsigned fl[SA_CPT], cd[SA_CPT];
+#pragma unroll
+    for (int u = 0; u < SA_CPT; ++u) {
+        const long x = cb + (long)u * SA_T + tid;
+        const bool in = x < rg.nX;
+        fl[u] = in ? pl.isdup[x] : 0u; cd[u] = in ? sb.code[x] : 0u;
+    }
+    int iIv[SA_CPT], rv[SA_CPT];
+    double av[SA_CPT];
+    uint32_t lenv[SA_CPT];
+#pragma unroll
+    for (int u = 0; u < SA_CPT; ++u) {
+        const long x = cb + (long)u * SA_T + tid;
+        const bool want = (cd[u] & (SA_ENT | SA_P)) != 0;
+        iIv[u] = want ? pl.exI[x] : 0;
+        rv[u] = want ? pl.aidx[x] : 0;
+        av[u] = (cd[u] & SA_ENT) ? rg.area[x] : 0.0;
+        lenv[u] = (!G_ROWS && x < rg.nX) ? sb.rl[x] : 0u;
+    }
+    double ev[SA_CPT];
+#pragma unroll
+    for (int u = 0; u < SA_CPT; ++u) ev[u] = (WITH_EP && (cd[u] & SA_ENT)) ? rg.em[iIv[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < SA_CPT; ++u) {
+        const long x = cb + (long)u * SA_T + tid;
+        const bool in = x < rg.nX;
+        const long xw = cb + (long)u * SA_T + (tid & ~63);
+        const bool P = (cd[u] & SA_P) != 0, ent = (cd[u] & SA_ENT) != 0, old = (cd[u] & SA_OLD) != 0;
+        const unsigned long long bp = __ballot(P);
+        const int iI = iIv[u], r = rv[u];
+        // dense id of the P key first seen at this cell
+        int pown;
+        if (p.fresh) pown = (xw < rg.nX ? (int)sb.Pw[xw >> 6] : 0) + (int)__popcll(bp & lt);
+        else pown = pkey_x ? (int)x : iI;
+        GEnt ge;
+        ge.n = 0; ge.cls0 = ge.cls1 = 0; ge.t0 = ge.t1 = 0.0; ge.gkey0 = ge.gkey1 = 0;
+        long iA = 0;
+        if (ent) {
+            iA = pl.riA[r];
+            const XCell c = make_cell<WITH_EP>(rg, iA, iI, av[u], ev[u]);
+            if (!(WITH_EP && c.range_error)) fa_group<WITH_EP>(rg, pl, s, G_ROWS, merge != 0 && (fl[u] & 128), c, x, ge);
+        }
+        if (ge.n > 0) {
+            // the entries of this group go to their slots of the range's block
+            int did;
+            if (!p.fresh) did = pkey_x ? (int)x : iI;
+            else if (pkey_x || (fl[u] & 4)) did = pown;
+            else did = (int)sa_prank_at(sb.Pw, sb.code, pl.ifirst[iI]);
+            const uint32_t eb = g.ebase[r];
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                if (j >= ge.n) break;
+                const uint32_t pos = eb + (uint32_t)rel[(size_t)S * x + j];
+                if (G_ROWS) { o.colind[pos] = did; o.val[pos] = ge.t(j); }
+                else { sval[pos] = ge.t(j); if (old) sdid[pos] = did; }
+            }
+        }
+        // ranks of this group's classes in their range (the order of its entries along a row / a column)
+        bool swap01 = false;
+        int id0 = 0, id1 = 0;
+        if (ge.n > 0 && (!G_ROWS || ge.n > 1)) {
+            if (G_ROWS) swap01 = g.erank[(size_t)r * g.NC + ge.cls0] > g.erank[(size_t)r * g.NC + ge.cls1];
+            else {
+                id0 = fa_gdense(g, r, ge.cls0, ge.gkey0);
+                id1 = ge.n > 1 ? fa_gdense(g, r, ge.cls1, ge.gkey1) : 0;
+                swap01 = ge.n > 1 && id0 > id1;
+            }
+        }
+        if (G_ROWS) {
+            if (P) {
+                if (p.fresh) p.to_sparse[pown] = pkey_x ? x : (long)iI;
+                // Mw of an exchange cell / of an ice cell with this one exchange cell: its <= 2 entries in ascending row order,
+                // from zero (spsparse sum()); a member without entries gets 0.  Ice cells with several cells: k_fa_pelem<SUMS>.
+                if (pkey_x || (fl[u] & 2)) {
+                    double sum = 0.0;
+                    if (ge.n == 1) sum = sum + ge.t0;
+                    else if (ge.n == 2) { sum = sum + (swap01 ? ge.t1 : ge.t0); sum = sum + (swap01 ? ge.t0 : ge.t1); }
+                    o.Mw[pown] = sum;
+                }
+            }
+        } else {
+            // rows come out in x order of the cells that own them: offset = row entries before this wave + before this lane
+            const uint32_t before = sa_wave_excl_u32(lenv[u], lane);
+            const uint32_t b0 = (xw < rg.nX ? sb.Lw[xw >> 6] : 0u) + before;
+            if (in && (P || !p.fresh)) o.rowptr[pown] = (int32_t)b0;
+            if (in && !P && !p.fresh) o.wM[pown] = 0.0;                  // identity set: a cell that is no member has an empty row
+            if (P) {
+                if (p.fresh) p.to_sparse[pown] = pkey_x ? x : (long)iI;
+                if (pkey_x || (fl[u] & 2)) {
+                    // FAM_IVAE rows (RegridMatrices_Dynamic.cpp:201-233): wM = rowsum by ascending column, M = [1/wM] * T [* sApvA]
+                    double sum = 0.0;
+                    const double ta = swap01 ? ge.t1 : ge.t0, tb = swap01 ? ge.t0 : ge.t1;
+                    if (ge.n >= 1) sum = sum + ta;
+                    if (ge.n == 2) sum = sum + tb;
+                    o.wM[pown] = sum;
+                    auto finish = [&](double t) {
+                        double v = t;
+                        if (o.scale) v = (1.0 / sum) * v;
+                        if (o.correctA) v = v * rg.ratioA[iA];
+                        return v;
+                    };
+                    if (ge.n >= 1) { o.colind[b0] = swap01 ? id1 : id0; o.val[b0] = finish(ta); }
+                    if (ge.n == 2) { o.colind[b0 + 1] = swap01 ? id0 : id1; o.val[b0 + 1] = finish(tb); }
+                }
+            }
+        }
+    }
+}
+
+// ---- S5: one wave per range -- straddlers into place, sequential sums, weights, scaling --------------------------------------------
+// EMIT: the rows of an A/E-row matrix (CSR in place: o.colind / o.val).  Otherwise the column sums of an I/X-row matrix over the
+// scratch copy of the terms (o.val = scratch, sdid = the row ids of the straddling terms).
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, FaOut o, int32_t *__restrict__ sdid, uint32_t *__restrict__ flags) {
+    __shared__ int s_did[4][FA_OLDMAX], s_did2[4][FA_OLDMAX];
+    __shared__ double s_t[4][FA_OLDMAX], s_t2[4][FA_OLDMAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wv;
+    if (r >= pl.nAr) return;
+    if (EMIT && r == pl.nAr - 1 && lane == 0) o.rowptr[g.gbase[pl.nAr]] = (int32_t)g.ebase[pl.nAr];      // rowptr[nrow] = nnz
+    const int ncls = (int)g.r_ncls[r];
+    if (ncls == 0) return;
+    const uint32_t eb = g.ebase[r];
+    int rank = -1;
+    uint32_t seg = 0, nold_c = 0;
+    if (lane < g.NC) {
+        rank = g.erank[(size_t)r * g.NC + lane];
+        nold_c = g.ecnto[(size_t)r * g.NC + lane];
+        seg = g.ecntn[(size_t)r * g.NC + lane] + nold_c;
+    }
+    int32_t *__restrict__ ids = EMIT ? o.colind : sdid;
+    uint32_t start = 0;
+    for (int q = 0; q < ncls; ++q) {
+        const unsigned long long mq = __ballot(rank == q);
+        if (!mq) break;                                          // (cannot happen: ranks 0 .. ncls-1 are all taken)
+        const int cls = __builtin_ctzll(mq);
+        const uint32_t sg = (uint32_t)__builtin_amdgcn_readlane((int)seg, cls);
+        uint32_t no = (uint32_t)__builtin_amdgcn_readlane((int)nold_c, cls);
+        if (no > (uint32_t)FA_OLDMAX) no = FA_OLDMAX;            // (the build is being discarded: FA_ERR_OLDOVER; stay inside the tables)
+        const uint32_t b = eb + start, e = b + sg;
+        start += sg;
+        // the straddling entries (ice cells first seen in an earlier range: smaller ids) lie at the segment's start in x order:
+        // into ascending id order -- inside a class the ids are distinct: rank by counting
+        for (uint32_t k = lane; k < no; k += 64) { s_did[wv][k] = ids[b + k]; s_t[wv][k] = o.val[b + k]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = lane; k < no; k += 64) {
+            const int did = s_did[wv][k];
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < no; ++j) cnt += s_did[wv][j] < did ? 1u : 0u;
+            s_did2[wv][cnt] = did; s_t2[wv][cnt] = s_t[wv][k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double sum = 0.0;
+        for (uint32_t k = 0; k < no; ++k) sum = sum + s_t2[wv][k];
+        // the entries first seen in this range follow in x order: 64 values loaded coalesced, the chain replayed from registers
+        for (uint32_t base = b + no; base < e; base += 64) {
+            const uint32_t k = base + lane;
+            const double v = k < e ? o.val[k] : 0.0;
+            const int cnt = (int)min(64u, e - base);
+            const int lo = __double2loint(v), hi = __double2hiint(v);
+            if (cnt == 64) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j)
+                    sum = sum + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+            } else {
+                for (int j = 0; j < cnt; ++j)
+                    sum = sum + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+            }
+        }
+        const long iA = pl.riA[r];
+        const long gkey = g.key == KEY_E ? iA * rg.sA + (long)cls * rg.sHC : iA;
+        const int gd = fa_gdense(g, r, cls, gkey);
+        if (gd < 0) continue;                                   // a key the pre-populated set lacks: the build is discarded (FA_ERR_MISSING)
+        double mul = 1.0;
+        if (EMIT) {                                            // FAM_AEVI rows (RegridMatrices_Dynamic.cpp:100-146)
+            double wM;
+            if (o.correctA) {
+                const double rr = ratio_of(rg, g.key, gkey);
+                wM = rr * sum;
+                if (o.scale) mul = (1.0 / rr) * (1.0 / sum);
+            } else {
+                wM = sum;
+                if (o.scale) mul = 1.0 / sum;
+            }
+            if (lane == 0) {
+                if (g.to_sparse) g.to_sparse[gd] = gkey;
+                o.wM[gd] = wM;
+                o.rowptr[gd] = (int32_t)b;
+            }
+            for (uint32_t k = lane; k < no; k += 64) {
+                o.colind[b + k] = s_did2[wv][k];
+                o.val[b + k] = o.scale ? mul * s_t2[wv][k] : s_t2[wv][k];
+            }
+            if (o.scale)
+                for (uint32_t k = b + no + lane; k < e; k += 64) o.val[k] = mul * o.val[k];
+        } else if (lane == 0) {                                // FAM_IVAE columns (:201-233)
+            if (g.to_sparse) g.to_sparse[gd] = gkey;
+            o.Mw[gd] = o.correctA ? ratio_of(rg, g.key, gkey) * sum : sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+// false: not served here (nothing has been touched: fast_build's own kernels run next)
+static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
+                         const RgView &rg, ibh_weighted *w, hipStream_t st) {
+    const ibh_regridder *gr = rm->rg;
+    const ibh_plan &P = gr->plan;
+    const long nX = gr->nX;
+    if (sp->family == FAM_EVA) return false;
+    if (!get_tuning("assemble_stream", nX >= (1l << 20) ? 1 : 0)) return false;
+    const bool g_is_row = sp->family == FAM_AEVI;
+    ibh_sparse_set *gset = dims[g_is_row ? 0 : 1], *pset = dims[g_is_row ? 1 : 0];
+    const int gkey = g_is_row ? sp->row_key : sp->col_key, glist = g_is_row ? sp->row_list : sp->col_list;
+    const int pkey = g_is_row ? sp->col_key : sp->row_key, plist = g_is_row ? sp->col_list : sp->row_list;
+    auto extent_of = [&](int key) -> int64_t {
+        return key == KEY_A ? gr->nA : key == KEY_E ? gr->nA * (int64_t)gr->nhc : key == KEY_I ? gr->nI : gr->nX;
+    };
+    const int pmode = fa_pset_mode(pset, extent_of(pkey));
+    if (pmode < 0) return false;
+    const bool g_fresh = gset->n == 0;
+    if (!g_fresh && (gset->identity || gkey != KEY_E || g_is_row)) return false;
+    const bool uses_ep = sp->row_list == LIST_EP || sp->col_list == LIST_EP;
+    if (uses_ep && (P.tiny || !P.icnt_nz.p)) return false;         // classes are counted by the sign of the area here
+    if (!P.icnt_pos.p) return false;
+    if (!g_is_row && pkey == KEY_I && pmode == 0) return false;    // rows in ice-cell order, not in first-seen order: fastasm.inl
+    const int merge = (sp->row_key != KEY_X && sp->col_key != KEY_X) ? 1 : 0;
+    const int S = uses_ep ? 2 : 1;
+    const bool rel32 = (int64_t)S * P.maxrange > 65535;
+
+    Arena &A = arena();
+    A.reset();
+    PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti, P.icnt_pos.p, P.icnt_nz.p, P.exI.p};
+    pl.riA = P.riA.p;
+    const int T = FA_T, nAr = P.nAr;
+    const long nW = ceil_div(nX, 64l);
+    FaG g{};
+    g.key = gkey; g.list = glist; g.NC = gkey == KEY_E ? gr->nhc : 1;
+    const size_t nrc = (size_t)nAr * g.NC;
+    g.erank = A.get<int8_t>(nrc); g.ecntn = A.get<uint32_t>(nrc); g.ecnto = A.get<uint32_t>(nrc);
+    g.r_ncls = A.get<uint32_t>((size_t)nAr); g.r_nent = A.get<uint32_t>((size_t)nAr);
+    g.gbase = A.get<uint32_t>((size_t)nAr + 1); g.ebase = A.get<uint32_t>((size_t)nAr + 1);
+    const int64_t gext = extent_of(gkey);
+    if (!g_fresh) g.tab = set_inverse_table(gset, gext, st);
+    FaP p{};
+    p.key = pkey; p.list = plist; p.fresh = pmode;
+    SaBuf sb{};
+    sb.code = A.get<uint8_t>((size_t)nW * 64);
+    if (uses_ep) sb.cls = A.get<uint8_t>((size_t)nW * 64);
+    if (!g_is_row) { sb.rl = A.get<uint8_t>((size_t)nW * 64); sb.cntL = A.get<uint32_t>((size_t)nW); sb.Lw = A.get<uint32_t>((size_t)nW); }
+    sb.rel = A.get_bytes((size_t)nX * S * (rel32 ? 4 : 2));
+    sb.cntP = A.get<uint8_t>((size_t)nW); sb.Pw = A.get<uint32_t>((size_t)nW);
+    p.Pw = sb.Pw; p.code = sb.code;
+    // counters read back with one sync: [0] first out-of-range cell, [1] fallback flags, [2] new P keys, [3] G classes, [4] entries
+    uint32_t *d_cnt = A.get<uint32_t>(8);
+    hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
+    const dim3 gs(ceil_div(nX, (long)SA_TILE)), gr4(ceil_div(nAr, 4));
+    if (uses_ep) hipLaunchKernelGGL((k_sa_flags<true>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt);
+    else hipLaunchKernelGGL((k_sa_flags<false>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt);
+    if (uses_ep) {
+        if (rel32) hipLaunchKernelGGL((k_sa_ranges<true, uint32_t>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1);
+        else hipLaunchKernelGGL((k_sa_ranges<true, uint16_t>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1);
+    } else {
+        if (rel32) hipLaunchKernelGGL((k_sa_ranges<false, uint32_t>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1);
+        else hipLaunchKernelGGL((k_sa_ranges<false, uint16_t>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1);
+    }
+    if (p.fresh) exclusive_scan_u8(sb.cntP, sb.Pw, (size_t)nW, d_cnt + 2, st);
+    if (!g_is_row) exclusive_scan_u32(sb.cntL, sb.Lw, (size_t)nW, nullptr, st);
+    if (nAr > 4096 && fa_rscan_many(g, nAr, nullptr, d_cnt + 3, nullptr, st)) {
+    } else if (nAr > 4096) {
+        exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
+        exclusive_scan_u32(g.r_nent, g.ebase, (size_t)nAr, g.ebase + nAr, st);
+        IBH_HIP(hipMemcpyAsync(d_cnt + 3, g.gbase + nAr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        IBH_HIP(hipMemcpyAsync(d_cnt + 4, g.ebase + nAr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(k_fa_rscan, dim3(1), dim3(1024), 0, st, g.r_ncls, g.r_nent, nAr, g.gbase, g.ebase, d_cnt + 3);
+    }
+    IBH_HIP(hipGetLastError());
+    uint32_t h[8];
+    auto check_counters = [&]() -> bool {
+        readback_sync(h, d_cnt, sizeof(h), st);
+        if (h[0] != 0xffffffffu) {                              // message of linterp_1d_b, IceRegridder_L0.cpp:84-85
+            int32_t ij[2];
+            IBH_HIP(hipMemcpy(ij, gr->ex_indices.p + 2 * (size_t)h[0], sizeof(ij), hipMemcpyDeviceToHost));
+            double e = 0;
+            IBH_HIP(hipMemcpy(&e, rm->elevmaskI.p + ij[1], sizeof(double), hipMemcpyDeviceToHost));
+            fail(IBH_ERANGE, "Elevation %g out of bounds (%g, %g)", e < 0 ? 0.0 : e, gr->hcdefs_h.front(), gr->hcdefs_h.back());
+        }
+        if (h[1]) return false;                                 // a limit of the fast path was hit: general pipeline
+        IBH_CHECK(h[4] < (1u << 31) && h[2] < (1u << 31), "matrix too large for int32 indices");
+        return true;
+    };
+    if (!check_counters()) return false;
+    const uint32_t nnz = h[4];
+    const int np_d = p.fresh ? (int)h[2] : (int)extent_of(pkey);
+    const int ng_d = g_fresh ? (int)h[3] : gset->n;
+    DevBuf<int64_t> ptable, gtable;
+    if (p.fresh) { ptable.alloc((size_t)np_d); p.to_sparse = ptable.p; }
+    if (g_fresh) { gtable.alloc((size_t)ng_d); g.to_sparse = gtable.p; }
+    const int nrow = g_is_row ? ng_d : np_d, ncol = g_is_row ? np_d : ng_d;
+    w->nrow = nrow; w->ncol = ncol; w->nnz = nnz;
+    w->rowptr.alloc((size_t)nrow + 1); w->colind.alloc(nnz); w->val.alloc(nnz);
+    w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
+    FaOut o{w->rowptr.p, w->colind.p, w->val.p, w->wM.p, w->Mw.p, sp->family, scale, correctA, 0};
+    uint32_t *flags = d_cnt + 1;
+    double *sval = nullptr;
+    int32_t *sdid = nullptr;
+#define SA_LAUNCH_EMIT(EP, GR)                                                                                                  \
+    do {                                                                                                                        \
+        if (rel32) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint32_t>), gs, dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
+        else hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t>), gs, dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid);       \
+    } while (0)
+    if (g_is_row) {
+        if (ncol && !p.fresh) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
+        if (uses_ep) SA_LAUNCH_EMIT(true, true); else SA_LAUNCH_EMIT(false, true);
+        if (p.key == KEY_I && P.nmulti) {                     // Mw of the ice cells with several exchange cells
+            const dim3 gm(ceil_div(P.nmulti, T));
+            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
+            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
+        }
+        hipLaunchKernelGGL((k_sa_rows<true>), gr4, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, flags);
+    } else {
+        sval = A.get<double>(nnz); sdid = A.get<int32_t>(nnz);
+        IBH_HIP(hipMemcpyAsync(w->rowptr.p + nrow, d_cnt + 4, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        if (uses_ep) SA_LAUNCH_EMIT(true, false); else SA_LAUNCH_EMIT(false, false);
+        if (p.key == KEY_I && P.nmulti) {                     // the rows of the ice cells with several exchange cells
+            const dim3 gm(ceil_div(P.nmulti, T));
+            if (!g_fresh) {
+                if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, true>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
+                else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, true>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
+            } else {
+                if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
+                else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
+            }
+        }
+        if (!g_fresh && ncol) hipLaunchKernelGGL(k_fa_zero_identity, dim3(ceil_div(ncol, T)), dim3(T), 0, st, w->Mw.p, (long)ncol);
+        FaOut os = o;
+        os.val = sval;
+        hipLaunchKernelGGL((k_sa_rows<false>), gr4, dim3(256), 0, st, rg, pl, g, os, sdid, flags);
+    }
+#undef SA_LAUNCH_EMIT
+    IBH_HIP(hipGetLastError());
+    auto commit = [&](ibh_sparse_set *set, int64_t extent, DevBuf<int64_t> &table, int n) {
+        set->sparse_extent = extent;
+        if (n == 0) return;
+        set->host.clear(); set->host_n = 0; set->inv.clear(); set->inv_n = 0;
+        set->dev = std::move(table);
+        set->dev_n = set->n = n;
+        set->identity = false;
+    };
+    if (p.fresh) commit(pset, extent_of(pkey), ptable, np_d); else if (pset->sparse_extent != extent_of(pkey)) pset->sparse_extent = extent_of(pkey);
+    if (g_fresh) commit(gset, gext, gtable, ng_d); else if (gset->sparse_extent != gext) gset->sparse_extent = gext;
+    IBH_HIP(hipStreamSynchronize(st));
+    w->built_fast = 2;
+    // (flags raised by the later kernels -- a straddler list that overflowed -- cannot differ from the count pass's; checked there)
+    return true;
+}

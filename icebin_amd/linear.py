@@ -366,6 +366,12 @@ class linear_Weighted:
         check(lib().ibh_weighted_built_fast(self._h, C.byref(v)))
         return bool(v.value)
 
+    def built_streamed(self):
+        """True when the streamed variant of the plan-based assembly (streamasm.inl: large sorted grids) built this matrix."""
+        v = C.c_int()
+        check(lib().ibh_weighted_built_fast(self._h, C.byref(v)))
+        return v.value == 2
+
     def last_kernel(self):
         buf = C.create_string_buffer(32)
         check(lib().ibh_weighted_last_kernel(self._h, buf, 32))

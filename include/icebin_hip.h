@@ -319,7 +319,13 @@ int ibh_comm_info(const ibh_comm *c, int *world, int *rank);
  * (0: chosen by size -- one exchange for KB-sized results, blocks of >= 8 fields and ~128 MB for the GB-sized results of
  * the I-row matrices) so that it overlaps the SpMM of the following block and of the following apply.  dB_all is complete once
  * ibh_comm_wait(c, s) has made stream s wait for the exchanges enqueued so far.  Same results as ibh_weighted_apply_device
- * on each rank's fields (bitwise), conservative matrices only (no force_conservation). */
+ * on each rank's fields (bitwise), conservative matrices only (no force_conservation).
+ * ldb: when ldb - nrow_d < 64 the gap is taken to be plane padding owned by the call (the library's own buffers round planes
+ * up to 512 bytes) and travels with the planes -- peers' padding is overwritten; a wider gap is a true leading dimension
+ * (a column view of a larger array): every plane then travels by itself and nothing outside [0, nrow_d) of a plane is touched.
+ * Streams: any stream may issue applies and waits on one communicator; an apply whose results overlap an exchange still in
+ * flight is ordered behind it whichever stream enqueued that exchange (the last 8 exchanges are tracked individually, older
+ * unfinished ones through the range hull of their successor). */
 int ibh_weighted_apply_sharded_device(const ibh_weighted *w, ibh_comm *c, const double *dA_local, int32_t nvar_local,
                                       int64_t lda, double *dB_all, int64_t ldb, double fill, int32_t block_fields,
                                       void *stream);
@@ -342,8 +348,9 @@ int ibh_weighted_device_view_get(const ibh_weighted *w, ibh_weighted_device_view
 /* Tuning / introspection (not part of the reference interface). */
 int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow", "rowdual", "colsweep", "rowgroup" */
 int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
-/* 1 when the matrix was assembled by the plan-based fast path for sorted exchange grids (fastasm.inl), 0 when the
- * general pipeline built it (ibh_set_tuning("assemble_fast", 0) forces the latter).  Results are bit-identical. */
+/* 1 when the matrix was assembled by the plan-based fast path for sorted exchange grids (fastasm.inl), 2 when its streamed
+ * variant did (streamasm.inl: grids of 2^20 exchange cells and more; ibh_set_tuning("assemble_stream", 0 | 1) overrides),
+ * 0 when the general pipeline built it (ibh_set_tuning("assemble_fast", 0) forces the latter).  Results are bit-identical. */
 int ibh_weighted_built_fast(const ibh_weighted *w, int *out);
 /* Launch-heuristic overrides for measurements and tests (README.md lists the keys: assemble_fast, assemble_fast_eva,
  * assemble_range_shape, assemble_stream_count, assemble_static_count, rowgroup_*, rowone*, rowblock_*, shortrow_*, sweep_*,

@@ -108,9 +108,9 @@ class SparseSet:
                 lib().orc_sset_add_dense(self._h, int(s))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_sset_free(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _LIB is not None:          # (at interpreter shutdown the module globals may already be gone: leak, do not raise)
+            _LIB.orc_sset_free(h)
 
     @property
     def dense_extent(self):
@@ -160,9 +160,9 @@ class Weighted:
         L.orc_weighted_coo(h, _p(self.row), _p(self.col), _p(self.val))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_weighted_free(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _LIB is not None:
+            _LIB.orc_weighted_free(h)
 
     @classmethod
     def from_coo(cls, nrow, ncol, row, col, val, wM, Mw, conservative=True, scaled=True):

@@ -89,3 +89,23 @@ def test_cython_module_builds_and_has_the_reference_surface():
     if _capi.device_count() == 0:
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             g.add_sheet("s", dict(nI=2), dict(indices=[[0, 0], [1, 1]], overlaps=[1., 1.]))
+
+
+def test_missing_rccl_is_enotimpl_not_a_crash(lib):
+    # with no librccl to be found, ibh_comm_unique_id must return IBH_ENOTIMPL ("multi-GPU exchange needs RCCL")
+    # -- it used to build a std::string from dlerror()'s second, NULL, return.  A fresh process without torch (whose bundled
+    # librccl would already be in the process), ICEBIN_RCCL_LIB naming a file that does not exist.
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "L = C.CDLL(%r)\n"
+        "L.ibh_last_error.restype = C.c_char_p\n"
+        "buf = C.create_string_buffer(128)\n"
+        "rc = L.ibh_comm_unique_id(buf)\n"
+        "print(rc, L.ibh_last_error().decode())\n" % os.path.join(ROOT, "icebin_amd", "lib", "libicebin_hip.so"))
+    env = dict(os.environ, ICEBIN_RCCL_LIB="/nonexistent/librccl.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rc, msg = r.stdout.strip().split(" ", 1)
+    assert int(rc) == _capi.IBH_ENOTIMPL and "needs RCCL" in msg and "/nonexistent/librccl.so" in msg, r.stdout

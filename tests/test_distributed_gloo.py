@@ -247,19 +247,31 @@ def _worker_sharded(rank, world, port, q):
         state = {}
 
         def exchange(d_base, count, stride, w_, r_, stream):
-            # every rank's `count` doubles at d_base + rank*stride -> the same place on every peer (gloo, through the host)
+            # every rank's `count` doubles at d_base + rank*stride -> the same place on every peer (gloo, through the host).
+            # STREAM-ORDERED: the copies are asynchronous on the stream the library hands over (its exchange stream) and only
+            # THAT stream is waited for, never the device -- if the library did not order its exchange stream behind the SpMM
+            # that produces the block (ready event), the block read here would still hold the -9 the test filled it with
             flat = state["out"]
             off = (d_base - flat.data_ptr()) // 8
-            torch.cuda.synchronize()
-            mine = flat[off + r_ * stride: off + r_ * stride + count].cpu()
-            parts = [torch.empty_like(mine) for _ in range(w_)]
-            dist.all_gather(parts, mine)
-            for p in range(w_):
-                if p != r_:
-                    flat[off + p * stride: off + p * stride + count].copy_(parts[p])
-            torch.cuda.synchronize()
+            xs = torch.cuda.ExternalStream(stream)
+            with torch.cuda.stream(xs):
+                def carve():          # from ONE pinned buffer allocated up front (a pinned allocation may synchronise the device)
+                    a = state["pin"][state["pin_off"]: state["pin_off"] + count]
+                    state["pin_off"] += count
+                    assert a.numel() == count
+                    return a
+                mine = carve()
+                mine.copy_(flat[off + r_ * stride: off + r_ * stride + count], non_blocking=True)
+                xs.synchronize()
+                parts = [carve() for _ in range(w_)]
+                dist.all_gather(parts, mine)
+                for p in range(w_):
+                    if p != r_:
+                        flat[off + p * stride: off + p * stride + count].copy_(parts[p], non_blocking=True)
             state["calls"] = state.get("calls", 0) + 1
+            state.setdefault("counts", []).append(int(count))
         comm = Communicator(world, rank, exchange=exchange)
+        state["pin"], state["pin_off"] = torch.empty(1 << 21, dtype=torch.float64).pin_memory(), 0
         ok = True
         ncalls = []
         for name, nl, bf in _sharded_cases():
@@ -268,7 +280,7 @@ def _worker_sharded(rank, world, port, q):
             x_all[1, 5] = np.nan
             ld = (w.nrow_d + 63) // 64 * 64
             store = torch.full((world * nl, ld), -9.0, dtype=torch.float64, device="cuda")
-            state["out"], state["calls"] = store.view(-1), 0
+            state["out"], state["calls"], state["pin_off"] = store.view(-1), 0, 0
             x_loc = torch.from_numpy(x_all[rank * nl:(rank + 1) * nl].copy()).cuda()
             out = apply_sharded(w, comm, x_loc, out_all=store[:, : w.nrow_d], fill=-2.0, block_fields=bf)
             comm.wait()
@@ -283,12 +295,29 @@ def _worker_sharded(rank, world, port, q):
                                           for f0 in range(0, nl, bf)])
                 got = out[p * nl:(p + 1) * nl].cpu().numpy()
                 ok = ok and bool(np.array_equal(got.view(np.uint64), ref.view(np.uint64)))
+        # ldb as a TRUE leading dimension: the result is a column view of a wider array whose other columns are live data
+        # (ADVICE r03): every plane travels by itself (nrow doubles), nothing outside the view changes on any rank
+        w, nl = rm.matrix("AvI"), 3
+        wide = torch.full((world * nl, w.nrow_d + 200), float(rank + 7), dtype=torch.float64, device="cuda")
+        state["out"], state["calls"], state["counts"], state["pin_off"] = wide.view(-1), 0, [], 0
+        x_all = syn.fields(world * nl, w.ncol_d, seed=41)
+        x_loc = torch.from_numpy(x_all[rank * nl:(rank + 1) * nl].copy()).cuda()
+        out = apply_sharded(w, comm, x_loc, out_all=wide[:, 100: 100 + w.nrow_d], fill=-2.0)
+        comm.wait()
+        torch.cuda.synchronize()
+        ok = ok and state["calls"] == nl and set(state["counts"]) == {w.nrow_d}
+        hw = wide.cpu().numpy()
+        ok = ok and bool(np.all(hw[:, :100] == rank + 7) and np.all(hw[:, 100 + w.nrow_d:] == rank + 7))
+        for p in range(world):
+            xp = torch.from_numpy(x_all[p * nl:(p + 1) * nl].copy()).cuda()
+            ref = w.apply_device(xp, fill=-2.0, force_conservation=False).cpu().numpy()
+            ok = ok and bool(np.array_equal(np.ascontiguousarray(hw[p * nl:(p + 1) * nl, 100: 100 + w.nrow_d]).view(np.uint64), ref.view(np.uint64)))
         # several field batches: one SpMM launch, one grouped exchange (the transport is called once per result here)
         from icebin_amd.distributed import apply_many_sharded
         w, nl, nb = rm.matrix("AvI"), 4, 3
         ld = (w.nrow_d + 63) // 64 * 64
         big = torch.full((nb, world * nl, ld), -9.0, dtype=torch.float64, device="cuda")
-        state["out"], state["calls"] = big.view(-1), 0
+        state["out"], state["calls"], state["pin_off"] = big.view(-1), 0, 0
         x_all = [syn.fields(world * nl, w.ncol_d, seed=31 + k) for k in range(nb)]
         xs = [torch.from_numpy(xa[rank * nl:(rank + 1) * nl].copy()).cuda() for xa in x_all]
         outs = apply_many_sharded(w, comm, xs, [big[k][:, : w.nrow_d] for k in range(nb)], fill=-2.0)
@@ -310,7 +339,8 @@ def test_sharded_apply_two_ranks_over_a_custom_transport():
     """ibh_weighted_apply_sharded_device with world 2: two processes share the box's GPU (RCCL refuses two ranks on one
     device), the exchange goes through ibh_comm_create_custom -- a gloo all-gather staged through the host -- so the library's
     own choreography runs with a peer: the local SpMM straight into this rank's rows of the gathered array, the exchange per
-    field block with the right offsets / counts / strides, ordering between SpMM and exchange, ibh_comm_wait."""
+    field block with the right offsets / counts / strides, ordering between SpMM and exchange (the transport is asynchronous on
+    the exchange stream and never synchronises the device), a result that is a column view of a wider array, ibh_comm_wait."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

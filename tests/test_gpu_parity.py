@@ -634,7 +634,8 @@ def test_config4_1km_64_fields_benched_kernels_against_the_oracle():
 
 def test_config5_antarctica_1km_assembly_and_apply_properties():
     # BASELINE config 5 (the Antarctic sheet, 36 012 001 ice cells, 1/2 deg GCM): COO -> CSR assembly +
-    # apply at full size.  Too large for the single-core oracle: checked through properties.
+    # apply at full size, through size-independent properties (the bit-level comparison with the oracle at this size is
+    # test_config5_full_size_assembly_is_the_oracle_bitwise below).
     g = _big_grids("a1h")
     assert g["nI"] == 36012001
     em = syn.dome_elevmask(g)
@@ -669,7 +670,8 @@ def test_config5_antarctica_1km_assembly_and_apply_properties():
 
 
 def _sheet_properties(config, names, nI_expected):
-    """Size-independent checks of a full-size sheet (too large for the single-core oracle): structure,
+    """Size-independent checks of a full-size sheet (the oracle comparison at this size goes through committed hashes:
+    test_config5_full_size_assembly_is_the_oracle_bitwise): structure,
     scaled rows sum to 1, sum(wM) == sum(Mw) == unmasked overlap area, conservation < 1e-13, and the
     constant field survives the round trips."""
     g = _big_grids(config)
@@ -720,6 +722,43 @@ def test_config5_antarctica_1km_elevation_class_matrices():
     one = np.ones((1, EvI.ncol_d))
     back = IvE.apply(EvI.apply(one)[:, np.argsort(EvI.dim(0))[np.searchsorted(np.sort(EvI.dim(0)), IvE.dim(1))]])
     assert np.all(np.abs(back - 1.0) < 1e-11)
+
+
+@pytest.mark.parametrize("config", ["g1h", "a1h"])
+def test_config5_full_size_assembly_is_the_oracle_bitwise(config):
+    """BASELINE config 5 at FULL size against the oracle, bit for bit: both sheets (Antarctica 1 km and
+    Greenland 1 km under the 1/2 deg GCM grid), all ten matrices, all four (scale, correctA) branches of
+    RegridMatrices_Dynamic.cpp:50-332.  The oracle's side was computed in the build container (16-30 s and 6 GB per Antarctic
+    matrix on one core: tests/golden/make_config5_hashes.py) and is committed as SHA-256 of dims / row / col / val / wM / Mw in
+    tests/golden/config5_oracle_hashes.json; here the same seeded inputs (their hashes are pinned too) go through the C-ABI and
+    the hashes of what comes back must be equal."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_config5_hashes", os.path.join(here, "golden", "make_config5_hashes.py"))
+    # (only its hashing helpers are used: importing the module imports the oracle wrapper but calls nothing in it)
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = json.load(open(os.path.join(here, "golden", "config5_oracle_hashes.json")))[config]
+    g = _big_grids(config)
+    em = syn.dome_elevmask(g)
+    assert mk.input_hashes(g, em) == gold["inputs"], "the synthetic inputs changed: regenerate tests/golden/config5_oracle_hashes.json"
+    mm = icebin_amd.from_synthetic(g)
+    n = 0
+    for scale, correctA in mk.BRANCHES:
+        rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
+        for name in ALL:
+            key = "%s scale=%d correctA=%d" % (name, scale, correctA)
+            want = {k: v for k, v in gold["matrices"][key].items() if k != "oracle_seconds"}
+            w = rm.matrix(name)
+            assert w.built_fast(), key                       # the plan-based build is what the bench times
+            row, col, val = w.coo_dense()
+            got = mk.weighted_hashes(w.nrow_d, w.ncol_d, w.nnz, w.dim(0), w.dim(1), row, col, val, w.wM, w.Mw)
+            assert got == want, (config, key, {k: (got[k], want[k]) for k in got if got[k] != want[k]})
+            n += 1
+            del w, row, col, val
+    assert n == 40
 
 
 def test_config5_antarctica_eva_ave_fast_build_is_the_general_pipeline_bitwise():
@@ -2004,16 +2043,76 @@ def test_random_sorted_grids_on_every_variant_of_the_plan_based_build(seed):
         icebin_amd.set_tuning("assemble_stream_count", 1)
         icebin_amd.set_tuning("assemble_range_shape", seed % 3)
         icebin_amd.set_tuning("assemble_static_count", seed % 2)
-        fast = 0
-        for name in ALL:
-            for scale, correctA in ((True, True), (False, False)):
-                w = rm.matrix_d(name, scale=scale, correctA=correctA)
-                fast += int(w.built_fast())
-                assert_same_weighted(w, rg.matrix_d(name, em, scale=scale, correctA=correctA), "%s seed=%d" % (name, seed))
-        assert fast >= 12, fast                 # (EvA / AvE with negative areas, and little else, go to the general pipeline)
+        for stream in (0, 1):                   # the per-range kernels (fastasm.inl), then the streamed build (streamasm.inl)
+            icebin_amd.set_tuning("assemble_stream", stream)
+            fast = streamed = 0
+            for name in ALL:
+                for scale, correctA in ((True, True), (False, False)):
+                    w = rm.matrix_d(name, scale=scale, correctA=correctA)
+                    fast += int(w.built_fast())
+                    streamed += int(w.built_streamed())
+                    assert_same_weighted(w, rg.matrix_d(name, em, scale=scale, correctA=correctA), "%s seed=%d stream=%d" % (name, seed, stream))
+            assert fast >= 12, fast             # (EvA / AvE with negative areas, and little else, go to the general pipeline)
+            assert streamed == (16 if stream else 0), (stream, streamed)       # all but EvA / AvE
     finally:
-        for k in ("assemble_stream_count", "assemble_range_shape", "assemble_static_count"):
+        for k in ("assemble_stream_count", "assemble_range_shape", "assemble_static_count", "assemble_stream"):
             icebin_amd.set_tuning(k, -2 ** 31)
+
+
+@pytest.mark.parametrize("config,variant", [("g50", "sorted"), ("g50", "zero_area"), ("g50", "negative_area"), ("g50", "elev_class"),
+                                            ("g20", "sorted"), ("g20", "x_fastest"), ("g5", "sorted")])
+def test_streamed_build_is_the_oracle_bitwise(config, variant):
+    """The streamed build (streamasm.inl: what grids of 2^20 exchange cells and more take) forced on the oracle-sized grids:
+    the eight matrices it serves x the four (scale, correctA) branches, own dims; identity I / X sets where it serves them;
+    the coupler's shared dimE, also permuted and incomplete -- every bit of dims / CSR / wM / Mw against the oracle."""
+    kw = {}
+    if variant == "zero_area":
+        kw["zero_area_every"] = 7
+    if variant == "x_fastest":
+        kw["x_fastest"] = True
+    g = syn.make_grids(config, **kw)
+    if variant == "negative_area":
+        g["ex_area"] = g["ex_area"].copy()
+        g["ex_area"][::11] *= -1.0
+    if variant == "elev_class":
+        g["interp_style"] = 1
+    em = syn.dome_elevmask(g)
+    mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
+    nI, nX, nE = g["nI"], len(g["ex_area"]), g["nA"] * len(g["hcdefs"])
+    names = [n for n in ALL if n not in ("EvA", "AvE")]
+    try:
+        icebin_amd.set_tuning("assemble_stream", 1)
+        for scale, correctA in ((True, True), (False, False), (True, False), (False, True)):
+            rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
+            for name in names:
+                w = rm.matrix(name)
+                assert w.built_streamed(), name
+                assert_same_weighted(w, rg.matrix_d(name, em, scale=scale, correctA=correctA), "%s %s scale=%d correctA=%d" % (name, variant, scale, correctA))
+        rm = mm.regrid_matrices("greenland", em)
+        # the coupler's step (IceCoupler.cpp:361-468): EvI / AvI on an identity dimI, XvE on the dimE EvI numbered and an identity
+        # dimX (IvE on an identity dimI keeps the per-range kernels: its rows lie in ice-cell order)
+        dimI, dimX, dimE = icebin_amd.SparseSet.identity(nI), icebin_amd.SparseSet.identity(nX), icebin_amd.SparseSet(nE)
+        oI, oX, oE = orc.SparseSet(nI, init=np.arange(nI)), orc.SparseSet(nX, init=np.arange(nX)), orc.SparseSet(nE)
+        for name, dims, odims, sc, cA, streamed in (("EvI", (dimE, dimI), (oE, oI), False, False, True), ("AvI", (None, dimI), (None, oI), False, True, True),
+                                                    ("IvE", (dimI, dimE), (oI, oE), True, True, False), ("XvE", (dimX, dimE), (oX, oE), False, True, True),
+                                                    ("IvE", (None, dimE), (None, oE), True, True, True), ("AvX", (None, dimX), (None, oX), True, True, True)):
+            w = rm.matrix_d(name, dims, scale=sc, correctA=cA)
+            assert w.built_fast() and w.built_streamed() == streamed, name
+            assert_same_weighted(w, rg.matrix_d(name, em, dims=odims, scale=sc, correctA=cA), "coupler %s %s" % (name, variant))
+        E_keys = dimE.to_sparse()
+        extra = np.setdiff1d(np.arange(nE), E_keys)[:7]
+        perm = np.random.default_rng(5).permutation(np.concatenate([E_keys, extra]))
+        for name, rowset, orow in (("IvE", None, None), ("XvE", dimX, oX), ("XvE", None, None)):
+            dE2, oE2 = icebin_amd.SparseSet(nE, perm), orc.SparseSet(nE, init=perm)
+            w = rm.matrix_d(name, (rowset, dE2), scale=True, correctA=True)
+            assert w.built_streamed(), name
+            assert_same_weighted(w, rg.matrix_d(name, em, dims=(orow, oE2), scale=True, correctA=True), "permuted dimE %s %s" % (name, variant))
+        dE3, oE3 = icebin_amd.SparseSet(nE, E_keys[:-3]), orc.SparseSet(nE, init=E_keys[:-3])
+        w = rm.matrix_d("XvE", (dimX, dE3), scale=True, correctA=True)              # a key is missing: the general pipeline appends it
+        assert not w.built_fast() and dE3.dense_extent() == len(E_keys)
+        assert_same_weighted(w, rg.matrix_d("XvE", em, dims=(oX, oE3), scale=True, correctA=True), "incomplete dimE " + variant)
+    finally:
+        icebin_amd.set_tuning("assemble_stream", -2 ** 31)
 
 
 @pytest.mark.parametrize("nA_real,nX", [(12, 150000), (60, 200000)])
