@@ -25,7 +25,11 @@
 // elevation-class builds count by the sign of the area), EvA / AvE (fast_build_eva).
 
 constexpr int SA_T = 256, SA_CPT = 4, SA_TILE = SA_T * SA_CPT;
-enum { SA_P = 1, SA_ENT = 2, SA_OLD = 4, SA_UNM = 8 };
+// code byte: a P key is first seen here | this cell heads a group with entries | those entries straddle in from an earlier range |
+// unmasked | static plan bits the emit pass needs (so that it does not read the plan's byte again): the only exchange cell of its
+// ice cell, the first-seen cell of its ice cell, a duplicate follows, the first cell of its range
+enum { SA_P = 1, SA_ENT = 2, SA_OLD = 4, SA_UNM = 8, SA_ONE = 16, SA_FIRST = 32, SA_DUPNEXT = 64, SA_RHEAD = 128 };
+constexpr int SA_OLDSEG = 256;      // straddling entries of one (range, class) segment sorted in LDS by k_sa_rows
 
 struct SaBuf {
     uint8_t *code;          // [nW * 64]
@@ -135,7 +139,8 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
         else P = n > 0;
         const bool old = ent && !pkey_x && p_fresh && (fl[u] & 64);
         if (in) {
-            sb.code[x] = (uint8_t)((P ? SA_P : 0) | (ent ? SA_ENT : 0) | (old ? SA_OLD : 0) | (unm ? SA_UNM : 0));
+            sb.code[x] = (uint8_t)((P ? SA_P : 0) | (ent ? SA_ENT : 0) | (old ? SA_OLD : 0) | (unm ? SA_UNM : 0) | ((fl[u] & 2) ? SA_ONE : 0) |
+                                   ((fl[u] & 4) ? SA_FIRST : 0) | ((fl[u] & 128) ? SA_DUPNEXT : 0) | ((fl[u] & 32) ? SA_RHEAD : 0));
             if (WITH_EP) sb.cls[x] = (uint8_t)(c0 | (n << 6));
         }
         const unsigned long long bp = __ballot(P);
@@ -166,49 +171,66 @@ __global__ __launch_bounds__(256) void k_sa_ranges(RgView rg, PlanView pl, SaBuf
     REL *__restrict__ rel = static_cast<REL *>(sb.rel);
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     if (!WITH_EP) {
+        // (four chunks of 64 bytes in flight per step: the wave walks its range in a handful of round trips)
         uint32_t cn = 0, co = 0;
-        for (long cb = x0; cb < x1; cb += 64) {
-            const long x = cb + lane;
-            const unsigned cd = x < x1 ? sb.code[x] : 0u;
-            cn += (uint32_t)__popcll(__ballot((cd & SA_ENT) && !(cd & SA_OLD)));
-            co += (uint32_t)__popcll(__ballot((cd & SA_OLD) != 0));
+        for (long cb = x0; cb < x1; cb += 256) {
+            unsigned cd[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const long x = cb + 64 * q + lane; cd[q] = x < x1 ? sb.code[x] : 0u; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cn += (uint32_t)__popcll(__ballot((cd[q] & SA_ENT) && !(cd[q] & SA_OLD)));
+                co += (uint32_t)__popcll(__ballot((cd[q] & SA_OLD) != 0));
+            }
         }
         if (lane == 0) {
             const bool member = cn + co > 0;
             g.erank[r] = member ? 0 : -1;
             g.ecntn[r] = cn; g.ecnto[r] = co;
             g.r_ncls[r] = member ? 1u : 0u; g.r_nent[r] = cn + co;
-            if (co > (uint32_t)FA_OLDMAX) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
+            if (co > (uint32_t)SA_OLDSEG) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
         }
         uint32_t runn = 0, runo = 0;
-        for (long cb = x0; cb < x1; cb += 64) {
-            const long x = cb + lane;
-            const unsigned cd = x < x1 ? sb.code[x] : 0u;
-            const bool en = (cd & SA_ENT) && !(cd & SA_OLD), eo = (cd & SA_OLD) != 0;
-            const unsigned long long mn = __ballot(en), mo = __ballot(eo);
-            if (en) rel[x] = (REL)(co + runn + (uint32_t)__popcll(mn & lt));
-            if (eo) rel[x] = (REL)(runo + (uint32_t)__popcll(mo & lt));
-            runn += (uint32_t)__popcll(mn); runo += (uint32_t)__popcll(mo);
+        for (long cb = x0; cb < x1; cb += 256) {
+            unsigned cd[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const long x = cb + 64 * q + lane; cd[q] = x < x1 ? sb.code[x] : 0u; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long x = cb + 64 * q + lane;
+                const bool en = (cd[q] & SA_ENT) && !(cd[q] & SA_OLD), eo = (cd[q] & SA_OLD) != 0;
+                const unsigned long long mn = __ballot(en), mo = __ballot(eo);
+                if (en) rel[x] = (REL)(co + runn + (uint32_t)__popcll(mn & lt));
+                if (eo) rel[x] = (REL)(runo + (uint32_t)__popcll(mo & lt));
+                runn += (uint32_t)__popcll(mn); runo += (uint32_t)__popcll(mo);
+            }
         }
         return;
     }
     // elevation classes: lane c holds the table entry of class c
     uint32_t first = 0xffffffffu, cn = 0, co = 0;
-    for (long cb = x0; cb < x1; cb += 64) {
-        const long x = cb + lane;
-        const unsigned cd = x < x1 ? sb.code[x] : 0u, cb8 = x < x1 ? sb.cls[x] : 0u;
-        const int n = (int)(cb8 >> 6), c0 = (int)(cb8 & 63);
-        unsigned long long bits = sa_wave_or64(n > 0 ? ((1ull << c0) | (n == 2 ? (2ull << c0) : 0ull)) : 0ull);
-        const unsigned long long men = __ballot((cd & SA_ENT) && !(cd & SA_OLD)), meo = __ballot((cd & SA_OLD) != 0);
-        while (bits) {
-            const int c = __builtin_ctzll(bits);
-            bits &= bits - 1;
-            const unsigned long long m0 = __ballot(n > 0 && c0 == c), m1 = __ballot(n == 2 && c0 + 1 == c), mem = m0 | m1;
-            const int l = __builtin_ctzll(mem);
-            const uint32_t pos = 2u * (uint32_t)(cb + l) + (((m0 >> l) & 1) ? 0u : 1u);
-            if (lane == c) {
-                if (first == 0xffffffffu) first = pos;
-                cn += (uint32_t)__popcll(men & mem); co += (uint32_t)__popcll(meo & mem);
+    for (long cb4 = x0; cb4 < x1; cb4 += 256) {
+        unsigned cdv[4], clv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const long x = cb4 + 64 * q + lane; cdv[q] = x < x1 ? sb.code[x] : 0u; clv[q] = x < x1 ? sb.cls[x] : 0u; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long cb = cb4 + 64 * q;
+            if (cb >= x1) break;
+            const unsigned cd = cdv[q], cb8 = clv[q];
+            const int n = (int)(cb8 >> 6), c0 = (int)(cb8 & 63);
+            unsigned long long bits = sa_wave_or64(n > 0 ? ((1ull << c0) | (n == 2 ? (2ull << c0) : 0ull)) : 0ull);
+            const unsigned long long men = __ballot((cd & SA_ENT) && !(cd & SA_OLD)), meo = __ballot((cd & SA_OLD) != 0);
+            while (bits) {
+                const int c = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const unsigned long long m0 = __ballot(n > 0 && c0 == c), m1 = __ballot(n == 2 && c0 + 1 == c), mem = m0 | m1;
+                const int l = __builtin_ctzll(mem);
+                const uint32_t pos = 2u * (uint32_t)(cb + l) + (((m0 >> l) & 1) ? 0u : 1u);
+                if (lane == c) {
+                    if (first == 0xffffffffu) first = pos;
+                    cn += (uint32_t)__popcll(men & mem); co += (uint32_t)__popcll(meo & mem);
+                }
             }
         }
     }
@@ -221,13 +243,13 @@ __global__ __launch_bounds__(256) void k_sa_ranges(RgView rg, PlanView pl, SaBuf
         rank += fk < first ? 1 : 0;
     }
     const uint32_t seg = cn + co;
-    uint32_t start = 0, nent = 0, nold = 0;
+    uint32_t start = 0, nent = 0;
     for (unsigned long long m = present; m; m &= m - 1) {
         const int k = __builtin_ctzll(m);
         const int rk = __builtin_amdgcn_readlane(rank, k);
-        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)seg, k), ok = (uint32_t)__builtin_amdgcn_readlane((int)co, k);
+        const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)seg, k);
         start += rk < rank ? sk : 0u;
-        nent += sk; nold += ok;
+        nent += sk;
     }
     const bool mine = first != 0xffffffffu;
     if (lane < g.NC) {
@@ -239,30 +261,36 @@ __global__ __launch_bounds__(256) void k_sa_ranges(RgView rg, PlanView pl, SaBuf
             if (g.tab[key] < 0) atomicOr(flags, (uint32_t)FA_ERR_MISSING);
         }
         if (!mine && seg) atomicOr(flags, (uint32_t)FA_ERR_MISSING);           // entries of a class that was never listed: cannot happen
+        if (co > (uint32_t)SA_OLDSEG) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
     }
-    if (lane == 0) {
-        g.r_ncls[r] = (uint32_t)__popcll(present); g.r_nent[r] = nent;
-        if (nold > (uint32_t)FA_OLDMAX) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
-    }
+    if (lane == 0) { g.r_ncls[r] = (uint32_t)__popcll(present); g.r_nent[r] = nent; }
     uint32_t runn = 0, runo = 0;
-    for (long cb = x0; cb < x1; cb += 64) {
-        const long x = cb + lane;
-        const unsigned cd = x < x1 ? sb.code[x] : 0u, cb8 = x < x1 ? sb.cls[x] : 0u;
-        const int n = (int)(cb8 >> 6), c0 = (int)(cb8 & 63);
-        const bool en = (cd & SA_ENT) && !(cd & SA_OLD), eo = (cd & SA_OLD) != 0;
-        unsigned long long bits = sa_wave_or64((en || eo) ? ((1ull << c0) | (n == 2 ? (2ull << c0) : 0ull)) : 0ull);
-        while (bits) {
-            const int c = __builtin_ctzll(bits);
-            bits &= bits - 1;
-            const bool s0 = (en || eo) && c0 == c, s1 = (en || eo) && n == 2 && c0 + 1 == c;
-            const unsigned long long mn = __ballot((s0 || s1) && en), mo = __ballot((s0 || s1) && eo);
-            const uint32_t st_c = (uint32_t)__builtin_amdgcn_readlane((int)start, c), co_c = (uint32_t)__builtin_amdgcn_readlane((int)co, c);
-            const uint32_t rn = (uint32_t)__builtin_amdgcn_readlane((int)runn, c), ro = (uint32_t)__builtin_amdgcn_readlane((int)runo, c);
-            if (s0 || s1) {
-                const uint32_t v = en ? st_c + co_c + rn + (uint32_t)__popcll(mn & lt) : st_c + ro + (uint32_t)__popcll(mo & lt);
-                rel[2 * x + (s1 ? 1 : 0)] = (REL)v;
+    for (long cb4 = x0; cb4 < x1; cb4 += 256) {
+        unsigned cdv[4], clv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const long x = cb4 + 64 * q + lane; cdv[q] = x < x1 ? sb.code[x] : 0u; clv[q] = x < x1 ? sb.cls[x] : 0u; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long cb = cb4 + 64 * q;
+            if (cb >= x1) break;
+            const long x = cb + lane;
+            const unsigned cd = cdv[q], cb8 = clv[q];
+            const int n = (int)(cb8 >> 6), c0 = (int)(cb8 & 63);
+            const bool en = (cd & SA_ENT) && !(cd & SA_OLD), eo = (cd & SA_OLD) != 0;
+            unsigned long long bits = sa_wave_or64((en || eo) ? ((1ull << c0) | (n == 2 ? (2ull << c0) : 0ull)) : 0ull);
+            while (bits) {
+                const int c = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const bool s0 = (en || eo) && c0 == c, s1 = (en || eo) && n == 2 && c0 + 1 == c;
+                const unsigned long long mn = __ballot((s0 || s1) && en), mo = __ballot((s0 || s1) && eo);
+                const uint32_t st_c = (uint32_t)__builtin_amdgcn_readlane((int)start, c), co_c = (uint32_t)__builtin_amdgcn_readlane((int)co, c);
+                const uint32_t rn = (uint32_t)__builtin_amdgcn_readlane((int)runn, c), ro = (uint32_t)__builtin_amdgcn_readlane((int)runo, c);
+                if (s0 || s1) {
+                    const uint32_t v = en ? st_c + co_c + rn + (uint32_t)__popcll(mn & lt) : st_c + ro + (uint32_t)__popcll(mo & lt);
+                    rel[2 * x + (s1 ? 1 : 0)] = (REL)v;
+                }
+                if (lane == c) { runn += (uint32_t)__popcll(mn); runo += (uint32_t)__popcll(mo); }
             }
-            if (lane == c) { runn += (uint32_t)__popcll(mn); runo += (uint32_t)__popcll(mo); }
         }
     }
 }
@@ -281,24 +309,38 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
     const REL *__restrict__ rel = static_cast<const REL *>(sb.rel);
     constexpr int S = WITH_EP ? 2 : 1;
     const bool pkey_x = p.key == KEY_X;
-    unsigned fl[SA_CPT], cd[SA_CPT];
+    // round 1: the code bytes and (one address per wave) the range of each wave's first cell; round 2: everything the cells with
+    // entries / with a new P key need -- the range of a cell is its wave's first range + the range heads up to its lane (code bit
+    // 7), so the per-range values are fetched in the same round as the cell itself; round 3: the mask value (elevation classes)
+    unsigned cd[SA_CPT];
+    int rb[SA_CPT];
 #pragma unroll
     for (int u = 0; u < SA_CPT; ++u) {
         const long x = cb + (long)u * SA_T + tid;
-        const bool in = x < rg.nX;
-        fl[u] = in ? pl.isdup[x] : 0u; cd[u] = in ? sb.code[x] : 0u;
+        const long xw = cb + (long)u * SA_T + (tid & ~63);
+        cd[u] = x < rg.nX ? sb.code[x] : 0u;
+        rb[u] = pl.aidx[xw < rg.nX ? xw : rg.nX - 1];
     }
-    int iIv[SA_CPT], rv[SA_CPT];
+    const unsigned long long le = lt | (1ull << lane);
+    int iIv[SA_CPT], rv[SA_CPT], iAv[SA_CPT];
     double av[SA_CPT];
-    uint32_t lenv[SA_CPT];
+    uint32_t lenv[SA_CPT], ebv[SA_CPT], relv[SA_CPT][S], pwv[SA_CPT], lwv[SA_CPT];
 #pragma unroll
     for (int u = 0; u < SA_CPT; ++u) {
         const long x = cb + (long)u * SA_T + tid;
-        const bool want = (cd[u] & (SA_ENT | SA_P)) != 0;
+        const long xw = cb + (long)u * SA_T + (tid & ~63);
+        const bool want = (cd[u] & (SA_ENT | SA_P)) != 0, ent = (cd[u] & SA_ENT) != 0;
+        const unsigned long long heads = __ballot((cd[u] & SA_RHEAD) != 0);
+        rv[u] = rb[u] + (int)__popcll(heads & le & ~1ull);
         iIv[u] = want ? pl.exI[x] : 0;
-        rv[u] = want ? pl.aidx[x] : 0;
-        av[u] = (cd[u] & SA_ENT) ? rg.area[x] : 0.0;
+        av[u] = ent ? rg.area[x] : 0.0;
+        ebv[u] = ent ? g.ebase[rv[u]] : 0u;
+        iAv[u] = (ent && (WITH_EP || !G_ROWS)) ? pl.riA[rv[u]] : 0;      // (an A-row matrix without classes never looks at the atmosphere index here)
+#pragma unroll
+        for (int j = 0; j < S; ++j) relv[u][j] = ent ? (uint32_t)rel[(size_t)S * x + j] : 0u;
         lenv[u] = (!G_ROWS && x < rg.nX) ? sb.rl[x] : 0u;
+        pwv[u] = (p.fresh && xw < rg.nX) ? sb.Pw[xw >> 6] : 0u;
+        lwv[u] = (!G_ROWS && xw < rg.nX) ? sb.Lw[xw >> 6] : 0u;
     }
     double ev[SA_CPT];
 #pragma unroll
@@ -307,33 +349,30 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
     for (int u = 0; u < SA_CPT; ++u) {
         const long x = cb + (long)u * SA_T + tid;
         const bool in = x < rg.nX;
-        const long xw = cb + (long)u * SA_T + (tid & ~63);
         const bool P = (cd[u] & SA_P) != 0, ent = (cd[u] & SA_ENT) != 0, old = (cd[u] & SA_OLD) != 0;
         const unsigned long long bp = __ballot(P);
         const int iI = iIv[u], r = rv[u];
         // dense id of the P key first seen at this cell
         int pown;
-        if (p.fresh) pown = (xw < rg.nX ? (int)sb.Pw[xw >> 6] : 0) + (int)__popcll(bp & lt);
+        if (p.fresh) pown = (int)pwv[u] + (int)__popcll(bp & lt);
         else pown = pkey_x ? (int)x : iI;
         GEnt ge;
         ge.n = 0; ge.cls0 = ge.cls1 = 0; ge.t0 = ge.t1 = 0.0; ge.gkey0 = ge.gkey1 = 0;
-        long iA = 0;
+        const long iA = iAv[u];
         if (ent) {
-            iA = pl.riA[r];
             const XCell c = make_cell<WITH_EP>(rg, iA, iI, av[u], ev[u]);
-            if (!(WITH_EP && c.range_error)) fa_group<WITH_EP>(rg, pl, s, G_ROWS, merge != 0 && (fl[u] & 128), c, x, ge);
+            if (!(WITH_EP && c.range_error)) fa_group<WITH_EP>(rg, pl, s, G_ROWS, merge != 0 && (cd[u] & SA_DUPNEXT), c, x, ge);
         }
         if (ge.n > 0) {
             // the entries of this group go to their slots of the range's block
             int did;
             if (!p.fresh) did = pkey_x ? (int)x : iI;
-            else if (pkey_x || (fl[u] & 4)) did = pown;
+            else if (pkey_x || (cd[u] & SA_FIRST)) did = pown;
             else did = (int)sa_prank_at(sb.Pw, sb.code, pl.ifirst[iI]);
-            const uint32_t eb = g.ebase[r];
 #pragma unroll
             for (int j = 0; j < S; ++j) {
                 if (j >= ge.n) break;
-                const uint32_t pos = eb + (uint32_t)rel[(size_t)S * x + j];
+                const uint32_t pos = ebv[u] + relv[u][j];
                 if (G_ROWS) { o.colind[pos] = did; o.val[pos] = ge.t(j); }
                 else { sval[pos] = ge.t(j); if (old) sdid[pos] = did; }
             }
@@ -354,7 +393,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
                 if (p.fresh) p.to_sparse[pown] = pkey_x ? x : (long)iI;
                 // Mw of an exchange cell / of an ice cell with this one exchange cell: its <= 2 entries in ascending row order,
                 // from zero (spsparse sum()); a member without entries gets 0.  Ice cells with several cells: k_fa_pelem<SUMS>.
-                if (pkey_x || (fl[u] & 2)) {
+                if (pkey_x || (cd[u] & SA_ONE)) {
                     double sum = 0.0;
                     if (ge.n == 1) sum = sum + ge.t0;
                     else if (ge.n == 2) { sum = sum + (swap01 ? ge.t1 : ge.t0); sum = sum + (swap01 ? ge.t0 : ge.t1); }
@@ -364,12 +403,12 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
         } else {
             // rows come out in x order of the cells that own them: offset = row entries before this wave + before this lane
             const uint32_t before = sa_wave_excl_u32(lenv[u], lane);
-            const uint32_t b0 = (xw < rg.nX ? sb.Lw[xw >> 6] : 0u) + before;
+            const uint32_t b0 = lwv[u] + before;
             if (in && (P || !p.fresh)) o.rowptr[pown] = (int32_t)b0;
             if (in && !P && !p.fresh) o.wM[pown] = 0.0;                  // identity set: a cell that is no member has an empty row
             if (P) {
                 if (p.fresh) p.to_sparse[pown] = pkey_x ? x : (long)iI;
-                if (pkey_x || (fl[u] & 2)) {
+                if (pkey_x || (cd[u] & SA_ONE)) {
                     // FAM_IVAE rows (RegridMatrices_Dynamic.cpp:201-233): wM = rowsum by ascending column, M = [1/wM] * T [* sApvA]
                     double sum = 0.0;
                     const double ta = swap01 ? ge.t1 : ge.t0, tb = swap01 ? ge.t0 : ge.t1;
@@ -395,8 +434,9 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
 // scratch copy of the terms (o.val = scratch, sdid = the row ids of the straddling terms).
 template <bool EMIT>
 __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, FaOut o, int32_t *__restrict__ sdid, uint32_t *__restrict__ flags) {
-    __shared__ int s_did[4][FA_OLDMAX], s_did2[4][FA_OLDMAX];
-    __shared__ double s_t[4][FA_OLDMAX], s_t2[4][FA_OLDMAX];
+    __shared__ int s_did[4][SA_OLDSEG], s_did2[4][SA_OLDSEG];
+    __shared__ double s_t[4][SA_OLDSEG], s_t2[4][SA_OLDSEG];
+    constexpr int NV = 8;                                        // chunks of 64 values of a segment kept in registers
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wv;
     if (r >= pl.nAr) return;
@@ -412,6 +452,7 @@ __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, 
         seg = g.ecntn[(size_t)r * g.NC + lane] + nold_c;
     }
     int32_t *__restrict__ ids = EMIT ? o.colind : sdid;
+    const long iA = pl.riA[r];
     uint32_t start = 0;
     for (int q = 0; q < ncls; ++q) {
         const unsigned long long mq = __ballot(rank == q);
@@ -419,14 +460,21 @@ __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, 
         const int cls = __builtin_ctzll(mq);
         const uint32_t sg = (uint32_t)__builtin_amdgcn_readlane((int)seg, cls);
         uint32_t no = (uint32_t)__builtin_amdgcn_readlane((int)nold_c, cls);
-        if (no > (uint32_t)FA_OLDMAX) no = FA_OLDMAX;            // (the build is being discarded: FA_ERR_OLDOVER; stay inside the tables)
-        const uint32_t b = eb + start, e = b + sg;
+        if (no > (uint32_t)SA_OLDSEG) no = SA_OLDSEG;            // (the build is being discarded: FA_ERR_OLDOVER; stay inside the tables)
+        const uint32_t b = eb + start, e = b + sg, bn = b + no;
         start += sg;
-        // the straddling entries (ice cells first seen in an earlier range: smaller ids) lie at the segment's start in x order:
-        // into ascending id order -- inside a class the ids are distinct: rank by counting
+        // every load of the segment is issued up front: the straddling entries (ice cells first seen in an earlier range: smaller
+        // ids; they lie at the segment's start in x order) and the first NV x 64 of the entries first seen in this range
         for (uint32_t k = lane; k < no; k += 64) { s_did[wv][k] = ids[b + k]; s_t[wv][k] = o.val[b + k]; }
+        double v[NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const uint32_t k = bn + 64u * c + lane;
+            v[c] = k < e ? o.val[k] : 0.0;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // the straddlers into ascending id order -- inside a class the ids are distinct: rank by counting
         for (uint32_t k = lane; k < no; k += 64) {
             const int did = s_did[wv][k];
             uint32_t cnt = 0;
@@ -435,14 +483,13 @@ __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // the sequential sum (spsparse sum(): ascending column / row): the straddlers, then the chain over the new entries
+        // replayed from registers with v_readlane (every lane computes the identical sum)
         double sum = 0.0;
         for (uint32_t k = 0; k < no; ++k) sum = sum + s_t2[wv][k];
-        // the entries first seen in this range follow in x order: 64 values loaded coalesced, the chain replayed from registers
-        for (uint32_t base = b + no; base < e; base += 64) {
-            const uint32_t k = base + lane;
-            const double v = k < e ? o.val[k] : 0.0;
-            const int cnt = (int)min(64u, e - base);
-            const int lo = __double2loint(v), hi = __double2hiint(v);
+        auto chain = [&](double val, uint32_t cb) {
+            const int cnt = (int)min(64u, e - cb);
+            const int lo = __double2loint(val), hi = __double2hiint(val);
             if (cnt == 64) {
 #pragma unroll
                 for (int j = 0; j < 64; ++j)
@@ -451,14 +498,32 @@ __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, 
                 for (int j = 0; j < cnt; ++j)
                     sum = sum + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
             }
+        };
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const uint32_t cb = bn + 64u * c;
+            if (cb >= e) break;
+            chain(v[c], cb);
         }
-        const long iA = pl.riA[r];
+        for (uint32_t base = bn + 64u * NV; base < e; base += 256) {          // longer segments: four chunks in flight per step
+            double u4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t k = base + 64u * c + lane;
+                u4[c] = k < e ? o.val[k] : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t cb = base + 64u * c;
+                if (cb >= e) break;
+                chain(u4[c], cb);
+            }
+        }
         const long gkey = g.key == KEY_E ? iA * rg.sA + (long)cls * rg.sHC : iA;
         const int gd = fa_gdense(g, r, cls, gkey);
         if (gd < 0) continue;                                   // a key the pre-populated set lacks: the build is discarded (FA_ERR_MISSING)
-        double mul = 1.0;
         if (EMIT) {                                            // FAM_AEVI rows (RegridMatrices_Dynamic.cpp:100-146)
-            double wM;
+            double wM, mul = 1.0;
             if (o.correctA) {
                 const double rr = ratio_of(rg, g.key, gkey);
                 wM = rr * sum;
@@ -476,8 +541,14 @@ __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, 
                 o.colind[b + k] = s_did2[wv][k];
                 o.val[b + k] = o.scale ? mul * s_t2[wv][k] : s_t2[wv][k];
             }
-            if (o.scale)
-                for (uint32_t k = b + no + lane; k < e; k += 64) o.val[k] = mul * o.val[k];
+            if (o.scale) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    const uint32_t k = bn + 64u * c + lane;
+                    if (k < e) o.val[k] = mul * v[c];
+                }
+                for (uint32_t k = bn + 64u * NV + lane; k < e; k += 64) o.val[k] = mul * o.val[k];
+            }
         } else if (lane == 0) {                                // FAM_IVAE columns (:201-233)
             if (g.to_sparse) g.to_sparse[gd] = gkey;
             o.Mw[gd] = o.correctA ? ratio_of(rg, g.key, gkey) * sum : sum;

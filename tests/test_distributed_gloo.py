@@ -253,7 +253,9 @@ def _worker_sharded(rank, world, port, q):
             # that produces the block (ready event), the block read here would still hold the -9 the test filled it with
             flat = state["out"]
             off = (d_base - flat.data_ptr()) // 8
-            xs = torch.cuda.ExternalStream(stream)
+            xs = state.get("xs")
+            if xs is None or xs.cuda_stream != stream:
+                xs = state["xs"] = torch.cuda.ExternalStream(stream)
             with torch.cuda.stream(xs):
                 def carve():          # from ONE pinned buffer allocated up front (a pinned allocation may synchronise the device)
                     a = state["pin"][state["pin_off"]: state["pin_off"] + count]
@@ -330,6 +332,15 @@ def _worker_sharded(rank, world, port, q):
                 ref = w.apply_device(xp, fill=-2.0, force_conservation=False).cpu().numpy()
                 ok = ok and bool(np.array_equal(outs[k][p * nl:(p + 1) * nl].cpu().numpy().view(np.uint64), ref.view(np.uint64)))
         q.put((rank, ok, ncalls))
+        # tear down in dependency order: the pinned staging buffer was used on the communicator's exchange stream (torch's host
+        # allocator remembers that stream) -- it goes first, while the stream still exists; the communicator last
+        torch.cuda.synchronize()
+        state.clear()
+        import gc
+        gc.collect()
+        torch._C._host_emptyCache() if hasattr(torch._C, "_host_emptyCache") else None
+        del comm
+        gc.collect()
     finally:
         dist.destroy_process_group()
 
