@@ -180,6 +180,11 @@ struct ibh_plan {
     ibh::DevBuf<int32_t> riA;
     int32_t maxrange = 0;
     bool tiny = false;
+    // the ice cells with several exchange cells, split for the streamed build: PAIRS -- exactly two exchange cells, in two ranges,
+    // the first one the first-seen cell (an ice cell across one GCM-cell edge: nearly all of them) -- as three parallel arrays
+    // (first cell, second cell, ice cell), served by a lean kernel without list walks; the rest (corners, duplicates) in mlist3
+    ibh::DevBuf<int32_t> px1, px2, piI, mlist3;
+    int32_t npair = 0, nmulti3 = 0;
 };
 
 struct ibh_regridder {

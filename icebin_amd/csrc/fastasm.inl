@@ -127,6 +127,22 @@ __global__ void k_plan_bits2(const int32_t *__restrict__ exi, const int32_t *__r
     if (x + 1 < nX && (isdup[x + 1] & 1)) b |= 128;              // (bit 0 of the neighbour is final since k_plan_flags)
     isdup[x] = b;
 }
+// ice cells with several exchange cells: a clean pair (two cells, two ranges, the first one first-seen) or not
+__global__ void k_plan_pairflags(const int32_t *__restrict__ ilptr, const int32_t *__restrict__ ilist, const int32_t *__restrict__ aidx,
+                                 const int32_t *__restrict__ ifirst, long nI, uint32_t *__restrict__ pair, uint32_t *__restrict__ m3) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nI) return;
+    const int b = ilptr[i], e = ilptr[i + 1];
+    bool pr = false;
+    if (e - b == 2) { const int x1 = ilist[b], x2 = ilist[b + 1]; pr = aidx[x1] != aidx[x2] && ifirst[i] == x1; }
+    pair[i] = pr ? 1u : 0u;
+    m3[i] = (e - b > 1 && !pr) ? 1u : 0u;
+}
+__global__ void k_plan_pairs(const uint32_t *__restrict__ pair, const uint32_t *__restrict__ ppos, const int32_t *__restrict__ ilptr,
+                             const int32_t *__restrict__ ilist, long nI, int32_t *__restrict__ px1, int32_t *__restrict__ px2, int32_t *__restrict__ piI) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nI && pair[i]) { const uint32_t k = ppos[i]; const int b = ilptr[i]; px1[k] = ilist[b]; px2[k] = ilist[b + 1]; piI[k] = (int32_t)i; }
+}
 __global__ void k_plan_mlist(const uint32_t *__restrict__ multi, const uint32_t *__restrict__ mpos, long nI, int32_t *__restrict__ mlist) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nI && multi[i]) mlist[mpos[i]] = (int32_t)i;
@@ -197,6 +213,17 @@ static bool ensure_plan(const ibh_regridder *g, hipStream_t st) {
     }
     P.mlist.alloc((size_t)P.nmulti);
     if (P.nmulti) hipLaunchKernelGGL(k_plan_mlist, dim3(ceil_div(nI, T)), dim3(T), 0, st, multi, mpos, nI, P.mlist.p);
+    {   // the same cells split into clean pairs and the rest (streamasm.inl)
+        uint32_t *pairf = A.get<uint32_t>((size_t)nI), *ppos = A.get<uint32_t>((size_t)nI), *m3 = A.get<uint32_t>((size_t)nI), *m3pos = A.get<uint32_t>((size_t)nI);
+        hipLaunchKernelGGL(k_plan_pairflags, dim3(ceil_div(nI, T)), dim3(T), 0, st, P.ilptr.p, P.ilist.p, P.aidx.p, P.ifirst.p, nI, pairf, m3);
+        exclusive_scan_u32(pairf, ppos, (size_t)nI, d_cnt, st);
+        exclusive_scan_u32(m3, m3pos, (size_t)nI, d_cnt + 1, st);
+        readback_sync(h, d_cnt, sizeof(h), st);
+        P.npair = (int32_t)h[0]; P.nmulti3 = (int32_t)h[1];
+        P.px1.alloc((size_t)P.npair); P.px2.alloc((size_t)P.npair); P.piI.alloc((size_t)P.npair); P.mlist3.alloc((size_t)P.nmulti3);
+        if (P.npair) hipLaunchKernelGGL(k_plan_pairs, dim3(ceil_div(nI, T)), dim3(T), 0, st, pairf, ppos, P.ilptr.p, P.ilist.p, nI, P.px1.p, P.px2.p, P.piI.p);
+        if (P.nmulti3) hipLaunchKernelGGL(k_plan_mlist, dim3(ceil_div(nI, T)), dim3(T), 0, st, m3, m3pos, nI, P.mlist3.p);
+    }
     IBH_HIP(hipGetLastError());
     IBH_HIP(hipStreamSynchronize(st));
     P.ok = true;

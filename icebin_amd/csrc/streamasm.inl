@@ -17,9 +17,10 @@
 //   S3  k_sa_emit    stream: the cells with entries are evaluated ONCE (area, mask value) and every entry goes straight to
 //                    ebase[range] + position; the dims table, Mw of the one-cell ice cells (A/E-row matrices) or the whole
 //                    row with its weight and scaling (I/X-row matrices: rows come out in x order) from the same pass
-//   S4  k_fa_pelem   the ice cells with several exchange cells (a few %): their Mw / their rows, from the static lists
-//   S5  k_sa_rows    one wave per range: straddlers sorted into place, the sequential sums (spsparse sum() order), weights,
-//                    scaling
+//   S4  k_sa_pairs   the ice cells across one GCM-cell edge (two exchange cells: a few %): their Mw / their rows, one thread each
+//       k_fa_pelem   the rest of the ice cells with several exchange cells (corners, duplicates), from the static lists
+//   S5  k_sa_rows    one wave per (range, class): straddlers sorted into place, the sequential sum (spsparse sum() order)
+//                    through scalar loads, weights, scaling
 // Same sums in the same order as fastasm.inl, the general pipeline and the oracle: bit-identical (tests force either path).
 // Not served here (fastasm.inl's kernels take them): I-row matrices on an identity I set, plans with underflowing areas (the
 // elevation-class builds count by the sign of the area), EvA / AvE (fast_build_eva).
@@ -29,7 +30,9 @@ constexpr int SA_T = 256, SA_CPT = 4, SA_TILE = SA_T * SA_CPT;
 // unmasked | static plan bits the emit pass needs (so that it does not read the plan's byte again): the only exchange cell of its
 // ice cell, the first-seen cell of its ice cell, a duplicate follows, the first cell of its range
 enum { SA_P = 1, SA_ENT = 2, SA_OLD = 4, SA_UNM = 8, SA_ONE = 16, SA_FIRST = 32, SA_DUPNEXT = 64, SA_RHEAD = 128 };
-constexpr int SA_OLDSEG = 256;      // straddling entries of one (range, class) segment sorted in LDS by k_sa_rows
+// straddling entries of one (range, class) segment sorted in LDS by k_sa_rows: tables of 128 (many short ranges: four waves of a
+// workgroup hold 12 KB, the CU stays full) or 512 (long ranges: few segments, occupancy does not matter); more -> fastasm.inl
+constexpr int SA_OLDSEG_S = 128, SA_OLDSEG_L = 512;
 
 struct SaBuf {
     uint8_t *code;          // [nW * 64]
@@ -55,11 +58,19 @@ __device__ __forceinline__ uint32_t sa_wave_excl_u32(uint32_t v, int lane) {
     }
     return inc - v;
 }
+// OR over the wave with DPP (VALU speed; lanes a step does not write contribute 0, the identity): quad swaps, half-row and row
+// mirrors, then the row broadcasts -- lane 63 ends up with the whole wave's value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned sa_dpp_or(unsigned v) {
+    return v | (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned sa_wave_or32(unsigned v) {
+    v = sa_dpp_or<0xB1, 0xf>(v); v = sa_dpp_or<0x4E, 0xf>(v); v = sa_dpp_or<0x141, 0xf>(v); v = sa_dpp_or<0x140, 0xf>(v);
+    v = sa_dpp_or<0x142, 0xa>(v); v = sa_dpp_or<0x143, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned long long sa_wave_or64(unsigned long long v) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { lo |= __shfl_xor(lo, off, 64); hi |= __shfl_xor(hi, off, 64); }
-    lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+    const unsigned lo = sa_wave_or32((unsigned)v), hi = sa_wave_or32((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
 
@@ -161,66 +172,45 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
     }
 }
 
-// ---- S2: one wave per range, over the bytes ------------------------------------------------------------------------------------
-template <bool WITH_EP, typename REL>
-__global__ __launch_bounds__(256) void k_sa_ranges(RgView rg, PlanView pl, SaBuf sb, FaG g, uint32_t *__restrict__ flags) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= pl.nAr) return;
-    const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
+// ---- S2: over the bytes only; WPR waves per range (1: four ranges per workgroup; 4 / 16: one range per workgroup, every wave
+// takes a slice of it in x order, the per-class tables are combined through LDS) -------------------------------------------------
+template <bool WITH_EP, typename REL, int WPR>
+__global__ __launch_bounds__(WPR == 16 ? 1024 : 256) void k_sa_ranges(RgView rg, PlanView pl, SaBuf sb, FaG g, uint32_t *__restrict__ flags, int oldseg) {
+    __shared__ uint32_t s_first[WPR > 1 ? WPR : 1][64], s_cn[WPR > 1 ? WPR : 1][64], s_co[WPR > 1 ? WPR : 1][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = WPR == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
+    const int ws = WPR == 1 ? 0 : wv;                              // this wave's slice of the range
+    if (r >= pl.nAr) return;                                     // (WPR > 1: the whole workgroup)
+    const long r0 = pl.arng[r], r1 = pl.arng[r + 1];
+    const long slice = WPR == 1 ? (r1 - r0) : ((((r1 - r0) + WPR - 1) / WPR + 63) & ~63l);
+    const long x0 = r0 + ws * slice, x1 = (x0 + slice < r1) ? x0 + slice : r1;
     REL *__restrict__ rel = static_cast<REL *>(sb.rel);
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    if (!WITH_EP) {
-        // (four chunks of 64 bytes in flight per step: the wave walks its range in a handful of round trips)
-        uint32_t cn = 0, co = 0;
-        for (long cb = x0; cb < x1; cb += 256) {
-            unsigned cd[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const long x = cb + 64 * q + lane; cd[q] = x < x1 ? sb.code[x] : 0u; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                cn += (uint32_t)__popcll(__ballot((cd[q] & SA_ENT) && !(cd[q] & SA_OLD)));
-                co += (uint32_t)__popcll(__ballot((cd[q] & SA_OLD) != 0));
-            }
-        }
-        if (lane == 0) {
-            const bool member = cn + co > 0;
-            g.erank[r] = member ? 0 : -1;
-            g.ecntn[r] = cn; g.ecnto[r] = co;
-            g.r_ncls[r] = member ? 1u : 0u; g.r_nent[r] = cn + co;
-            if (co > (uint32_t)SA_OLDSEG) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
-        }
-        uint32_t runn = 0, runo = 0;
-        for (long cb = x0; cb < x1; cb += 256) {
-            unsigned cd[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const long x = cb + 64 * q + lane; cd[q] = x < x1 ? sb.code[x] : 0u; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long x = cb + 64 * q + lane;
-                const bool en = (cd[q] & SA_ENT) && !(cd[q] & SA_OLD), eo = (cd[q] & SA_OLD) != 0;
-                const unsigned long long mn = __ballot(en), mo = __ballot(eo);
-                if (en) rel[x] = (REL)(co + runn + (uint32_t)__popcll(mn & lt));
-                if (eo) rel[x] = (REL)(runo + (uint32_t)__popcll(mo & lt));
-                runn += (uint32_t)__popcll(mn); runo += (uint32_t)__popcll(mo);
-            }
-        }
-        return;
-    }
-    // elevation classes: lane c holds the table entry of class c
+    // pass 1 -- lane c holds the table entry of class c (one class: lane 0): first-seen position, new / straddling entries
     uint32_t first = 0xffffffffu, cn = 0, co = 0;
-    for (long cb4 = x0; cb4 < x1; cb4 += 256) {
+    for (long cb4 = x0; cb4 < x1; cb4 += 256) {                   // (four chunks of 64 bytes in flight per step)
         unsigned cdv[4], clv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const long x = cb4 + 64 * q + lane; cdv[q] = x < x1 ? sb.code[x] : 0u; clv[q] = x < x1 ? sb.cls[x] : 0u; }
+        for (int q = 0; q < 4; ++q) {
+            const long x = cb4 + 64 * q + lane;
+            cdv[q] = x < x1 ? sb.code[x] : 0u;
+            clv[q] = (WITH_EP && x < x1) ? sb.cls[x] : 0u;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long cb = cb4 + 64 * q;
             if (cb >= x1) break;
             const unsigned cd = cdv[q], cb8 = clv[q];
+            const unsigned long long men = __ballot((cd & SA_ENT) && !(cd & SA_OLD)), meo = __ballot((cd & SA_OLD) != 0);
+            if (!WITH_EP) {
+                if (lane == 0) {
+                    if (first == 0xffffffffu && (men | meo)) first = 0;
+                    cn += (uint32_t)__popcll(men); co += (uint32_t)__popcll(meo);
+                }
+                continue;
+            }
             const int n = (int)(cb8 >> 6), c0 = (int)(cb8 & 63);
             unsigned long long bits = sa_wave_or64(n > 0 ? ((1ull << c0) | (n == 2 ? (2ull << c0) : 0ull)) : 0ull);
-            const unsigned long long men = __ballot((cd & SA_ENT) && !(cd & SA_OLD)), meo = __ballot((cd & SA_OLD) != 0);
             while (bits) {
                 const int c = __builtin_ctzll(bits);
                 bits &= bits - 1;
@@ -232,6 +222,19 @@ __global__ __launch_bounds__(256) void k_sa_ranges(RgView rg, PlanView pl, SaBuf
                     cn += (uint32_t)__popcll(men & mem); co += (uint32_t)__popcll(meo & mem);
                 }
             }
+        }
+    }
+    uint32_t runn = 0, runo = 0;                                   // entries of this lane's class in the slices before this wave's
+    if (WPR > 1) {
+        s_first[ws][lane] = first; s_cn[ws][lane] = cn; s_co[ws][lane] = co;
+        __syncthreads();
+        first = 0xffffffffu; cn = 0; co = 0;
+#pragma unroll
+        for (int w = 0; w < WPR; ++w) {
+            const uint32_t fw = s_first[w][lane], nw = s_cn[w][lane], ow = s_co[w][lane];
+            if (first == 0xffffffffu) first = fw;                 // (slices lie in x order: the first slice that lists the class)
+            if (w < ws) { runn += nw; runo += ow; }
+            cn += nw; co += ow;
         }
     }
     // first-seen rank of every class of the range, start of its segment inside the range's block of entries
@@ -252,31 +255,47 @@ __global__ __launch_bounds__(256) void k_sa_ranges(RgView rg, PlanView pl, SaBuf
         nent += sk;
     }
     const bool mine = first != 0xffffffffu;
-    if (lane < g.NC) {
-        g.erank[(size_t)r * g.NC + lane] = (int8_t)(mine ? rank : -1);
-        g.ecntn[(size_t)r * g.NC + lane] = cn;
-        g.ecnto[(size_t)r * g.NC + lane] = co;
-        if (mine && g.tab) {                                       // pre-populated set: every key must already be there
-            const long key = (long)pl.riA[r] * rg.sA + (long)lane * rg.sHC;
-            if (g.tab[key] < 0) atomicOr(flags, (uint32_t)FA_ERR_MISSING);
+    if (ws == 0) {
+        if (lane < g.NC) {
+            g.erank[(size_t)r * g.NC + lane] = (int8_t)(mine ? rank : -1);
+            g.ecntn[(size_t)r * g.NC + lane] = cn;
+            g.ecnto[(size_t)r * g.NC + lane] = co;
+            if (mine && g.tab) {                                   // pre-populated set: every key must already be there
+                const long key = (long)pl.riA[r] * rg.sA + (long)lane * rg.sHC;
+                if (g.tab[key] < 0) atomicOr(flags, (uint32_t)FA_ERR_MISSING);
+            }
+            if (!mine && seg) atomicOr(flags, (uint32_t)FA_ERR_MISSING);       // entries of a class that was never listed: cannot happen
+            if (co > (uint32_t)oldseg) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
         }
-        if (!mine && seg) atomicOr(flags, (uint32_t)FA_ERR_MISSING);           // entries of a class that was never listed: cannot happen
-        if (co > (uint32_t)SA_OLDSEG) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
+        if (lane == 0) { g.r_ncls[r] = (uint32_t)__popcll(present); g.r_nent[r] = nent; }
     }
-    if (lane == 0) { g.r_ncls[r] = (uint32_t)__popcll(present); g.r_nent[r] = nent; }
-    uint32_t runn = 0, runo = 0;
+    // pass 2 -- the position of every entry inside the range's block: segment of its class, straddlers first (in x order here;
+    // k_sa_rows sorts them by id), then the entries first seen in this range in x order
     for (long cb4 = x0; cb4 < x1; cb4 += 256) {
         unsigned cdv[4], clv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const long x = cb4 + 64 * q + lane; cdv[q] = x < x1 ? sb.code[x] : 0u; clv[q] = x < x1 ? sb.cls[x] : 0u; }
+        for (int q = 0; q < 4; ++q) {
+            const long x = cb4 + 64 * q + lane;
+            cdv[q] = x < x1 ? sb.code[x] : 0u;
+            clv[q] = (WITH_EP && x < x1) ? sb.cls[x] : 0u;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long cb = cb4 + 64 * q;
             if (cb >= x1) break;
             const long x = cb + lane;
             const unsigned cd = cdv[q], cb8 = clv[q];
-            const int n = (int)(cb8 >> 6), c0 = (int)(cb8 & 63);
             const bool en = (cd & SA_ENT) && !(cd & SA_OLD), eo = (cd & SA_OLD) != 0;
+            if (!WITH_EP) {
+                const unsigned long long mn = __ballot(en), mo = __ballot(eo);
+                const uint32_t co0 = (uint32_t)__builtin_amdgcn_readlane((int)co, 0);
+                const uint32_t rn = (uint32_t)__builtin_amdgcn_readlane((int)runn, 0), ro = (uint32_t)__builtin_amdgcn_readlane((int)runo, 0);
+                if (en) rel[x] = (REL)(co0 + rn + (uint32_t)__popcll(mn & lt));
+                if (eo) rel[x] = (REL)(ro + (uint32_t)__popcll(mo & lt));
+                if (lane == 0) { runn += (uint32_t)__popcll(mn); runo += (uint32_t)__popcll(mo); }
+                continue;
+            }
+            const int n = (int)(cb8 >> 6), c0 = (int)(cb8 & 63);
             unsigned long long bits = sa_wave_or64((en || eo) ? ((1ull << c0) | (n == 2 ? (2ull << c0) : 0ull)) : 0ull);
             while (bits) {
                 const int c = __builtin_ctzll(bits);
@@ -429,20 +448,106 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
     }
 }
 
-// ---- S5: one wave per range -- straddlers into place, sequential sums, weights, scaling --------------------------------------------
+// ---- S4a: the ice cells across ONE GCM-cell edge (two exchange cells in two ranges: nearly all ice cells with several cells) -----
+// One thread per pair from three static arrays (first cell, second cell, ice cell): every dynamic load -- the two areas, the mask
+// value, the code byte, the id -- is independent of the others, where k_fa_pelem walks mlist -> ilptr -> ilist -> cell (measured on
+// the Antarctic AvI: 528 MB fetched for 2.7 M ice cells).  G_ROWS: Mw of the ice cell (its <= 4 entries in ascending row order,
+// from zero); otherwise its row (ascending column, wM, scaling) at the offset k_sa_emit recorded.
+template <bool WITH_EP, bool G_ROWS>
+__global__ __launch_bounds__(256) void k_sa_pairs(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, SaBuf sb, const int32_t *__restrict__ px1,
+                                                   const int32_t *__restrict__ px2, const int32_t *__restrict__ piI, int npair, FaOut o) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    stage_hc<WITH_EP>(rg, s_hc);
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= npair) return;
+    const int x1 = px1[k], x2 = px2[k], iI = piI[k];
+    if (!(sb.code[x1] & SA_P)) return;                           // masked (or no area at all): not a member of the I set
+    const double e = WITH_EP ? rg.em[iI] : 0.0;
+    const double a1 = rg.area[x1], a2 = rg.area[x2];
+    const int r1 = pl.aidx[x1], r2 = pl.aidx[x2];
+    const int did = p.fresh ? (int)sa_prank_at(sb.Pw, sb.code, x1) : iI;
+    const long iA1 = pl.riA[r1], iA2 = pl.riA[r2];
+    GEnt g1, g2;
+    {
+        const XCell c1 = make_cell<WITH_EP>(rg, iA1, iI, a1, e), c2 = make_cell<WITH_EP>(rg, iA2, iI, a2, e);
+        g1.n = g2.n = 0; g1.cls0 = g1.cls1 = g2.cls0 = g2.cls1 = 0; g1.t0 = g1.t1 = g2.t0 = g2.t1 = 0.0; g1.gkey0 = g1.gkey1 = g2.gkey0 = g2.gkey1 = 0;
+        if (!(WITH_EP && c1.range_error)) {
+            fa_group<WITH_EP>(rg, pl, s, G_ROWS, false, c1, x1, g1);
+            fa_group<WITH_EP>(rg, pl, s, G_ROWS, false, c2, x2, g2);
+        }
+    }
+    if (G_ROWS) {
+        // rows ascend with the range, inside a range with the first-seen rank of the class
+        double sum = 0.0;
+        auto add = [&](const GEnt &ge, int r) {
+            if (ge.n == 1) sum = sum + ge.t0;
+            else if (ge.n == 2) {
+                const bool sw = g.erank[(size_t)r * g.NC + ge.cls0] > g.erank[(size_t)r * g.NC + ge.cls1];
+                sum = sum + (sw ? ge.t1 : ge.t0); sum = sum + (sw ? ge.t0 : ge.t1);
+            }
+        };
+        add(g1, r1); add(g2, r2);
+        o.Mw[did] = sum;
+        return;
+    }
+    // the row: <= 4 entries (id, term, atmosphere cell) into ascending column order (a pre-populated column set may list them in
+    // any order), wM = their sum in that order, M = [1/wM] * T [* sApvA]   (RegridMatrices_Dynamic.cpp:201-233)
+    int id[4] = {0, 0, 0, 0};
+    double t[4] = {0, 0, 0, 0};
+    long ia[4] = {0, 0, 0, 0};
+    int n = 0;
+    auto put = [&](const GEnt &ge, int r, long iA) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j >= ge.n) break;
+            const int d = fa_gdense(g, r, ge.cls(j), ge.gkey(j));
+            // insertion into the sorted prefix (n <= 3 here)
+            int pos = n;
+#pragma unroll
+            for (int q = 3; q >= 1; --q)
+                if (q <= n && q == pos && id[q - 1] > d) { id[q] = id[q - 1]; t[q] = t[q - 1]; ia[q] = ia[q - 1]; pos = q - 1; }
+            id[pos] = d; t[pos] = ge.t(j); ia[pos] = iA;
+            ++n;
+        }
+    };
+    put(g1, r1, iA1); put(g2, r2, iA2);
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (q < n) sum = sum + t[q];
+    o.wM[did] = sum;
+    const int b0 = o.rowptr[did];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q >= n) break;
+        double v = t[q];
+        if (o.scale) v = (1.0 / sum) * v;
+        if (o.correctA) v = v * rg.ratioA[ia[q]];
+        o.colind[b0 + q] = id[q]; o.val[b0 + q] = v;
+    }
+}
+
+// ---- S5: one wave per (range, class) -- straddlers into place, sequential sums, weights, scaling --------------------------------
+// A segment = the entries of one (range, class): a row of an A/E-row matrix, or the terms of one column of an I/X-row matrix
+// (scratch copy).  The sum must run in sequence (spsparse sum(): ascending column / row): the wave loads the segment coalesced
+// into registers -- every load issued before anything is consumed -- and replays the chain with v_readlane; the scaled values are
+// written from the same registers.  Tried and measured on 17.5 M values in 50 000 segments (scratch/sload_test.hip: chain 206 us,
+// wide SCALAR loads -- s_load_dwordx16 through the constant cache feeding v_add_f64 directly -- 106 us, a THREAD per segment
+// 40 us): inside this kernel the scalar chain brought nothing (a1h EvI 310 -> 334 us: eleven dependent L2 round trips per
+// segment where the register chain has none) and read every value twice; the thread per segment cannot scale the row in place
+// (its stores touch 64 lines per instruction: 600 us) and starves on long rows (1 km: 685 us).
 // EMIT: the rows of an A/E-row matrix (CSR in place: o.colind / o.val).  Otherwise the column sums of an I/X-row matrix over the
 // scratch copy of the terms (o.val = scratch, sdid = the row ids of the straddling terms).
-template <bool EMIT>
-__global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, FaOut o, int32_t *__restrict__ sdid, uint32_t *__restrict__ flags) {
-    __shared__ int s_did[4][SA_OLDSEG], s_did2[4][SA_OLDSEG];
-    __shared__ double s_t[4][SA_OLDSEG], s_t2[4][SA_OLDSEG];
-    constexpr int NV = 8;                                        // chunks of 64 values of a segment kept in registers
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+template <bool EMIT, int OLDSEG>
+__global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, FaOut o, int32_t *__restrict__ sdid) {
+    __shared__ int s_did[4][OLDSEG], s_did2[4][OLDSEG];
+    __shared__ double s_t[4][OLDSEG], s_t2[4][OLDSEG];
+    constexpr int NV = 8;                                        // chunks of 64 values of a segment loaded up front and kept in registers
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = blockIdx.x * 4 + wv;
     if (r >= pl.nAr) return;
-    if (EMIT && r == pl.nAr - 1 && lane == 0) o.rowptr[g.gbase[pl.nAr]] = (int32_t)g.ebase[pl.nAr];      // rowptr[nrow] = nnz
+    if (EMIT && r == pl.nAr - 1 && lane == 0 && blockIdx.y == 0) o.rowptr[g.gbase[pl.nAr]] = (int32_t)g.ebase[pl.nAr];      // rowptr[nrow] = nnz
     const int ncls = (int)g.r_ncls[r];
-    if (ncls == 0) return;
+    if ((int)blockIdx.y >= ncls) return;
     const uint32_t eb = g.ebase[r];
     int rank = -1;
     uint32_t seg = 0, nold_c = 0;
@@ -453,16 +558,17 @@ __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, 
     }
     int32_t *__restrict__ ids = EMIT ? o.colind : sdid;
     const long iA = pl.riA[r];
-    uint32_t start = 0;
-    for (int q = 0; q < ncls; ++q) {
+    // the classes of a range are dealt to the waves of grid dimension y (first-seen rank q, q + gridDim.y, ...): a class's segment
+    // starts where the segments of the classes ranked before it end
+    for (int q = (int)blockIdx.y; q < ncls; q += (int)gridDim.y) {
         const unsigned long long mq = __ballot(rank == q);
         if (!mq) break;                                          // (cannot happen: ranks 0 .. ncls-1 are all taken)
         const int cls = __builtin_ctzll(mq);
+        const uint32_t start = (uint32_t)__builtin_amdgcn_readfirstlane((int)sa_wave_sum_u32((rank >= 0 && rank < q) ? seg : 0u));
         const uint32_t sg = (uint32_t)__builtin_amdgcn_readlane((int)seg, cls);
         uint32_t no = (uint32_t)__builtin_amdgcn_readlane((int)nold_c, cls);
-        if (no > (uint32_t)SA_OLDSEG) no = SA_OLDSEG;            // (the build is being discarded: FA_ERR_OLDOVER; stay inside the tables)
+        if (no > (uint32_t)OLDSEG) no = OLDSEG;                  // (the build is being discarded: FA_ERR_OLDOVER; stay inside the tables)
         const uint32_t b = eb + start, e = b + sg, bn = b + no;
-        start += sg;
         // every load of the segment is issued up front: the straddling entries (ice cells first seen in an earlier range: smaller
         // ids; they lie at the segment's start in x order) and the first NV x 64 of the entries first seen in this range
         for (uint32_t k = lane; k < no; k += 64) { s_did[wv][k] = ids[b + k]; s_t[wv][k] = o.val[b + k]; }
@@ -483,8 +589,8 @@ __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // the sequential sum (spsparse sum(): ascending column / row): the straddlers, then the chain over the new entries
-        // replayed from registers with v_readlane (every lane computes the identical sum)
+        // the sequential sum: the straddlers, then the chain over the entries first seen in the range replayed from registers
+        // with v_readlane (every lane computes the identical sum)
         double sum = 0.0;
         for (uint32_t k = 0; k < no; ++k) sum = sum + s_t2[wv][k];
         auto chain = [&](double val, uint32_t cb) {
@@ -589,6 +695,8 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     A.reset();
     PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti, P.icnt_pos.p, P.icnt_nz.p, P.exI.p};
     pl.riA = P.riA.p;
+    PlanView pl3 = pl;                                           // (k_fa_pelem walks pl.mlist: here the ice cells that are no clean pairs)
+    pl3.mlist = P.mlist3.p; pl3.nmulti = P.nmulti3;
     const int T = FA_T, nAr = P.nAr;
     const long nW = ceil_div(nX, 64l);
     FaG g{};
@@ -614,12 +722,23 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     const dim3 gs(ceil_div(nX, (long)SA_TILE)), gr4(ceil_div(nAr, 4));
     if (uses_ep) hipLaunchKernelGGL((k_sa_flags<true>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt);
     else hipLaunchKernelGGL((k_sa_flags<false>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt);
-    if (uses_ep) {
-        if (rel32) hipLaunchKernelGGL((k_sa_ranges<true, uint32_t>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1);
-        else hipLaunchKernelGGL((k_sa_ranges<true, uint16_t>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1);
-    } else {
-        if (rel32) hipLaunchKernelGGL((k_sa_ranges<false, uint32_t>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1);
-        else hipLaunchKernelGGL((k_sa_ranges<false, uint16_t>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1);
+    const long mean = nX / std::max(nAr, 1);
+    // (straddlers of a range ~ its perimeter: a range of ~10^3 cells has a few dozen, one of 10^4 a few hundred)
+    const int forced_os = get_tuning("assemble_stream_oldseg", -1);
+    const int oldseg = (forced_os == SA_OLDSEG_S || forced_os == SA_OLDSEG_L) ? forced_os : mean <= 2048 ? SA_OLDSEG_S : SA_OLDSEG_L;
+    {
+        // waves per range by the size of the ranges: one wave walks ~10^3 cells in a few round trips; longer ranges are cut
+        const int forced = get_tuning("assemble_stream_wpr", -1);
+        const int wpr = (forced == 1 || forced == 4 || forced == 16) ? forced : mean <= 1024 ? 1 : mean <= 4096 ? 4 : 16;
+#define SA_LAUNCH_RANGES(EP, RT)                                                                                               \
+        do {                                                                                                                \
+            if (wpr == 1) hipLaunchKernelGGL((k_sa_ranges<EP, RT, 1>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg);    \
+            else if (wpr == 4) hipLaunchKernelGGL((k_sa_ranges<EP, RT, 4>), dim3(nAr), dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg); \
+            else hipLaunchKernelGGL((k_sa_ranges<EP, RT, 16>), dim3(nAr), dim3(1024), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg);     \
+        } while (0)
+        if (uses_ep) { if (rel32) SA_LAUNCH_RANGES(true, uint32_t); else SA_LAUNCH_RANGES(true, uint16_t); }
+        else { if (rel32) SA_LAUNCH_RANGES(false, uint32_t); else SA_LAUNCH_RANGES(false, uint16_t); }
+#undef SA_LAUNCH_RANGES
     }
     if (p.fresh) exclusive_scan_u8(sb.cntP, sb.Pw, (size_t)nW, d_cnt + 2, st);
     if (!g_is_row) exclusive_scan_u32(sb.cntL, sb.Lw, (size_t)nW, nullptr, st);
@@ -660,6 +779,8 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
     FaOut o{w->rowptr.p, w->colind.p, w->val.p, w->wM.p, w->Mw.p, sp->family, scale, correctA, 0};
     uint32_t *flags = d_cnt + 1;
+    // row kernel: a wave per (range, class); y = the classes a range has on average, rounded up, + 1 (the others loop)
+    const dim3 grq(ceil_div(nAr, 4), g.NC == 1 ? 1 : std::max(1, std::min(std::min(g.NC, 16), (int)(h[3] / (uint32_t)std::max(nAr, 1)) + 2)));
     double *sval = nullptr;
     int32_t *sdid = nullptr;
 #define SA_LAUNCH_EMIT(EP, GR)                                                                                                  \
@@ -670,30 +791,42 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     if (g_is_row) {
         if (ncol && !p.fresh) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
         if (uses_ep) SA_LAUNCH_EMIT(true, true); else SA_LAUNCH_EMIT(false, true);
-        if (p.key == KEY_I && P.nmulti) {                     // Mw of the ice cells with several exchange cells
-            const dim3 gm(ceil_div(P.nmulti, T));
-            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
-            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
+        if (p.key == KEY_I && P.npair) {                      // Mw of the ice cells across one GCM-cell edge
+            const dim3 gp2(ceil_div(P.npair, 256));
+            if (uses_ep) hipLaunchKernelGGL((k_sa_pairs<true, true>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.npair, o);
+            else hipLaunchKernelGGL((k_sa_pairs<false, true>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.npair, o);
         }
-        hipLaunchKernelGGL((k_sa_rows<true>), gr4, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, flags);
+        if (p.key == KEY_I && P.nmulti3) {                    // ... and of the rest of the ice cells with several exchange cells
+            const dim3 gm(ceil_div(P.nmulti3, T));
+            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
+            else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
+        }
+        if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_S>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr);
+        else hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_L>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr);
     } else {
         sval = A.get<double>(nnz); sdid = A.get<int32_t>(nnz);
         IBH_HIP(hipMemcpyAsync(w->rowptr.p + nrow, d_cnt + 4, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         if (uses_ep) SA_LAUNCH_EMIT(true, false); else SA_LAUNCH_EMIT(false, false);
-        if (p.key == KEY_I && P.nmulti) {                     // the rows of the ice cells with several exchange cells
-            const dim3 gm(ceil_div(P.nmulti, T));
+        if (p.key == KEY_I && P.npair) {                      // the rows of the ice cells across one GCM-cell edge
+            const dim3 gp2(ceil_div(P.npair, 256));
+            if (uses_ep) hipLaunchKernelGGL((k_sa_pairs<true, false>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.npair, o);
+            else hipLaunchKernelGGL((k_sa_pairs<false, false>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.npair, o);
+        }
+        if (p.key == KEY_I && P.nmulti3) {                    // ... and of the rest of the ice cells with several exchange cells
+            const dim3 gm(ceil_div(P.nmulti3, T));
             if (!g_fresh) {
-                if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, true>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
-                else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, true>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
+                if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, true>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
+                else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, true>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
             } else {
-                if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
-                else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, o, (uint32_t *)nullptr, flags, 1);
+                if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, false>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
+                else hipLaunchKernelGGL((k_fa_pelem<false, FA_PEMIT, false>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
             }
         }
         if (!g_fresh && ncol) hipLaunchKernelGGL(k_fa_zero_identity, dim3(ceil_div(ncol, T)), dim3(T), 0, st, w->Mw.p, (long)ncol);
         FaOut os = o;
         os.val = sval;
-        hipLaunchKernelGGL((k_sa_rows<false>), gr4, dim3(256), 0, st, rg, pl, g, os, sdid, flags);
+        if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_S>), grq, dim3(256), 0, st, rg, pl, g, os, sdid);
+        else hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_L>), grq, dim3(256), 0, st, rg, pl, g, os, sdid);
     }
 #undef SA_LAUNCH_EMIT
     IBH_HIP(hipGetLastError());

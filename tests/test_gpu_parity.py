@@ -2082,6 +2082,10 @@ def test_streamed_build_is_the_oracle_bitwise(config, variant):
     names = [n for n in ALL if n not in ("EvA", "AvE")]
     try:
         icebin_amd.set_tuning("assemble_stream", 1)
+        # waves per range of the byte pass (by default chosen by the mean range length): every shape is walked
+        icebin_amd.set_tuning("assemble_stream_wpr", {("g20", "sorted"): 4, ("g20", "x_fastest"): 16, ("g50", "negative_area"): 16,
+                                                      ("g50", "elev_class"): 4}.get((config, variant), -2 ** 31))
+        icebin_amd.set_tuning("assemble_stream_oldseg", 512 if variant in ("x_fastest", "zero_area") else -2 ** 31)   # (the table size of the straddler sort)
         for scale, correctA in ((True, True), (False, False), (True, False), (False, True)):
             rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
             for name in names:
@@ -2113,6 +2117,8 @@ def test_streamed_build_is_the_oracle_bitwise(config, variant):
         assert_same_weighted(w, rg.matrix_d("XvE", em, dims=(oX, oE3), scale=True, correctA=True), "incomplete dimE " + variant)
     finally:
         icebin_amd.set_tuning("assemble_stream", -2 ** 31)
+        icebin_amd.set_tuning("assemble_stream_wpr", -2 ** 31)
+        icebin_amd.set_tuning("assemble_stream_oldseg", -2 ** 31)
 
 
 @pytest.mark.parametrize("nA_real,nX", [(12, 150000), (60, 200000)])
