@@ -74,6 +74,7 @@ def parse_args(argv=None):
     ap.add_argument("--warm", action="store_true", help="reuse ONE field batch (Infinity-Cache-resident numbers)")
     ap.add_argument("--queue-depth", type=int, default=32, help="applies submitted per launch (1..32); N>1: also applies per all-gather")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="ibh_set_tuning override (experiments)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not attach HIP events to the SpMM dispatches (plain launches: what a rocprofv3 kernel trace of a product call sees; roofline figures then come from the region events)")
     ap.add_argument("--dry-run", action="store_true", help="rehearse launcher + rendezvous + sharding + gather check on CPU (gloo, scipy apply); NOT a measurement")
     return ap.parse_args(argv)
 
@@ -194,18 +195,76 @@ def main():
     # results of `depth` applies share ONE all-gather while they are small (a [64, 122] AvI result is 62 KB:
     # a collective of that size is latency-bound); a result of megabytes (I-row matrices) is gathered per apply
     gsteps = depth if 8 * nf * ldy < (4 << 20) else 1
-    # ICEBIN_BENCH_SHARDED=cabi: the gathers through the library's own RCCL calls (ibh_comm, ibh_weighted_apply_*_sharded_device:
-    # direct peer-to-peer exchange) instead of torch.distributed's all_gather_into_tensor -- the path a C++ host takes
+    # The gathers go through the library's own RCCL calls by default (ibh_comm, ibh_weighted_apply_*_sharded_device: direct
+    # peer-to-peer exchange) -- the path a C++ host takes (north_star: "host code stays C++").  ICEBIN_BENCH_SHARDED=torch opts
+    # out (torch.distributed's all_gather_into_tensor); `gather_via` in the JSON line says which one ran.  If the C-ABI
+    # communicator cannot be created, or its first gathered result is not bitwise the locally recomputed shards, EVERY rank
+    # falls back to the torch path together (the decision is all-reduced) and `gather_via_fallback` says why.
     sharded = None
     sharded_via = None
+    sharded_fallback = None
     if use_dist:
-        if os.environ.get("ICEBIN_BENCH_SHARDED", "torch") == "cabi" and backend == "nccl":
+        want_cabi = os.environ.get("ICEBIN_BENCH_SHARDED", "cabi") == "cabi" and backend == "nccl"
+        if want_cabi:
             from icebin_amd.distributed import CabiFieldShardedApply, Communicator
-            sharded = CabiFieldShardedApply(W, nf_total, Communicator(world, rank, rccl=True), dev, steps_per_gather=gsteps)
-            sharded_via = "C-ABI: ibh_weighted_apply_many_sharded_device (grouped ncclSend/ncclRecv to every peer)"
-        else:
+            why = None
+            try:
+                sharded = CabiFieldShardedApply(W, nf_total, Communicator(world, rank, rccl=True), dev, steps_per_gather=gsteps)
+            except Exception as e:      # noqa: BLE001 -- e.g. no librccl to dlopen
+                why = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+            ok_t = torch.tensor([0 if why else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+            if ok_t.item() == 1:           # one gathered apply against the local recomputation, before anything is timed
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    x_probe = torch.from_numpy(syn.fields(nf, ncol, seed=syn.SEED + rank)).to(dev)
+                    g_, slot_ = sharded.apply_ptr(x_probe.data_ptr(), ncol)
+                    sharded.flush(); sharded.wait()
+                    torch.cuda.synchronize(dev)
+                    mine = sharded.result(g_, slot_)[rank * nf:(rank + 1) * nf] if not strong else None
+                    if mine is not None:
+                        ref = W.apply_device(x_probe, fill=nan, force_conservation=False)
+                        torch.cuda.synchronize(dev)
+                        same = torch.equal(mine.contiguous().view(torch.int64), ref[:, :nrow].contiguous().view(torch.int64))
+                        ok_t = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+                        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+                        if ok_t.item() != 1:
+                            why = "the first exchange through ibh_comm did not reproduce the local shard bitwise"
+            else:
+                why = why or "another rank could not create its ibh_comm communicator"
+            if why is None:
+                sharded_via = "C-ABI: ibh_weighted_apply_many_sharded_device (grouped ncclSend/ncclRecv to every peer)"
+            else:
+                sharded, sharded_fallback = None, why
+        if sharded is None:
             sharded = FieldShardedApply(W, nf_total, None, dev, steps_per_gather=gsteps)
             sharded_via = "torch.distributed all_gather_into_tensor (%s)" % backend
+
+    # ---- the assembly shared by the ranks (ibh_regrid_matrices_matrix_d_sharded; BASELINE config 5: "assembly + apply, 8 x MI355X")
+    asm_sharded = None
+    if use_dist and sharded_via and sharded_via.startswith("C-ABI"):
+        try:
+            ts = []
+            Ws = None
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+                t0 = time.perf_counter()
+                Ws = rm.matrix_d_sharded(sharded.comm, args.matrix, scale=True, correctA=True)
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t0)
+            same = (Ws.nrow_d, Ws.ncol_d, Ws.nnz) == (nrow, ncol, nnz)
+            if same:
+                for a, b in zip(Ws.csr_dense() + (Ws.wM, Ws.Mw), W.csr_dense() + (W.wM, W.Mw)):
+                    same = same and bool(np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, b.view(np.uint64) if b.dtype == np.float64 else b))
+            tt = torch.tensor([min(ts), 0.0 if same else 1.0, 1.0 if Ws.built_sharded() else 0.0], dtype=torch.float64, device=dev)
+            tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tmin = tt.clone(); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            asm_sharded = {"ms_max_over_ranks": float(tmax[0]) * 1e3, "ms_min_over_ranks": float(tmin[0]) * 1e3, "ms_this_rank": min(ts) * 1e3,
+                           "shared_by_the_ranks": bool(tmin[2] == 1.0), "bitwise_equal_to_the_replicated_build_on_every_rank": bool(tmax[1] == 0.0),
+                           "what": "ibh_regrid_matrices_matrix_d_sharded: best of 3 collective builds, barrier before each, wall time until this rank holds the whole matrix"}
+            del Ws
+        except Exception as e:      # noqa: BLE001
+            asm_sharded = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")}
 
     def plan(i0, n, depth_=None, nbuf_=None):
         """Launch plan for steps i0 .. i0+n-1: (count, X pointers, X pointer table, Y pointer table),
@@ -295,7 +354,7 @@ def main():
     nlaunch = len(timed_plan)
     B = spmm_bytes(nnz, nrow, ncol, nf)
     csr_bytes = 12 * nnz + 4 * (nrow + 1)
-    single_call_launches = not use_dist or all(m <= gsteps for (m, _, _, _) in timed_plan)
+    single_call_launches = (not use_dist or all(m <= gsteps for (m, _, _, _) in timed_plan)) and not args.no_kernel_events
     regions = []            # (wall s, region events ms, [kernel ms per launch]) per repetition
     spmm_only = None
     extras = {}
@@ -434,11 +493,15 @@ def main():
                          "algorithmic_bytes": asm_bytes(len(grids["ex_area"]), grids["nI"], nnz, nrow, ncol),
                          "GBps": asm_bytes(len(grids["ex_area"]), grids["nI"], nnz, nrow, ncol) / t_asm / 1e9},
         }
+        if asm_sharded is not None:
+            result["assembly"]["sharded"] = asm_sharded
         if use_dist:
             result["spmm_only_ms"] = spmm_only
             result["spmm_plus_gather_ms"] = dt / args.steps * 1e3
             result["gather_bytes_per_rank_per_step"] = 8 * nf * ((nrow + 63) // 64 * 64)
             result["gather_via"] = sharded_via
+            if sharded_fallback:
+                result["gather_via_fallback"] = sharded_fallback
             result["gather_check"] = gather_check
             result["ranks_seen"] = ranks_seen
         if not args.no_cpu_baseline and world == 1:

@@ -7,8 +7,10 @@
 
 namespace ibh {
 // RegridMatrices_Dynamic::matrix_d (RegridMatrices_Dynamic.cpp:412-423) on device.
+// comm: the sharded build (streamasm.inl) -- every rank of the communicator makes this call with the same arguments and gets the
+// whole matrix; the ranks share the work when the build is one the streamed path serves, and build redundantly otherwise
 bool assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_sparse_set *dim0, ibh_sparse_set *dim1,
-                     int scale, int correctA, const double sigma[3], ibh_weighted **out, bool fast_only = false);
+                     int scale, int correctA, const double sigma[3], ibh_weighted **out, bool fast_only = false, ibh_comm *comm = nullptr);
 // n builds with the results of n matrix_d calls in order; independent ones run concurrently (assemble.hip assemble_batch)
 void assemble_batch(const ibh_regrid_matrices *rm, int n, const char *const *specs, ibh_sparse_set *const *dim0,
                     ibh_sparse_set *const *dim1, const int32_t *scale, const int32_t *correctA, const double sigma[3],

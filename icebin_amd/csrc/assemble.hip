@@ -102,8 +102,10 @@ __device__ __forceinline__ void stage_hc(RgView &rg, double *s_hc) {
     }
 }
 // the arithmetic of a cell from its four inputs (callers that stage the loads of several cells themselves use this form)
+// (hint: the result of the class search when the caller already has it -- the upper class index of Z_INTERP, the class of
+// ELEV_CLASS_INTERP; < 0: search)
 template <bool WITH_EP>
-__device__ __forceinline__ XCell make_cell(const RgView &rg, long iA, long iI, double a, double e) {
+__device__ __forceinline__ XCell make_cell(const RgView &rg, long iA, long iI, double a, double e, int hint = -1) {
     XCell c;
     c.iA = iA;
     c.iI = iI;
@@ -119,7 +121,7 @@ __device__ __forceinline__ XCell make_cell(const RgView &rg, long iA, long iI, d
     if (WITH_EP && c.unmasked) {
         const double elevation = e < 0.0 ? 0.0 : e;          // std::max(elev, 0.0), :123
         if (rg.interp == 0) {                                // Z_INTERP, :127-145
-            int i1 = dev_lower_bound(rg.hc, rg.nhc, elevation);
+            int i1 = hint >= 0 ? hint : dev_lower_bound(rg.hc, rg.nhc, elevation);
             if (i1 <= 0) i1 = 1;
             if (i1 >= rg.nhc) { c.range_error = true; return c; }      // :84-85
             const int i0 = i1 - 1;
@@ -138,9 +140,10 @@ __device__ __forceinline__ XCell make_cell(const RgView &rg, long iA, long iI, d
             }
         } else {                                             // ELEV_CLASS_INTERP, :146-150 + nearest_1d :43-67
             const int n = rg.nhc;
-            int i1 = dev_lower_bound(rg.hc, n, elevation);
+            int i1 = hint >= 0 ? 0 : dev_lower_bound(rg.hc, n, elevation);
             int ih;
-            if (i1 <= 0) ih = 0;
+            if (hint >= 0) ih = hint;
+            else if (i1 <= 0) ih = 0;
             else if (i1 >= n) ih = n - 1;
             else {
                 const int i0 = i1 - 1;
@@ -1998,7 +2001,7 @@ static const MatSpec *find_spec(const char *spec_name) {
 // fast_only: build through the plan-based fast path or not at all (returns false, nothing touched) -- the mode of the
 // concurrent builds of a batch, which must not append to a set another build of the same wave is reading
 bool assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_sparse_set *dim0, ibh_sparse_set *dim1,
-                     int scale, int correctA, const double sigma[3], ibh_weighted **out, bool fast_only) {
+                     int scale, int correctA, const double sigma[3], ibh_weighted **out, bool fast_only, ibh_comm *comm) {
     IBH_CHECK(rm && spec_name && out, "null argument");
     const MatSpec *sp = find_spec(spec_name);
     // RegridParams::smooth() (RegridMatrices.hpp:31): only compute_IvAE smooths (RegridMatrices_Dynamic.cpp:237-248)
@@ -2035,7 +2038,7 @@ bool assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
     // sorted exchange grid + dims shapes it covers: the plan-based fast path (fastasm.inl); smoothing and the
     // band structure work on intermediates of the general pipeline
     const bool bands_wanted = sp->row_key == KEY_E && (sp->col_key == KEY_I || sp->col_key == KEY_X) && get_tuning("assemble_bands", 0);
-    if (!smooth && !bands_wanted && fast_build(rm, sp, dims, scale, correctA, rg, w.get(), st)) {
+    if (!smooth && !bands_wanted && fast_build(rm, sp, dims, scale, correctA, rg, w.get(), st, comm)) {
         if (!w->built_fast) w->built_fast = 1;          // (2: the streamed build, set by stream_build)
         *out = w.release();
         return true;

@@ -364,6 +364,16 @@ int ibh_regrid_matrices_matrix_d(const ibh_regrid_matrices *rm, const char *spec
         assemble_matrix(rm, spec, dim0, dim1, scale, correctA, sigma, out);
     });
 }
+int ibh_regrid_matrices_matrix_d_sharded(const ibh_regrid_matrices *rm, ibh_comm *c, const char *spec, ibh_sparse_set *dim0,
+                                         ibh_sparse_set *dim1, int scale, int correctA, ibh_weighted **out) {
+    return guarded([&] {
+        IBH_CHECK(rm && c && spec && out, "null argument");
+        check_rm_device(rm);
+        IBH_CHECK(dim0 == nullptr || dim0 != dim1, "dims[0] and dims[1] must be distinct sets");
+        const double sigma[3] = {0, 0, 0};
+        assemble_matrix(rm, spec, dim0, dim1, scale, correctA, sigma, out, false, c);
+    });
+}
 int ibh_regrid_matrices_matrix_batch(const ibh_regrid_matrices *rm, int32_t n, const char *const *specs,
                                      ibh_sparse_set *const *dim0, ibh_sparse_set *const *dim1, const int32_t *scale,
                                      const int32_t *correctA, const double sigma[3], ibh_weighted **out) {

@@ -39,6 +39,7 @@ struct Rccl {
     std::string err;
 };
 constexpr int kNcclFloat64 = 8;      // ncclDataType_t (rccl.h: ncclFloat64 = 8)
+constexpr int kNcclInt8 = 0;         //                 (ncclInt8 = ncclChar = 0)
 
 Rccl &rccl() {
     static Rccl r;
@@ -93,6 +94,7 @@ struct ibh_comm {
     int world = 1, rank = 0, device = 0;
     ibh::nccl_comm_t nccl = nullptr;
     ibh_exchange_fn custom = nullptr;
+    ibh_gatherv_fn custom_v = nullptr;       // pieces of unequal size (the sharded assembly); nullptr: the transport cannot carry them
     void *custom_user = nullptr;
     hipStream_t xs = nullptr;            // the exchange stream
     hipEvent_t ready = nullptr;
@@ -169,7 +171,62 @@ static void exchange(ibh_comm *c, double *const *d_bases, int nbase, int nplane,
     IBH_NCCL(r.GroupEnd());
 }
 
+// ---- pieces of the sharded ASSEMBLY (streamasm.inl): equal small blocks, and all-gathers of pieces of unequal size ------------------
+namespace ibh {
+int comm_world(const ibh_comm *c) { return c->world; }
+int comm_rank(const ibh_comm *c) { return c->rank; }
+// every rank's `count` doubles at base + rank*stride -> the same place on every peer, on `st`
+void comm_exchange_blocks(ibh_comm *c, double *base, int64_t count, int64_t stride, hipStream_t st) {
+    if (c->world == 1 || count == 0) return;
+    if (c->custom) {
+        const int rc = c->custom(c->custom_user, base, count, stride, c->world, c->rank, st);
+        if (rc != 0) fail(IBH_EHIP, "custom exchange callback failed (%d)", rc);
+        return;
+    }
+    Rccl &r = need_rccl();
+    IBH_NCCL(r.GroupStart());
+    for (int k = 1; k < c->world; ++k) {
+        const int to = (c->rank + k) % c->world, from = (c->rank - k + c->world) % c->world;
+        IBH_NCCL(r.Send(base + (int64_t)c->rank * stride, (size_t)count, kNcclFloat64, to, c->nccl, st));
+        IBH_NCCL(r.Recv(base + (int64_t)from * stride, (size_t)count, kNcclFloat64, from, c->nccl, st));
+    }
+    IBH_NCCL(r.GroupEnd());
+}
+// n arrays; of array i rank q owns the bytes [offs[i][q], offs[i][q+1]) and every rank ends up with all of them, in place; one
+// group (one RCCL launch) for all arrays, on `st`
+void comm_gatherv(ibh_comm *c, int n, void *const *bases, const int64_t *const *offs, hipStream_t st) {
+    if (c->world == 1 || n == 0) return;
+    if (c->custom) {
+        if (!c->custom_v) fail(IBH_ENOTIMPL, "this custom transport carries equal blocks only (ibh_comm_set_custom_gatherv)");
+        for (int i = 0; i < n; ++i) {
+            const int rc = c->custom_v(c->custom_user, bases[i], offs[i], c->world, c->rank, st);
+            if (rc != 0) fail(IBH_EHIP, "custom gatherv callback failed (%d)", rc);
+        }
+        return;
+    }
+    Rccl &r = need_rccl();
+    IBH_NCCL(r.GroupStart());
+    for (int k = 1; k < c->world; ++k) {
+        const int to = (c->rank + k) % c->world, from = (c->rank - k + c->world) % c->world;
+        for (int i = 0; i < n; ++i) {
+            char *b = static_cast<char *>(bases[i]);
+            const int64_t mine = offs[i][c->rank + 1] - offs[i][c->rank], theirs = offs[i][from + 1] - offs[i][from];
+            if (mine > 0) IBH_NCCL(r.Send(b + offs[i][c->rank], (size_t)mine, kNcclInt8, to, c->nccl, st));
+            if (theirs > 0) IBH_NCCL(r.Recv(b + offs[i][from], (size_t)theirs, kNcclInt8, from, c->nccl, st));
+        }
+    }
+    IBH_NCCL(r.GroupEnd());
+}
+}  // namespace ibh
+
 extern "C" {
+
+int ibh_comm_set_custom_gatherv(ibh_comm *c, ibh_gatherv_fn fn) {
+    return guarded([&] {
+        IBH_CHECK(c != nullptr && c->custom != nullptr, "not a communicator over a custom transport");
+        c->custom_v = fn;
+    });
+}
 
 int ibh_comm_unique_id(char id[IBH_UNIQUE_ID_BYTES]) {
     return guarded([&] {

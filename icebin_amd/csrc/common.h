@@ -185,6 +185,7 @@ struct ibh_plan {
     // (first cell, second cell, ice cell), served by a lean kernel without list walks; the rest (corners, duplicates) in mlist3
     ibh::DevBuf<int32_t> px1, px2, piI, mlist3;
     int32_t npair = 0, nmulti3 = 0;
+    std::vector<int32_t> arng_h;         // host copy of arng (the sharded build deals ranges to ranks), filled on first use
 };
 
 struct ibh_regridder {
@@ -293,6 +294,11 @@ struct ibh_exgrid {
 
 namespace ibh {
 // spmm.hip
+// comm.hip: the exchanges of the sharded assembly (streamasm.inl), enqueued on the caller's stream
+int comm_world(const ibh_comm *c);
+int comm_rank(const ibh_comm *c);
+void comm_exchange_blocks(ibh_comm *c, double *base, int64_t count, int64_t stride, hipStream_t st);
+void comm_gatherv(ibh_comm *c, int n, void *const *bases, const int64_t *const *offs, hipStream_t st);
 void spmm_launch(const ibh_weighted *w, const double *dA, int nvar, int64_t lda, double *dB, int64_t ldb,
                  double fill, int force_conservation, hipStream_t stream);
 void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA, int nvar, int64_t lda,

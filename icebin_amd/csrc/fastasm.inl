@@ -45,6 +45,7 @@ struct PlanView {
     const uint8_t *icnt_pos, *icnt_nz;      // static entry counts per ice cell (nullptr: count by visiting), see ibh_plan
     const int32_t *exI;                     // ice-cell index per exchange cell (compact copy of ex_indices[:, 1])
     const int32_t *riA;                     // atmosphere cell of every range (streamasm.inl)
+    long sx0, sx1;                          // sharded streamed build: only the ice cells first seen in [sx0, sx1) (sx1 == 0: all)
 };
 
 // ---- static plan ---------------------------------------------------------------------------------
@@ -897,6 +898,7 @@ __global__ __launch_bounds__(FA_T, (WITH_EP && MODE == 2) ? (ANYORDER ? 1 : 6) :
         const bool masked = e != e;
         if (masked && p.fresh) return;                      // not a member of the set: nothing to write
         const int f = pl.ifirst[q];
+        if (only_multi && pl.sx1 > 0 && (f < pl.sx0 || f >= pl.sx1)) return;      // another rank's ice cell
         if (!p.fresh) d = (int)q;
         else if (f >= 0) d = (int)fa_poff_at(p.poff, p.Pw, p.code, f);
         if (!masked) { lb = pl.ilptr[q]; le = pl.ilptr[q + 1]; }      // a masked cell has no entries (identity dims: an empty row / column)
@@ -1248,15 +1250,29 @@ static void fast_prewarm(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
 }
 
 static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
-                         const RgView &rg, ibh_weighted *w, hipStream_t st);          // streamasm.inl
+                         const RgView &rg, ibh_weighted *w, hipStream_t st, ibh_comm *comm);          // streamasm.inl
+// the first exchange cell of every range on the host (the sharded build deals ranges to ranks), copied once per plan
+static const std::vector<int32_t> &plan_arng_host(const ibh_regridder *g) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    ibh_plan &P = g->plan;
+    if (P.arng_h.empty()) {
+        P.arng_h.resize((size_t)P.nAr + 1);
+        IBH_HIP(hipMemcpy(P.arng_h.data(), P.arng.p, sizeof(int32_t) * ((size_t)P.nAr + 1), hipMemcpyDeviceToHost));
+    }
+    return P.arng_h;
+}
 // returns false when the fast path does not apply (nothing has been touched: the caller runs the general pipeline)
 static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
-                       const RgView &rg, ibh_weighted *w, hipStream_t st) {
+                       const RgView &rg, ibh_weighted *w, hipStream_t st, ibh_comm *comm = nullptr) {
     const ibh_regridder *gr = rm->rg;
     if (!get_tuning("assemble_fast", 1)) return false;
     if (!ensure_plan(gr, st)) return false;
     if (sp->family == FAM_EVA) return get_tuning("assemble_fast_eva", 1) && fast_build_eva(rm, sp, dims, scale, correctA, rg, w, st);
-    if (stream_build(rm, sp, dims, scale, correctA, rg, w, st)) return true;       // large grids: the streamed build
+    // the sharded build; when it does not apply (the same on every rank: static conditions, exchanged flags) the ranks go on
+    // to build the matrix redundantly
+    if (comm && comm_world(comm) > 1 && stream_build(rm, sp, dims, scale, correctA, rg, w, st, comm)) return true;
+    if (stream_build(rm, sp, dims, scale, correctA, rg, w, st, nullptr)) return true;       // large grids: the streamed build
     const bool g_is_row = sp->family == FAM_AEVI;
     ibh_sparse_set *gset = dims[g_is_row ? 0 : 1], *pset = dims[g_is_row ? 1 : 0];
     const int gkey = g_is_row ? sp->row_key : sp->col_key, glist = g_is_row ? sp->row_list : sp->col_list;

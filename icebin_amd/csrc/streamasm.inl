@@ -42,6 +42,12 @@ struct SaBuf {
     uint8_t *cntP;          // [nW]        new P keys per 64 cells
     uint32_t *cntL;         // [nW]        row entries per 64 cells (I/X-row matrices)
     uint32_t *Pw, *Lw;      // their exclusive scans
+    // the slice of the exchange grid this build works on (a whole sheet, or one rank's share of it -- ibh_regrid_matrices_matrix_d_sharded):
+    // ranges [sr0, sr1) = cells [sx0, sx1); the per-cell passes cover whole waves, [gx0, gx1) = the slice rounded out to 64 cells
+    long sx0, sx1, gx0, gx1;
+    int sr0, sr1;
+    int end_row;            // rowptr[end_row] = end_nnz (the closing entry of the row pointer), written by the emit pass
+    uint32_t end_nnz;
 };
 
 __device__ __forceinline__ uint32_t sa_wave_sum_u32(uint32_t v) {
@@ -115,14 +121,14 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     stage_hc<WITH_EP>(rg, s_hc);
     const int tid = threadIdx.x, lane = tid & 63;
-    const long cb = (long)blockIdx.x * SA_TILE;
+    const long cb = sb.gx0 + (long)blockIdx.x * SA_TILE;
     int iIv[SA_CPT];
     unsigned fl[SA_CPT];
     double ev[SA_CPT];
 #pragma unroll
     for (int u = 0; u < SA_CPT; ++u) {
         const long x = cb + (long)u * SA_T + tid;
-        const long xx = x < rg.nX ? x : rg.nX - 1;
+        const long xx = x < sb.gx1 ? x : sb.gx1 - 1;
         iIv[u] = pl.exI[xx]; fl[u] = pl.isdup[xx];
     }
 #pragma unroll
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
 #pragma unroll
     for (int u = 0; u < SA_CPT; ++u) {
         const long x = cb + (long)u * SA_T + tid;
-        const bool in = x < rg.nX;
+        const bool in = x < sb.gx1;
         const bool unm = in && !(ev[u] != ev[u]);
         const bool head = pkey_x || !(fl[u] & 1);
         unsigned ga = fl[u] & 24;                                  // sign classes of the areas of the group this cell heads
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
         }
         const unsigned long long bp = __ballot(P);
         const long xw = cb + (long)u * SA_T + (tid & ~63);
-        if (lane == 0 && xw < rg.nX) sb.cntP[xw >> 6] = (uint8_t)__popcll(bp);
+        if (lane == 0 && xw < sb.gx1) sb.cntP[xw >> 6] = (uint8_t)__popcll(bp);
         if (prows) {
             // entries of the row this cell owns: a one-cell ice cell / an exchange cell -> its own entries; an ice cell with
             // several exchange cells -> (groups of duplicates with a contributing member: static, plan) x (classes)
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
             }
             if (in) sb.rl[x] = (uint8_t)len;
             const uint32_t tot = sa_wave_sum_u32(len);
-            if (lane == 0 && xw < rg.nX) sb.cntL[xw >> 6] = tot;
+            if (lane == 0 && xw < sb.gx1) sb.cntL[xw >> 6] = tot;
         }
     }
 }
@@ -178,9 +184,9 @@ template <bool WITH_EP, typename REL, int WPR>
 __global__ __launch_bounds__(WPR == 16 ? 1024 : 256) void k_sa_ranges(RgView rg, PlanView pl, SaBuf sb, FaG g, uint32_t *__restrict__ flags, int oldseg) {
     __shared__ uint32_t s_first[WPR > 1 ? WPR : 1][64], s_cn[WPR > 1 ? WPR : 1][64], s_co[WPR > 1 ? WPR : 1][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = WPR == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
+    const int r = sb.sr0 + (WPR == 1 ? (int)blockIdx.x * 4 + wv : (int)blockIdx.x);
     const int ws = WPR == 1 ? 0 : wv;                              // this wave's slice of the range
-    if (r >= pl.nAr) return;                                     // (WPR > 1: the whole workgroup)
+    if (r >= sb.sr1) return;                                     // (WPR > 1: the whole workgroup)
     const long r0 = pl.arng[r], r1 = pl.arng[r + 1];
     const long slice = WPR == 1 ? (r1 - r0) : ((((r1 - r0) + WPR - 1) / WPR + 63) & ~63l);
     const long x0 = r0 + ws * slice, x1 = (x0 + slice < r1) ? x0 + slice : r1;
@@ -317,39 +323,44 @@ __global__ __launch_bounds__(WPR == 16 ? 1024 : 256) void k_sa_ranges(RgView rg,
 // ---- S3: the entries, the dims table, Mw / the rows -----------------------------------------------------------------------------
 // G_ROWS: A/E-row matrix -- o is the matrix (CSR in place), Mw of the P side.  Otherwise I/X-row matrix -- o is the matrix (rows
 // written here, one per P key), sval / sdid the scratch copy of the terms in (range, class) order for the column sums.
-template <bool WITH_EP, bool G_ROWS, typename REL>
+template <bool WITH_EP, bool G_ROWS, typename REL, int CPT>
 __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, SaBuf sb, int merge, FaOut o,
                                                   double *__restrict__ sval, int32_t *__restrict__ sdid) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     stage_hc<WITH_EP>(rg, s_hc);
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    const long cb = (long)blockIdx.x * SA_TILE;
+    const long cb = sb.gx0 + (long)blockIdx.x * (SA_T * CPT);
     const REL *__restrict__ rel = static_cast<const REL *>(sb.rel);
     constexpr int S = WITH_EP ? 2 : 1;
     const bool pkey_x = p.key == KEY_X;
+    if (blockIdx.x == 0 && tid == 0) o.rowptr[sb.end_row] = (int32_t)sb.end_nnz;
     // round 1: the code bytes and (one address per wave) the range of each wave's first cell; round 2: everything the cells with
     // entries / with a new P key need -- the range of a cell is its wave's first range + the range heads up to its lane (code bit
     // 7), so the per-range values are fetched in the same round as the cell itself; round 3: the mask value (elevation classes)
-    unsigned cd[SA_CPT];
-    int rb[SA_CPT];
+    unsigned cd[CPT];
+    int rb[CPT];
 #pragma unroll
-    for (int u = 0; u < SA_CPT; ++u) {
+    for (int u = 0; u < CPT; ++u) {
         const long x = cb + (long)u * SA_T + tid;
         const long xw = cb + (long)u * SA_T + (tid & ~63);
-        cd[u] = x < rg.nX ? sb.code[x] : 0u;
-        rb[u] = pl.aidx[xw < rg.nX ? xw : rg.nX - 1];
+        cd[u] = x < sb.gx1 ? sb.code[x] : 0u;
+        rb[u] = pl.aidx[xw < sb.gx1 ? xw : sb.gx1 - 1];
     }
     const unsigned long long le = lt | (1ull << lane);
-    int iIv[SA_CPT], rv[SA_CPT], iAv[SA_CPT];
-    double av[SA_CPT];
-    uint32_t lenv[SA_CPT], ebv[SA_CPT], relv[SA_CPT][S], pwv[SA_CPT], lwv[SA_CPT];
+    int iIv[CPT], rv[CPT], iAv[CPT], hintv[CPT];
+    double av[CPT];
+    uint32_t lenv[CPT], ebv[CPT], relv[CPT][S], pwv[CPT], lwv[CPT];
+    unsigned long long bpv[CPT];
 #pragma unroll
-    for (int u = 0; u < SA_CPT; ++u) {
+    for (int u = 0; u < CPT; ++u) {
         const long x = cb + (long)u * SA_T + tid;
         const long xw = cb + (long)u * SA_T + (tid & ~63);
+        // (the wave's ballots -- range heads here, new P keys below -- see every lane; the ROLES only the cells of the slice)
+        const unsigned long long heads = __ballot((cd[u] & SA_RHEAD) != 0), pbits = __ballot((cd[u] & SA_P) != 0);
+        bpv[u] = pbits;
+        if (x < sb.sx0 || x >= sb.sx1) cd[u] = 0u;
         const bool want = (cd[u] & (SA_ENT | SA_P)) != 0, ent = (cd[u] & SA_ENT) != 0;
-        const unsigned long long heads = __ballot((cd[u] & SA_RHEAD) != 0);
         rv[u] = rb[u] + (int)__popcll(heads & le & ~1ull);
         iIv[u] = want ? pl.exI[x] : 0;
         av[u] = ent ? rg.area[x] : 0.0;
@@ -357,19 +368,27 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
         iAv[u] = (ent && (WITH_EP || !G_ROWS)) ? pl.riA[rv[u]] : 0;      // (an A-row matrix without classes never looks at the atmosphere index here)
 #pragma unroll
         for (int j = 0; j < S; ++j) relv[u][j] = ent ? (uint32_t)rel[(size_t)S * x + j] : 0u;
-        lenv[u] = (!G_ROWS && x < rg.nX) ? sb.rl[x] : 0u;
-        pwv[u] = (p.fresh && xw < rg.nX) ? sb.Pw[xw >> 6] : 0u;
-        lwv[u] = (!G_ROWS && xw < rg.nX) ? sb.Lw[xw >> 6] : 0u;
+        lenv[u] = (!G_ROWS && x < sb.gx1) ? sb.rl[x] : 0u;
+        hintv[u] = -1;
+        if (WITH_EP && ent) {
+            // the class search was done by k_sa_flags: byte = first class | classes << 6.  Z_INTERP: two classes -> (c0, c0 + 1); one
+            // class -> the elevation sits exactly on class c0, which lower_bound reports as the UPPER index (the lower one only at 0)
+            const unsigned cb8 = sb.cls[x];
+            const int c0 = (int)(cb8 & 63), n = (int)(cb8 >> 6);
+            hintv[u] = rg.interp == 0 ? (n == 2 ? c0 + 1 : (c0 == 0 ? 1 : c0)) : c0;
+        }
+        pwv[u] = (p.fresh && xw < sb.gx1) ? sb.Pw[xw >> 6] : 0u;
+        lwv[u] = (!G_ROWS && xw < sb.gx1) ? sb.Lw[xw >> 6] : 0u;
     }
-    double ev[SA_CPT];
+    double ev[CPT];
 #pragma unroll
-    for (int u = 0; u < SA_CPT; ++u) ev[u] = (WITH_EP && (cd[u] & SA_ENT)) ? rg.em[iIv[u]] : 0.0;
+    for (int u = 0; u < CPT; ++u) ev[u] = (WITH_EP && (cd[u] & SA_ENT)) ? rg.em[iIv[u]] : 0.0;
 #pragma unroll
-    for (int u = 0; u < SA_CPT; ++u) {
+    for (int u = 0; u < CPT; ++u) {
         const long x = cb + (long)u * SA_T + tid;
-        const bool in = x < rg.nX;
+        const bool in = x >= sb.sx0 && x < sb.sx1;
         const bool P = (cd[u] & SA_P) != 0, ent = (cd[u] & SA_ENT) != 0, old = (cd[u] & SA_OLD) != 0;
-        const unsigned long long bp = __ballot(P);
+        const unsigned long long bp = bpv[u];
         const int iI = iIv[u], r = rv[u];
         // dense id of the P key first seen at this cell
         int pown;
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
         ge.n = 0; ge.cls0 = ge.cls1 = 0; ge.t0 = ge.t1 = 0.0; ge.gkey0 = ge.gkey1 = 0;
         const long iA = iAv[u];
         if (ent) {
-            const XCell c = make_cell<WITH_EP>(rg, iA, iI, av[u], ev[u]);
+            const XCell c = make_cell<WITH_EP>(rg, iA, iI, av[u], ev[u], hintv[u]);
             if (!(WITH_EP && c.range_error)) fa_group<WITH_EP>(rg, pl, s, G_ROWS, merge != 0 && (cd[u] & SA_DUPNEXT), c, x, ge);
         }
         if (ge.n > 0) {
@@ -461,12 +480,15 @@ __global__ __launch_bounds__(256) void k_sa_pairs(RgView rg, PlanView pl, MatSpe
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= npair) return;
     const int x1 = px1[k], x2 = px2[k], iI = piI[k];
+    if (x1 < sb.sx0 || x1 >= sb.sx1) return;                     // (the rank whose slice holds the first cell serves the ice cell)
     if (!(sb.code[x1] & SA_P)) return;                           // masked (or no area at all): not a member of the I set
     const double e = WITH_EP ? rg.em[iI] : 0.0;
     const double a1 = rg.area[x1], a2 = rg.area[x2];
-    const int r1 = pl.aidx[x1], r2 = pl.aidx[x2];
+    // (an A-row matrix without classes needs neither the ranges nor the atmosphere cells: its terms are functions of the areas)
+    constexpr bool NEED_R = WITH_EP || !G_ROWS;
+    const int r1 = NEED_R ? pl.aidx[x1] : 0, r2 = NEED_R ? pl.aidx[x2] : 0;
     const int did = p.fresh ? (int)sa_prank_at(sb.Pw, sb.code, x1) : iI;
-    const long iA1 = pl.riA[r1], iA2 = pl.riA[r2];
+    const long iA1 = NEED_R ? pl.riA[r1] : 0, iA2 = NEED_R ? pl.riA[r2] : 0;
     GEnt g1, g2;
     {
         const XCell c1 = make_cell<WITH_EP>(rg, iA1, iI, a1, e), c2 = make_cell<WITH_EP>(rg, iA2, iI, a2, e);
@@ -538,14 +560,13 @@ __global__ __launch_bounds__(256) void k_sa_pairs(RgView rg, PlanView pl, MatSpe
 // EMIT: the rows of an A/E-row matrix (CSR in place: o.colind / o.val).  Otherwise the column sums of an I/X-row matrix over the
 // scratch copy of the terms (o.val = scratch, sdid = the row ids of the straddling terms).
 template <bool EMIT, int OLDSEG>
-__global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, FaOut o, int32_t *__restrict__ sdid) {
+__global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, FaOut o, int32_t *__restrict__ sdid, int sr0, int sr1) {
     __shared__ int s_did[4][OLDSEG], s_did2[4][OLDSEG];
     __shared__ double s_t[4][OLDSEG], s_t2[4][OLDSEG];
     constexpr int NV = 8;                                        // chunks of 64 values of a segment loaded up front and kept in registers
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = blockIdx.x * 4 + wv;
-    if (r >= pl.nAr) return;
-    if (EMIT && r == pl.nAr - 1 && lane == 0 && blockIdx.y == 0) o.rowptr[g.gbase[pl.nAr]] = (int32_t)g.ebase[pl.nAr];      // rowptr[nrow] = nnz
+    const int r = sr0 + (int)blockIdx.x * 4 + wv;
+    if (r >= sr1) return;
     const int ncls = (int)g.r_ncls[r];
     if ((int)blockIdx.y >= ncls) return;
     const uint32_t eb = g.ebase[r];
@@ -664,14 +685,50 @@ __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, 
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
-// false: not served here (nothing has been touched: fast_build's own kernels run next)
+// sum of the row-length bytes before cell x inside its wave (the P-key counterpart is sa_prank_at)
+__device__ __forceinline__ uint32_t sa_lrank_at(const uint32_t *__restrict__ Lw, const uint8_t *__restrict__ rl, long x) {
+    const long w = x >> 6;
+    const int k = (int)(x & 63);
+    uint32_t v = Lw[w];
+    for (int j = 0; j < k; ++j) v += rl[(w << 6) + j];
+    return v;
+}
+// a rank's share of a sharded build: keys / row entries of ITS cells [sx0, sx1) from the scans that started at gx0
+// out: [2] new P keys, [5] row entries, [6] P keys before sx0 in the local numbering, [7] row entries before sx0
+__global__ void k_sa_slice_counts(SaBuf sb, int p_fresh, int prows, uint32_t *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t p0 = 0, p1 = 0, l0 = 0, l1 = 0;
+    if (p_fresh) { p0 = sa_prank_at(sb.Pw, sb.code, sb.sx0); p1 = sa_prank_at(sb.Pw, sb.code, sb.sx1); }
+    if (prows) { l0 = sa_lrank_at(sb.Lw, sb.rl, sb.sx0); l1 = sa_lrank_at(sb.Lw, sb.rl, sb.sx1); }
+    out[2] = p1 - p0; out[5] = l1 - l0; out[6] = p0; out[7] = l0;
+}
+// local scans -> global numbering: Pw, Lw over the slice's waves, gbase / ebase over its ranges
+__global__ void k_sa_shift(uint32_t *__restrict__ Pw, uint32_t *__restrict__ Lw, long w0, long nw, uint32_t dP, uint32_t dL,
+                           uint32_t *__restrict__ gbase, uint32_t *__restrict__ ebase, int r0, int nr, uint32_t dG, uint32_t dE) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nw) { if (Pw) Pw[w0 + i] += dP; if (Lw) Lw[w0 + i] += dL; }
+    if (i <= nr) { gbase[r0 + i] += dG; ebase[r0 + i] += dE; }
+}
+__global__ void k_sa_set_u32(uint32_t *p, uint32_t v) { *p = v; }
+
+// false: not served here (nothing has been touched: fast_build's own kernels run next).
+// comm != nullptr: the SHARDED build of ibh_regrid_matrices_matrix_d_sharded -- every rank of the communicator calls this with the
+// same arguments; rank k runs the passes over its share of the ranges (contiguous, balanced by exchange cells: the grid is sorted
+// by atmosphere cell, AbbrGrid.cpp:10-21, so a block of ranges is a block of rows of an A/E-row matrix), three exchanges make
+// every rank's result the whole matrix:
+//   1. per rank {first out-of-range cell, fallback flags, new P keys, classes, entries, row entries} (32 bytes) -> offsets of every
+//      rank's pieces; an error or a fallback is taken by all ranks together
+//   2. the code bytes and the P-key prefixes of every 64 cells (the "first-seen flags": a straddler's id is looked up in the slice
+//      of the rank that numbered its ice cell), the class ranks and row offsets of every range   (~1 byte per exchange cell)
+//   3. the pieces of the result: CSR, wM, Mw, the dims tables
 static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
-                         const RgView &rg, ibh_weighted *w, hipStream_t st) {
+                         const RgView &rg, ibh_weighted *w, hipStream_t st, ibh_comm *comm) {
     const ibh_regridder *gr = rm->rg;
     const ibh_plan &P = gr->plan;
     const long nX = gr->nX;
+    const int world = comm ? comm_world(comm) : 1, rank = comm ? comm_rank(comm) : 0;
     if (sp->family == FAM_EVA) return false;
-    if (!get_tuning("assemble_stream", nX >= (1l << 20) ? 1 : 0)) return false;
+    if (!comm && !get_tuning("assemble_stream", nX >= (1l << 20) ? 1 : 0)) return false;
     const bool g_is_row = sp->family == FAM_AEVI;
     ibh_sparse_set *gset = dims[g_is_row ? 0 : 1], *pset = dims[g_is_row ? 1 : 0];
     const int gkey = g_is_row ? sp->row_key : sp->col_key, glist = g_is_row ? sp->row_list : sp->col_list;
@@ -687,6 +744,9 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     if (uses_ep && (P.tiny || !P.icnt_nz.p)) return false;         // classes are counted by the sign of the area here
     if (!P.icnt_pos.p) return false;
     if (!g_is_row && pkey == KEY_I && pmode == 0) return false;    // rows in ice-cell order, not in first-seen order: fastasm.inl
+    // sharded: the pieces of a rank must be contiguous in every result array -- sets numbered by this build (an identity or a
+    // pre-populated set indexes Mw by sparse position); at most 8 ranks (one 256-byte read-back carries all counters)
+    if (world > 1 && (pmode != 1 || !g_fresh || world > 8 || P.nAr < world)) return false;
     const int merge = (sp->row_key != KEY_X && sp->col_key != KEY_X) ? 1 : 0;
     const int S = uses_ep ? 2 : 1;
     const bool rel32 = (int64_t)S * P.maxrange > 65535;
@@ -695,10 +755,30 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     A.reset();
     PlanView pl{P.arng.p, P.aidx.p, P.ilptr.p, P.ilist.p, P.ifirst.p, P.isdup.p, P.mlist.p, P.nAr, P.nmulti, P.icnt_pos.p, P.icnt_nz.p, P.exI.p};
     pl.riA = P.riA.p;
-    PlanView pl3 = pl;                                           // (k_fa_pelem walks pl.mlist: here the ice cells that are no clean pairs)
-    pl3.mlist = P.mlist3.p; pl3.nmulti = P.nmulti3;
     const int T = FA_T, nAr = P.nAr;
     const long nW = ceil_div(nX, 64l);
+    // ---- this rank's share: ranges [sr0, sr1) chosen so that every rank gets about the same number of exchange cells
+    std::vector<int> R(world + 1, 0);
+    std::vector<long> X(world + 1, 0);
+    R[world] = nAr; X[world] = nX;
+    if (world > 1) {
+        const std::vector<int32_t> &ah = plan_arng_host(gr);
+        for (int k = 1; k < world; ++k) {
+            const long target = nX * k / world;
+            int r = (int)(std::lower_bound(ah.begin(), ah.begin() + nAr, (int32_t)target) - ah.begin());
+            r = std::max(r, R[k - 1] + 1);                       // (every rank owns at least one range)
+            r = std::min(r, nAr - (world - k));
+            R[k] = r; X[k] = ah[r];
+        }
+    }
+    SaBuf sb{};
+    sb.sr0 = R[rank]; sb.sr1 = R[rank + 1]; sb.sx0 = X[rank]; sb.sx1 = X[rank + 1];
+    sb.gx0 = sb.sx0 & ~63l; sb.gx1 = std::min(nX, (sb.sx1 + 63) & ~63l);
+    const int nr = sb.sr1 - sb.sr0;
+    const long gW0 = sb.gx0 >> 6, gW1 = ceil_div(sb.gx1, 64l), nwl = gW1 - gW0;
+    pl.sx0 = sb.sx0; pl.sx1 = world > 1 ? sb.sx1 : 0;
+    PlanView pl3 = pl;                                           // (k_fa_pelem walks pl.mlist: here the ice cells that are no clean pairs)
+    pl3.mlist = P.mlist3.p; pl3.nmulti = P.nmulti3;
     FaG g{};
     g.key = gkey; g.list = glist; g.NC = gkey == KEY_E ? gr->nhc : 1;
     const size_t nrc = (size_t)nAr * g.NC;
@@ -709,17 +789,22 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     if (!g_fresh) g.tab = set_inverse_table(gset, gext, st);
     FaP p{};
     p.key = pkey; p.list = plist; p.fresh = pmode;
-    SaBuf sb{};
     sb.code = A.get<uint8_t>((size_t)nW * 64);
     if (uses_ep) sb.cls = A.get<uint8_t>((size_t)nW * 64);
-    if (!g_is_row) { sb.rl = A.get<uint8_t>((size_t)nW * 64); sb.cntL = A.get<uint32_t>((size_t)nW); sb.Lw = A.get<uint32_t>((size_t)nW); }
+    if (!g_is_row) { sb.rl = A.get<uint8_t>((size_t)nW * 64); sb.cntL = A.get<uint32_t>((size_t)nW + 1); sb.Lw = A.get<uint32_t>((size_t)nW + 1); }
     sb.rel = A.get_bytes((size_t)nX * S * (rel32 ? 4 : 2));
-    sb.cntP = A.get<uint8_t>((size_t)nW); sb.Pw = A.get<uint32_t>((size_t)nW);
+    sb.cntP = A.get<uint8_t>((size_t)nW + 1); sb.Pw = A.get<uint32_t>((size_t)nW + 1);
     p.Pw = sb.Pw; p.code = sb.code;
-    // counters read back with one sync: [0] first out-of-range cell, [1] fallback flags, [2] new P keys, [3] G classes, [4] entries
-    uint32_t *d_cnt = A.get<uint32_t>(8);
+    // counters, 8 per rank, read back with one sync: [0] first out-of-range cell, [1] fallback flags, [2] new P keys, [3] G classes,
+    // [4] entries, [5] row entries (I/X-row matrices), [6] / [7] where the slice starts in the local numberings
+    uint32_t *d_tot = A.get<uint32_t>((size_t)8 * world);
+    uint32_t *d_cnt = d_tot + 8 * rank;
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
-    const dim3 gs(ceil_div(nX, (long)SA_TILE)), gr4(ceil_div(nAr, 4));
+    if (world > 1) {     // (one more wave than the slice has: a zero count behind the last one, so that the scans also yield totals)
+        IBH_HIP(hipMemsetAsync(sb.cntP + gW1, 0, 1, st));
+        if (!g_is_row) IBH_HIP(hipMemsetAsync(sb.cntL + gW1, 0, sizeof(uint32_t), st));
+    }
+    const dim3 gs(ceil_div(sb.gx1 - sb.gx0, (long)SA_TILE)), gr4(ceil_div(nr, 4));
     if (uses_ep) hipLaunchKernelGGL((k_sa_flags<true>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt);
     else hipLaunchKernelGGL((k_sa_flags<false>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt);
     const long mean = nX / std::max(nAr, 1);
@@ -733,43 +818,73 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
 #define SA_LAUNCH_RANGES(EP, RT)                                                                                               \
         do {                                                                                                                \
             if (wpr == 1) hipLaunchKernelGGL((k_sa_ranges<EP, RT, 1>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg);    \
-            else if (wpr == 4) hipLaunchKernelGGL((k_sa_ranges<EP, RT, 4>), dim3(nAr), dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg); \
-            else hipLaunchKernelGGL((k_sa_ranges<EP, RT, 16>), dim3(nAr), dim3(1024), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg);     \
+            else if (wpr == 4) hipLaunchKernelGGL((k_sa_ranges<EP, RT, 4>), dim3(nr), dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg); \
+            else hipLaunchKernelGGL((k_sa_ranges<EP, RT, 16>), dim3(nr), dim3(1024), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg);     \
         } while (0)
         if (uses_ep) { if (rel32) SA_LAUNCH_RANGES(true, uint32_t); else SA_LAUNCH_RANGES(true, uint16_t); }
         else { if (rel32) SA_LAUNCH_RANGES(false, uint32_t); else SA_LAUNCH_RANGES(false, uint16_t); }
 #undef SA_LAUNCH_RANGES
     }
-    if (p.fresh) exclusive_scan_u8(sb.cntP, sb.Pw, (size_t)nW, d_cnt + 2, st);
-    if (!g_is_row) exclusive_scan_u32(sb.cntL, sb.Lw, (size_t)nW, nullptr, st);
-    if (nAr > 4096 && fa_rscan_many(g, nAr, nullptr, d_cnt + 3, nullptr, st)) {
-    } else if (nAr > 4096) {
-        exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
-        exclusive_scan_u32(g.r_nent, g.ebase, (size_t)nAr, g.ebase + nAr, st);
-        IBH_HIP(hipMemcpyAsync(d_cnt + 3, g.gbase + nAr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        IBH_HIP(hipMemcpyAsync(d_cnt + 4, g.ebase + nAr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    // scans over the slice (numberings local to it until the offsets of the ranks are known)
+    if (world == 1) {
+        if (p.fresh) exclusive_scan_u8(sb.cntP, sb.Pw, (size_t)nW, d_cnt + 2, st);
+        if (!g_is_row) exclusive_scan_u32(sb.cntL, sb.Lw, (size_t)nW, d_cnt + 5, st);
     } else {
-        hipLaunchKernelGGL(k_fa_rscan, dim3(1), dim3(1024), 0, st, g.r_ncls, g.r_nent, nAr, g.gbase, g.ebase, d_cnt + 3);
+        if (p.fresh) exclusive_scan_u8(sb.cntP + gW0, sb.Pw + gW0, (size_t)nwl + 1, nullptr, st);
+        if (!g_is_row) exclusive_scan_u32(sb.cntL + gW0, sb.Lw + gW0, (size_t)nwl + 1, nullptr, st);
     }
-    IBH_HIP(hipGetLastError());
-    uint32_t h[8];
-    auto check_counters = [&]() -> bool {
-        readback_sync(h, d_cnt, sizeof(h), st);
-        if (h[0] != 0xffffffffu) {                              // message of linterp_1d_b, IceRegridder_L0.cpp:84-85
-            int32_t ij[2];
-            IBH_HIP(hipMemcpy(ij, gr->ex_indices.p + 2 * (size_t)h[0], sizeof(ij), hipMemcpyDeviceToHost));
-            double e = 0;
-            IBH_HIP(hipMemcpy(&e, rm->elevmaskI.p + ij[1], sizeof(double), hipMemcpyDeviceToHost));
-            fail(IBH_ERANGE, "Elevation %g out of bounds (%g, %g)", e < 0 ? 0.0 : e, gr->hcdefs_h.front(), gr->hcdefs_h.back());
+    {
+        FaG gl = g;
+        gl.r_ncls += sb.sr0; gl.r_nent += sb.sr0; gl.gbase += sb.sr0; gl.ebase += sb.sr0;
+        if (nr > 4096 && fa_rscan_many(gl, nr, nullptr, d_cnt + 3, nullptr, st)) {
+        } else if (nr > 4096) {
+            exclusive_scan_u32(gl.r_ncls, gl.gbase, (size_t)nr, gl.gbase + nr, st);
+            exclusive_scan_u32(gl.r_nent, gl.ebase, (size_t)nr, gl.ebase + nr, st);
+            IBH_HIP(hipMemcpyAsync(d_cnt + 3, gl.gbase + nr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            IBH_HIP(hipMemcpyAsync(d_cnt + 4, gl.ebase + nr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        } else {
+            hipLaunchKernelGGL(k_fa_rscan, dim3(1), dim3(1024), 0, st, gl.r_ncls, gl.r_nent, nr, gl.gbase, gl.ebase, d_cnt + 3);
         }
-        if (h[1]) return false;                                 // a limit of the fast path was hit: general pipeline
-        IBH_CHECK(h[4] < (1u << 31) && h[2] < (1u << 31), "matrix too large for int32 indices");
-        return true;
-    };
-    if (!check_counters()) return false;
-    const uint32_t nnz = h[4];
-    const int np_d = p.fresh ? (int)h[2] : (int)extent_of(pkey);
-    const int ng_d = g_fresh ? (int)h[3] : gset->n;
+    }
+    if (world > 1) hipLaunchKernelGGL(k_sa_slice_counts, dim3(1), dim3(64), 0, st, sb, p.fresh, g_is_row ? 0 : 1, d_cnt);
+    IBH_HIP(hipGetLastError());
+    if (world > 1) comm_exchange_blocks(comm, reinterpret_cast<double *>(d_tot), 4, 4, st);          // exchange 1
+    uint32_t hh[64];
+    readback_sync(hh, d_tot, sizeof(uint32_t) * 8 * (size_t)world, st);
+    uint32_t err_x = 0xffffffffu, fl = 0;
+    std::vector<uint64_t> P0(world + 1, 0), G0(world + 1, 0), E0(world + 1, 0), L0(world + 1, 0);
+    for (int k = 0; k < world; ++k) {
+        const uint32_t *hk = hh + 8 * k;
+        err_x = std::min(err_x, hk[0]); fl |= hk[1];
+        P0[k + 1] = P0[k] + hk[2]; G0[k + 1] = G0[k] + hk[3]; E0[k + 1] = E0[k] + hk[4]; L0[k + 1] = L0[k] + hk[5];
+    }
+    if (err_x != 0xffffffffu) {                                  // message of linterp_1d_b, IceRegridder_L0.cpp:84-85
+        int32_t ij[2];
+        IBH_HIP(hipMemcpy(ij, gr->ex_indices.p + 2 * (size_t)err_x, sizeof(ij), hipMemcpyDeviceToHost));
+        double e = 0;
+        IBH_HIP(hipMemcpy(&e, rm->elevmaskI.p + ij[1], sizeof(double), hipMemcpyDeviceToHost));
+        fail(IBH_ERANGE, "Elevation %g out of bounds (%g, %g)", e < 0 ? 0.0 : e, gr->hcdefs_h.front(), gr->hcdefs_h.back());
+    }
+    if (fl) return false;                                        // a limit of the fast path was hit (on some rank): general pipeline
+    IBH_CHECK(E0[world] < (1u << 31) && P0[world] < (1u << 31), "matrix too large for int32 indices");
+    const uint32_t *hme = hh + 8 * rank;
+    const uint32_t nnz = (uint32_t)E0[world];
+    const int np_d = p.fresh ? (int)P0[world] : (int)extent_of(pkey);
+    const int ng_d = g_fresh ? (int)G0[world] : gset->n;
+    // local -> global numbering of this rank's slice
+    if (world > 1) hipLaunchKernelGGL(k_sa_shift, dim3(ceil_div(std::max<long>(nwl + 1, nr + 1), 256l)), dim3(256), 0, st, p.fresh ? sb.Pw : nullptr, g_is_row ? nullptr : sb.Lw,
+                       gW0, nwl + 1, (uint32_t)(P0[rank] - hme[6]), (uint32_t)(L0[rank] - hme[7]), g.gbase, g.ebase, sb.sr0, nr, (uint32_t)G0[rank], (uint32_t)E0[rank]);
+    if (world > 1) {                                             // exchange 2: what the ranks look up in each other's slices
+        std::vector<int64_t> oc(world + 1), op(world + 1), oe(world + 1), og(world + 1);
+        for (int k = 0; k <= world; ++k) {
+            const long wk = k == world ? nW : (X[k] >> 6);
+            oc[k] = wk * 64; op[k] = wk * 4; oe[k] = (int64_t)R[k] * g.NC; og[k] = (int64_t)R[k] * 4;
+        }
+        void *bases[4] = {sb.code, sb.Pw, g.erank, g.gbase};
+        const int64_t *offs[4] = {oc.data(), op.data(), oe.data(), og.data()};
+        comm_gatherv(comm, 4, bases, offs, st);
+        hipLaunchKernelGGL(k_sa_set_u32, dim3(1), dim3(1), 0, st, g.gbase + nAr, (uint32_t)G0[world]);
+    }
     DevBuf<int64_t> ptable, gtable;
     if (p.fresh) { ptable.alloc((size_t)np_d); p.to_sparse = ptable.p; }
     if (g_fresh) { gtable.alloc((size_t)ng_d); g.to_sparse = gtable.p; }
@@ -780,14 +895,19 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     FaOut o{w->rowptr.p, w->colind.p, w->val.p, w->wM.p, w->Mw.p, sp->family, scale, correctA, 0};
     uint32_t *flags = d_cnt + 1;
     // row kernel: a wave per (range, class); y = the classes a range has on average, rounded up, + 1 (the others loop)
-    const dim3 grq(ceil_div(nAr, 4), g.NC == 1 ? 1 : std::max(1, std::min(std::min(g.NC, 16), (int)(h[3] / (uint32_t)std::max(nAr, 1)) + 2)));
+    const dim3 grq(ceil_div(nr, 4), g.NC == 1 ? 1 : std::max(1, std::min(std::min(g.NC, 16), (int)(hme[3] / (uint32_t)std::max(nr, 1)) + 2)));
     double *sval = nullptr;
     int32_t *sdid = nullptr;
+    const int ecpt = get_tuning("assemble_stream_emit_cpt", 2);      // cells per thread of the emit pass (measured: 4 / 2 / 1 -> a1h EvI 1.34 / 1.27 / 1.28 ms)
+    const long ncell = sb.gx1 - sb.gx0;
 #define SA_LAUNCH_EMIT(EP, GR)                                                                                                  \
     do {                                                                                                                        \
-        if (rel32) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint32_t>), gs, dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
-        else hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t>), gs, dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid);       \
+        if (rel32) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint32_t, 4>), gs, dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
+        else if (ecpt == 2) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 2>), dim3(ceil_div(ncell, (long)SA_T * 2)), dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
+        else if (ecpt == 1) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 1>), dim3(ceil_div(ncell, (long)SA_T)), dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
+        else hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 4>), gs, dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid);       \
     } while (0)
+    sb.end_row = nrow; sb.end_nnz = nnz;
     if (g_is_row) {
         if (ncol && !p.fresh) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
         if (uses_ep) SA_LAUNCH_EMIT(true, true); else SA_LAUNCH_EMIT(false, true);
@@ -801,11 +921,10 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
             if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
             else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
         }
-        if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_S>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr);
-        else hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_L>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr);
+        if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_S>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
+        else hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_L>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
     } else {
         sval = A.get<double>(nnz); sdid = A.get<int32_t>(nnz);
-        IBH_HIP(hipMemcpyAsync(w->rowptr.p + nrow, d_cnt + 4, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         if (uses_ep) SA_LAUNCH_EMIT(true, false); else SA_LAUNCH_EMIT(false, false);
         if (p.key == KEY_I && P.npair) {                      // the rows of the ice cells across one GCM-cell edge
             const dim3 gp2(ceil_div(P.npair, 256));
@@ -825,11 +944,23 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         if (!g_fresh && ncol) hipLaunchKernelGGL(k_fa_zero_identity, dim3(ceil_div(ncol, T)), dim3(T), 0, st, w->Mw.p, (long)ncol);
         FaOut os = o;
         os.val = sval;
-        if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_S>), grq, dim3(256), 0, st, rg, pl, g, os, sdid);
-        else hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_L>), grq, dim3(256), 0, st, rg, pl, g, os, sdid);
+        if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_S>), grq, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
+        else hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_L>), grq, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
     }
 #undef SA_LAUNCH_EMIT
     IBH_HIP(hipGetLastError());
+    if (world > 1) {                                             // exchange 3: the pieces of the result
+        // A/E-row matrix: CSR by entries of the ranges, rows by classes; I/X-row matrix: CSR by row entries, rows by P keys
+        const std::vector<uint64_t> &En = g_is_row ? E0 : L0, &Rw = g_is_row ? G0 : P0, &Cl = g_is_row ? P0 : G0;
+        std::vector<int64_t> o4e(world + 1), o8e(world + 1), o4r(world + 1), o8r(world + 1), o8c(world + 1);
+        for (int k = 0; k <= world; ++k) {
+            o4e[k] = (int64_t)En[k] * 4; o8e[k] = (int64_t)En[k] * 8; o4r[k] = (int64_t)Rw[k] * 4; o8r[k] = (int64_t)Rw[k] * 8; o8c[k] = (int64_t)Cl[k] * 8;
+        }
+        void *bases[7] = {w->colind.p, w->val.p, w->rowptr.p, w->wM.p, w->Mw.p, g_is_row ? (void *)gtable.p : (void *)ptable.p,
+                          g_is_row ? (void *)ptable.p : (void *)gtable.p};
+        const int64_t *offs[7] = {o4e.data(), o8e.data(), o4r.data(), o8r.data(), o8c.data(), o8r.data(), o8c.data()};
+        comm_gatherv(comm, 7, bases, offs, st);
+    }
     auto commit = [&](ibh_sparse_set *set, int64_t extent, DevBuf<int64_t> &table, int n) {
         set->sparse_extent = extent;
         if (n == 0) return;
@@ -841,7 +972,7 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     if (p.fresh) commit(pset, extent_of(pkey), ptable, np_d); else if (pset->sparse_extent != extent_of(pkey)) pset->sparse_extent = extent_of(pkey);
     if (g_fresh) commit(gset, gext, gtable, ng_d); else if (gset->sparse_extent != gext) gset->sparse_extent = gext;
     IBH_HIP(hipStreamSynchronize(st));
-    w->built_fast = 2;
+    w->built_fast = world > 1 ? 3 : 2;
     // (flags raised by the later kernels -- a straddler list that overflowed -- cannot differ from the count pass's; checked there)
     return true;
 }

@@ -301,15 +301,16 @@ class Communicator:
     backend: it only carries 128 bytes); a C++ host would use its own channel (ModelE: MPI_Bcast).  world == 1 needs nothing.
     `exchange` (a Python callable, tests only) replaces RCCL by a custom transport (ibh_comm_create_custom)."""
 
-    def __init__(self, world=1, rank=0, bootstrap=None, exchange=None, rccl=None):
+    def __init__(self, world=1, rank=0, bootstrap=None, exchange=None, rccl=None, gatherv=None):
         """rccl: None = only when world > 1; True = also at world 1 (a one-rank RCCL communicator: exercises the library's
-        RCCL binding on a single GPU)."""
+        RCCL binding on a single GPU).  gatherv (custom transports, tests): callable(d_base, offsets, world, rank, stream) for
+        pieces of unequal size -- offsets is a list of world + 1 byte offsets (ibh_comm_set_custom_gatherv: the sharded assembly)."""
         import ctypes as C
         from . import _capi
         self._capi, self._C = _capi, C
         L = _capi.lib()
         h = C.c_void_p()
-        self._cb = None
+        self._cb = self._cbv = None
         if exchange is not None:
             proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p)
 
@@ -323,6 +324,19 @@ class Communicator:
                     return 1
             self._cb = proto(_cb)
             _capi.check(L.ibh_comm_create_custom(world, rank, C.cast(self._cb, C.c_void_p), None, C.byref(h)))
+            if gatherv is not None:
+                proto_v = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_void_p)
+
+                def _cbv(user, d_base, offs, w, r, stream):
+                    try:
+                        gatherv(d_base, [int(offs[k]) for k in range(w + 1)], w, r, stream)
+                        return 0
+                    except Exception:      # noqa: BLE001 -- must not unwind through the C frame
+                        import traceback
+                        traceback.print_exc()
+                        return 1
+                self._cbv = proto_v(_cbv)
+                _capi.check(L.ibh_comm_set_custom_gatherv(h, C.cast(self._cbv, C.c_void_p)))
         elif world == 1 and not rccl:
             _capi.check(L.ibh_comm_create(1, 0, None, C.byref(h)))
         else:

@@ -370,7 +370,13 @@ class linear_Weighted:
         """True when the streamed variant of the plan-based assembly (streamasm.inl: large sorted grids) built this matrix."""
         v = C.c_int()
         check(lib().ibh_weighted_built_fast(self._h, C.byref(v)))
-        return v.value == 2
+        return v.value in (2, 3)
+
+    def built_sharded(self):
+        """True when the ranks of a communicator shared the assembly of this matrix (ibh_regrid_matrices_matrix_d_sharded)."""
+        v = C.c_int()
+        check(lib().ibh_weighted_built_fast(self._h, C.byref(v)))
+        return v.value == 3
 
     def last_kernel(self):
         buf = C.create_string_buffer(32)

@@ -44,6 +44,16 @@ class RegridMatrices:
         return linear_Weighted(h, keep=(self, dims))
 
 
+    def matrix_d_sharded(self, comm, spec_name, dims=(None, None), scale=True, correctA=False):
+        """ibh_regrid_matrices_matrix_d_sharded: matrix_d with the assembly shared by the ranks of `comm`
+        (icebin_amd.distributed.Communicator).  Collective -- every rank makes the same call -- and every rank receives the whole
+        matrix, bitwise what matrix_d builds."""
+        h = C.c_void_p()
+        d0 = dims[0]._h if dims[0] is not None else None
+        d1 = dims[1]._h if dims[1] is not None else None
+        check(lib().ibh_regrid_matrices_matrix_d_sharded(self._h, comm._h, spec_name.encode(), d0, d1, int(scale), int(correctA), C.byref(h)))
+        return linear_Weighted(h, keep=(self, dims))
+
     def matrix_batch(self, jobs, sigma=None):
         """The matrices of one coupling step in one call (IceCoupler.cpp:361-468): jobs is a list of
         (spec_name, (dim0, dim1), scale, correctA) -- dims as in matrix_d -- and the results are those of the

@@ -310,6 +310,11 @@ typedef int (*ibh_exchange_fn)(void *user, double *d_base, int64_t count, int64_
 int ibh_comm_unique_id(char id[IBH_UNIQUE_ID_BYTES]);
 int ibh_comm_create(int world, int rank, const char id[IBH_UNIQUE_ID_BYTES], ibh_comm **out);
 int ibh_comm_create_custom(int world, int rank, ibh_exchange_fn fn, void *user, ibh_comm **out);
+/* A custom transport that also carries pieces of UNEQUAL size (the sharded assembly, ibh_regrid_matrices_matrix_d_sharded):
+ * fn(user, d_base, offsets[world + 1] (bytes), world, rank, stream) must deliver every rank q's bytes
+ * [offsets[q], offsets[q+1]) of d_base to the same place on every peer, ordered on `stream`; 0 = success. */
+typedef int (*ibh_gatherv_fn)(void *user, void *d_base, const int64_t *offsets, int world, int rank, void *stream);
+int ibh_comm_set_custom_gatherv(ibh_comm *c, ibh_gatherv_fn fn);
 int ibh_comm_destroy(ibh_comm *c);
 int ibh_comm_info(const ibh_comm *c, int *world, int *rank);
 /* Weighted::apply of world*nvar_local fields, sharded by field: dB_all [world*nvar_local x ldb] (device, the same
@@ -336,6 +341,18 @@ int ibh_weighted_apply_many_sharded_device(const ibh_weighted *w, ibh_comm *c, i
                                            int32_t nvar_local, int64_t lda, double *const *dB_all, int64_t ldb, double fill,
                                            void *stream);
 int ibh_comm_wait(ibh_comm *c, void *stream);
+/* RegridMatrices_Dynamic::matrix_d with the ASSEMBLY shared by the ranks of a communicator (BASELINE.json config 5: "overlap
+ * COO->CSR assembly + apply, 8 x MI355X"; the reference rebuilds its matrices every coupling step, IceCoupler.cpp:361-468, on one
+ * core).  Collective: every rank calls it with the same arguments on the same regridder / elevation mask and receives the WHOLE
+ * matrix -- bitwise the result of ibh_regrid_matrices_matrix_d.  The exchange grid is sorted by atmosphere cell
+ * (AbbrGrid.cpp:10-21), so rank k runs the streamed passes over a contiguous block of ranges holding ~1/world of the exchange
+ * cells; three exchanges on the caller's thread stream (counters; the first-seen flags and class ranks the ranks look up in each
+ * other's blocks, ~1 byte per exchange cell; the pieces of the CSR / weights / dims tables) complete it.  Served this way: the
+ * eight A/E/I/X matrices on sets numbered by the build (dims NULL or empty), sorted grids, at most 8 ranks; anything else is
+ * built redundantly on every rank (same result).  ibh_weighted_built_fast reports 3 for a shared build.  A custom transport needs
+ * ibh_comm_set_custom_gatherv. */
+int ibh_regrid_matrices_matrix_d_sharded(const ibh_regrid_matrices *rm, ibh_comm *c, const char *spec, ibh_sparse_set *dim0,
+                                         ibh_sparse_set *dim1, int scale, int correctA, ibh_weighted **out);
 
 /* Device pointers of the CSR and weights, for callers that keep fields resident
  * (IceCoupler.cpp:408,445,456 read ->M and ->wM directly). */
@@ -348,7 +365,8 @@ int ibh_weighted_device_view_get(const ibh_weighted *w, ibh_weighted_device_view
 /* Tuning / introspection (not part of the reference interface). */
 int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow", "rowdual", "colsweep", "rowgroup" */
 int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
-/* 1 when the matrix was assembled by the plan-based fast path for sorted exchange grids (fastasm.inl), 2 when its streamed
+/* 1 when the matrix was assembled by the plan-based fast path for sorted exchange grids (fastasm.inl), 3 when the ranks of a
+ * communicator shared the streamed build (ibh_regrid_matrices_matrix_d_sharded), 2 when its streamed
  * variant did (streamasm.inl: grids of 2^20 exchange cells and more; ibh_set_tuning("assemble_stream", 0 | 1) overrides),
  * 0 when the general pipeline built it (ibh_set_tuning("assemble_fast", 0) forces the latter).  Results are bit-identical. */
 int ibh_weighted_built_fast(const ibh_weighted *w, int *out);

@@ -365,3 +365,130 @@ def test_sharded_apply_two_ranks_over_a_custom_transport():
     assert all(ok for _, ok, _ in got), got
     # one exchange per field block: 6 fields in one, 6 in blocks of 4, 5 in blocks of 2, 8 in one
     assert got[0][2] == [1, 2, 3, 1, 3] and got[1][2] == [1, 2, 3, 1, 3], got
+
+
+# ---- the sharded ASSEMBLY behind the C-ABI (ibh_regrid_matrices_matrix_d_sharded; SURVEY.md 8e "Assembly (cfg 5)") -------------------
+def _hip_runtime():
+    import ctypes as C
+    rt = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    rt.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    rt.hipStreamSynchronize.argtypes = [C.c_void_p]
+    return rt
+
+
+def _worker_asm_sharded(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import icebin_amd
+        from icebin_amd import _capi, synthetic as syn
+        from icebin_amd.distributed import Communicator
+        torch.cuda.set_device(0)                        # the ranks share the box's one card: the transport is host-staged
+        hip = _hip_runtime()
+        stage = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+        calls = {"blocks": 0, "gatherv": 0, "bytes": 0}
+
+        def move(d_base, pieces, r_, stream):
+            """pieces[k] = (byte offset, length) of rank k's piece of the array at d_base: every rank ends up with all of them"""
+            maxn = max(n for _, n in pieces)
+            off, n = pieces[r_]
+            assert maxn * (len(pieces) + 1) <= stage.numel()
+            mine = stage[:maxn]
+            if n:
+                assert hip.hipMemcpyAsync(mine.data_ptr(), d_base + off, n, 2, stream) == 0
+            assert hip.hipStreamSynchronize(stream) == 0
+            parts = [torch.empty(maxn, dtype=torch.uint8) for _ in pieces]
+            dist.all_gather(parts, mine.clone())
+            for k, (offk, nk) in enumerate(pieces):
+                if k != r_ and nk:
+                    dst = stage[(k + 1) * maxn:(k + 1) * maxn + nk]
+                    dst.copy_(parts[k][:nk])
+                    assert hip.hipMemcpyAsync(d_base + offk, dst.data_ptr(), nk, 1, stream) == 0
+            assert hip.hipStreamSynchronize(stream) == 0
+            calls["bytes"] += sum(nk for _, nk in pieces)
+
+        def exchange(d_base, count, stride, w_, r_, stream):
+            calls["blocks"] += 1
+            move(d_base, [(8 * k * stride, 8 * count) for k in range(w_)], r_, stream)
+
+        def gatherv(d_base, offs, w_, r_, stream):
+            calls["gatherv"] += 1
+            move(d_base, [(offs[k], offs[k + 1] - offs[k]) for k in range(w_)], r_, stream)
+
+        comm = Communicator(world, rank, exchange=exchange, gatherv=gatherv)
+        ok, notes = True, []
+
+        def same(a, b, what):
+            nonlocal ok
+            good = (a.nrow_d, a.ncol_d, a.nnz) == (b.nrow_d, b.ncol_d, b.nnz)
+            if good:
+                for x, y in zip(a.csr_dense() + (a.wM, a.Mw, a.dim(0), a.dim(1)), b.csr_dense() + (b.wM, b.Mw, b.dim(0), b.dim(1))):
+                    x = x.view(np.uint64) if x.dtype == np.float64 else x
+                    y = y.view(np.uint64) if y.dtype == np.float64 else y
+                    good = good and bool(np.array_equal(x, y))
+            if not good:
+                notes.append(what)
+            ok = ok and good
+
+        for config in ("g5", "g20"):
+            g = syn.make_grids(config)
+            em = syn.dome_elevmask(g)
+            mm = icebin_amd.from_synthetic(g)
+            for scale, correctA in ((True, True), (False, False)):
+                rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
+                for name in ("AvI", "EvI", "IvA", "IvE", "AvX", "EvX", "XvA", "XvE"):
+                    n0 = calls["gatherv"]
+                    ws = rm.matrix_d_sharded(comm, name, scale=scale, correctA=correctA)
+                    w1 = rm.matrix_d(name, scale=scale, correctA=correctA)
+                    if not ws.built_sharded() or calls["gatherv"] - n0 != 4 + 7:     # (exchange 2: four arrays, exchange 3: seven)
+                        ok = False
+                        notes.append("%s %s not shared (%d gathers)" % (config, name, calls["gatherv"] - n0))
+                    same(ws, w1, "%s %s scale=%d correctA=%d" % (config, name, scale, correctA))
+            rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+            # not served by the shared build: built redundantly by every rank, same result (EvA: another pipeline; an identity set)
+            ws, w1 = rm.matrix_d_sharded(comm, "EvA"), rm.matrix_d("EvA")
+            ok = ok and not ws.built_sharded()
+            same(ws, w1, config + " EvA")
+            ident = [icebin_amd.SparseSet.identity(g["nI"]) for _ in range(2)]
+            ws, w1 = rm.matrix_d_sharded(comm, "AvI", (None, ident[0])), rm.matrix_d("AvI", (None, ident[1]))
+            ok = ok and not ws.built_sharded()
+            same(ws, w1, config + " AvI identity dimI")
+        # an elevation above the last class: every rank raises the reference's error, whichever rank's block holds the cell
+        g = syn.make_grids("g20")
+        em = syn.dome_elevmask(g)
+        em[np.flatnonzero(np.isfinite(em))[-3]] = 1e5
+        rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em)
+        try:
+            rm.matrix_d_sharded(comm, "EvI")
+            ok = False
+            notes.append("no range error")
+        except _capi.IcebinHipError as e:
+            ok = ok and e.code == _capi.IBH_ERANGE and "out of bounds" in str(e)
+        q.put((rank, ok, notes, dict(calls)))
+        torch.cuda.synchronize()
+        del comm
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_assembly_is_the_single_rank_build_bitwise(world):
+    """ibh_regrid_matrices_matrix_d_sharded with 2 and 3 ranks (processes sharing the box's GPU, a host-staged gloo transport for
+    the equal blocks and for the pieces of unequal size): every rank's matrix -- dims, CSR, wM, Mw -- is bitwise the single-rank
+    build for the eight matrices the shared build serves, at 5 km (ranges of ~1 500 cells, ice cells straddling the ranks' blocks)
+    and 20 km; builds it does not serve come out redundantly and equal; an out-of-range elevation raises on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_asm_sharded, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert all(ok for _, ok, _, _ in got), got
+    assert all(c["gatherv"] > 0 and c["blocks"] > 0 for _, _, _, c in got), got
