@@ -447,7 +447,8 @@ def main():
             par = ("field-shard x%d (%s: %d fields/rank) + all-gather every %d steps" %
                    (world, "strong" if strong else "weak", nf, gsteps))
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, W.last_kernel(), depth, per),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, W.last_kernel(), depth, per, W.last_launch()),
+                "launched": W.last_launch(),
                 "kernel_us": kernel_us, "algorithmic_bytes": B,
                 "launches": nlaunch, "steps_per_launch": per, "launch_us": launch_us,
                 "statistic": "median over %d launches (%d repetitions of the timed region x %d launches)" % (len(full_ms), R, nlaunch) if have_k
@@ -456,7 +457,7 @@ def main():
                 "timing": "HIP events attached to each SpMM dispatch of the timed regions (kernel start -> end)" if have_k else "HIP events around the timed region on the launch stream",
                 "region_us_per_step": region_ms * 1e3 / max(args.steps, 1),
                 "algorithmic_bytes_per_launch": B_launch,
-                "traffic_source": "profiles/*_pmc_traffic.json: separate rocprofv3 --pmc passes of this command, per launch; not measured in this run"}
+                "traffic_source": "profiles/*_pmc_traffic.json: separate rocprofv3 --pmc passes of this command, per launch; not measured in this run; null when that profile was taken on another kernel instantiation than `launched`"}
         if have_k:
             roof.update({"launch_us_min": min(full_ms) * 1e3, "launch_us_max": max(full_ms) * 1e3, "launch_samples": len(full_ms),
                          "kernel_us_min": min(per_apply_us), "kernel_us_max": max(per_apply_us),
@@ -623,7 +624,7 @@ def variant_all_unmasked(torch, icebin_amd, _capi, syn, grids, args, dev, steps=
             "achieved_GBps": B / us / 1e3, "frac": B / us / 1e3 / HBM_PEAK_GBS, "cells_per_s": ncol * nf / us * 1e6}
 
 
-def pmc_traffic(args, kernel, depth, applies_per_launch):
+def pmc_traffic(args, kernel, depth, applies_per_launch, launched=None):
     """HBM bytes per LAUNCH of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of this very command,
     FETCH doubled per the gfx950 correction), scaled from the profiled launch (32 applies) to this
@@ -636,6 +637,9 @@ def pmc_traffic(args, kernel, depth, applies_per_launch):
         except (OSError, ValueError):
             continue
         if key in d and not args.warm:
+            # the profile is quoted only for the kernel instantiation it was taken on (a retuned launch makes it stale: null then)
+            if launched and d[key].get("kernel") and d[key]["kernel"] != launched:
+                return None
             return d[key]["traffic_bytes"] / d[key].get("applies_per_launch", 1) * applies_per_launch
     return None
 

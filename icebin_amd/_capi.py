@@ -125,6 +125,8 @@ _SIGS = {
     "ibh_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "ibh_set_launch_events": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ibh_weighted_built_fast": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "ibh_weighted_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "ibh_weighted_last_launch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "ibh_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "ibh_release_cached_memory": (C.c_int, []),
     "ibh_selftest_sort": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),

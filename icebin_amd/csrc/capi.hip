@@ -660,6 +660,19 @@ int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen) {
         snprintf(buf, (size_t)buflen, "%s", w->last_kernel == 1 ? "rowblock" : w->last_kernel == 2 ? "shortrow" : w->last_kernel == 3 ? "rowdual" : w->last_kernel == 4 ? "colsweep" : w->last_kernel == 5 ? "rowgroup" : "none");
     });
 }
+int ibh_weighted_last_launch(const ibh_weighted *w, char *buf, int buflen) {
+    return guarded([&] {
+        IBH_CHECK(w && buf && buflen > 0, "bad arguments");
+        snprintf(buf, (size_t)buflen, "%s", w->last_sig);
+    });
+}
+int ibh_weighted_set_option(ibh_weighted *w, const char *key, int value) {
+    return guarded([&] {
+        IBH_CHECK(w && key, "null argument");
+        if (value == INT32_MIN) w->opts.erase(key);
+        else w->opts[key] = value;
+    });
+}
 int ibh_weighted_built_fast(const ibh_weighted *w, int *out) {
     return guarded([&] { IBH_CHECK(w && out, "null argument"); *out = w->built_fast; });
 }

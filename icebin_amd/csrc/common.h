@@ -232,6 +232,10 @@ struct ibh_weighted {
     int built_fast = 0;                 // assembled by the plan-based fast path (fastasm.inl); introspection only
     // SpMM dispatch
     int kernel_override = 0;            // 0 auto, 1 rowblock, 2 shortrow, 3 rowdual
+    mutable char last_sig[64] = {0};    // the kernel instantiation the last apply launched, as rocprofv3 names it (rowblock / rowone; else the kernel family)
+    // per-handle launch options (ibh_weighted_set_option): looked up before the process-wide ibh_set_tuning map by every apply of
+    // THIS matrix, so two host threads tuning different handles do not interfere
+    mutable std::unordered_map<std::string, int> opts;
     mutable int last_kernel = 0;
     // apply_transformed: scratch fields + small transform, and M*1 (row sums) for the offset term
     mutable ibh::DevBuf<double> scratch, tbuf, rowsum1;

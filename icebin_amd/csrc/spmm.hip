@@ -41,7 +41,18 @@ struct Tuning {
 };
 Tuning &tuning() { static Tuning *t = new Tuning; return *t; }
 }  // namespace
+// the matrix whose apply is being set up on this thread: its own options (ibh_weighted_set_option) win over the process-wide map
+static thread_local const ibh_weighted *tl_handle = nullptr;
+struct HandleScope {
+    const ibh_weighted *prev;
+    explicit HandleScope(const ibh_weighted *w) : prev(tl_handle) { tl_handle = w; }
+    ~HandleScope() { tl_handle = prev; }
+};
 int get_tuning(const char *key, int dflt) {
+    if (tl_handle && !tl_handle->opts.empty()) {
+        auto it = tl_handle->opts.find(key);
+        if (it != tl_handle->opts.end()) return it->second;
+    }
     Tuning &t = tuning();
     std::lock_guard<std::mutex> lk(t.mu);
     if (t.map.empty()) return dflt;
@@ -925,9 +936,12 @@ static void launch_rowblock(const ibh_weighted *w, const BatchPtrs &bp, int nbat
     hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
 #define IBH_RB(U)                                                                                        \
-    hipExtLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U, NW>), grid, dim3(NW * 64), 0, stream, ev0, ev1, 0,  \
-                          w->rowptr.p, w->colind.p, w->val.p, bp, nbatch, qi, lda, w->ncol, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill, \
-                          (const double *)nullptr, (double *)nullptr, (const int *)rowperm, 0l)
+    do {                                                                                                 \
+        snprintf(w->last_sig, sizeof(w->last_sig), "spmm_rowblock_kernel<%d, %d, %d, %d, false>", FPW, WK, (int)(U), NW);  \
+        hipExtLaunchKernelGGL((spmm_rowblock_kernel<FPW, WK, U, NW>), grid, dim3(NW * 64), 0, stream, ev0, ev1, 0,  \
+                              w->rowptr.p, w->colind.p, w->val.p, bp, nbatch, qi, lda, w->ncol, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill, \
+                              (const double *)nullptr, (double *)nullptr, (const int *)rowperm, 0l);     \
+    } while (0)
     if (unroll == 1) IBH_RB(1);
     else if (unroll == 2) IBH_RB(2);
     else if (unroll == 8) IBH_RB(8);
@@ -950,6 +964,7 @@ static void launch_rowone(const ibh_weighted *w, const double *X, double *Y, int
     IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
     hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
+    snprintf(w->last_sig, sizeof(w->last_sig), "spmm_rowone_kernel<%d, %d>", NW, U);
     hipExtLaunchKernelGGL((spmm_rowone_kernel<NW, U>), dim3((unsigned)nb), dim3(NW * 64), 0, stream, ev0, ev1, 0, w->rowptr.p, w->colind.p,
                           w->val.p, X, Y, lda, w->ncol, ldb, w->nrow, nvar, nfc, xcd_mode, w->wM.p, fill);
     IBH_HIP(hipGetLastError());
@@ -1139,8 +1154,11 @@ static int pick_kernel(const ibh_weighted *w, int nvar, int nbatch = 1) {
     // launch: 51 against 63 us per apply).  The other long-row matrices (AvI, AvX) take the sweep in batched launches only
     // (1 km, 64 fields: 167 against 173 us per apply 32 deep, but 193 against 183 us one launch per apply).
     if (kernel == 1 && w->kernel_override == 0) {
+        // (round 4, the Antarctic sheet -- 17.6 / 35.2 M entries -- one apply per launch: AvI, 128 fields, sweep 3 131 against 3 654 us;
+        // EvI, 16 fields, row groups 641 against 812 (bands) / 747 (rows) / 1 994 us (sweep): scratch/kernel_choice.py)
+        const bool huge = w->nnz >= (1l << 24);
         const bool sweep_ok = w->sweep_ntask > 0 && sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
-                              (w->band_eligible || nbatch >= get_tuning("sweep_min_batch", 4));
+                              (w->band_eligible || nbatch >= get_tuning("sweep_min_batch", 4) || (huge && nvar >= 128));
         const bool grp_ok = w->grp_n > 0 && nvar >= 4 && get_tuning("rowgroup_auto", 1);
         if (grp_ok && (nvar >= 32 || !sweep_ok)) kernel = 5;
         else if (sweep_ok) kernel = 4;
@@ -1168,9 +1186,12 @@ static ShortrowPlan shortrow_plan(const ibh_weighted *w, int nvar, int nbatch = 
     // field-major with 4 fields per thread -- 64 fields 13.2 us against 15.8 through the transposed copy, whose second
     // launch costs more than its lines save; 16 fields 5.6 against 6.8; deep launches keep the transposed form: 7.0)
     const int small_one = w->nrow >= 16384 ? (nbatch >= 4 ? 8 : nvar >= 64 ? 16 : 4) : 4;
-    p.fper = get_tuning("shortrow_fper", p.big ? (p.one_entry ? 16 : 32) : (p.one_entry ? small_one : small_multi));
+    // (round 4, the Antarctic sheet -- 17.2 M one-entry rows, results of 2.2 / 17.6 GB: groups of 4 fields and, from ~100 fields on,
+    // 32 fields per thread: 16 fields 579 -> 546 us, 128 fields 4 761 -> 3 829 us = 0.45 -> 0.56 of 8 TB/s; scratch/tune_shortrow.py)
+    const bool huge = w->nrow >= (1 << 23);
+    p.fper = get_tuning("shortrow_fper", p.big ? (p.one_entry ? (huge && nvar >= 96 ? 32 : 16) : 32) : (p.one_entry ? small_one : small_multi));
     if (p.fper < 1) p.fper = 1;
-    p.g = get_tuning("shortrow_group", p.big ? (p.one_entry ? 8 : 4) : (p.fper >= 8 ? 8 : 4));
+    p.g = get_tuning("shortrow_group", p.big ? (p.one_entry ? (huge ? 4 : 8) : 4) : (p.fper >= 8 ? 8 : 4));
     if (p.g > p.fper) p.g = p.fper;
     // transposed input: the G fields of an entry are 8*G contiguous bytes per lane (one line per entry instead of one per
     // field): 5 km IvE 26.9 -> 18.5 us, 1 km IvE 302 -> 183 us, 1 km IvA 207 -> 176 us, 5 km IvA 13.2 -> 12.1 us
@@ -1192,7 +1213,8 @@ static bool wants_sweep(const ibh_weighted *w, int nvar, int nbatch, bool seen) 
     if (w->kernel_override == 4) return true;
     const bool long_rows = w->nrow > 0 && (double)w->nnz / (double)w->nrow >= 64.0 && w->nnz <= 2 * (int64_t)w->ncol;      // AvI, AvX
     const bool e_rows = w->band_eligible && (nvar < 32 || (w->grp_tried && w->grp_n == 0) || !get_tuning("rowgroup_auto", 1));
-    return (e_rows || (long_rows && nbatch >= get_tuning("sweep_min_batch", 4))) && w->kernel_override == 0 && seen &&
+    const bool huge_wide = w->nnz >= (1l << 24) && nvar >= 128;      // (one launch of >= 128 fields on the Antarctic AvI: see launch_kernel_for)
+    return (e_rows || (long_rows && (nbatch >= get_tuning("sweep_min_batch", 4) || huge_wide))) && w->kernel_override == 0 && seen &&
            sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
            (double)w->nnz * sweep_lanes(nvar, nbatch) >= (double)get_tuning("sweep_min_work", 64 << 20);
 }
@@ -1213,7 +1235,9 @@ static bool wants_groups(const ibh_weighted *w, int nvar, int nbatch, long seen)
     if (!w->band_eligible || w->grp_tried || w->grp_n > 0) return false;
     if (w->kernel_override == 5) return true;
     if (w->kernel_override != 0 || nvar < 4 || !get_tuning("rowgroup_auto", 1)) return false;
-    if (sweep_sized(w, nvar, nbatch)) return nvar >= 32 && seen >= 1;
+    // (bandwidth-sized matrices: from 32 fields -- fewer fields per launch share the lanes of the column sweep when launches are
+    // batched; a single launch of a 2^24-entry matrix takes the groups from 4 fields on)
+    if (sweep_sized(w, nvar, nbatch)) return (nvar >= 32 || (nbatch < 4 && w->nnz >= (1l << 24))) && seen >= 1;
     return seen >= get_tuning("rowgroup_after", 1 << 30);
 }
 static void drop_groups(const ibh_weighted *w) {
@@ -1277,11 +1301,13 @@ static void size_scratch(const ibh_weighted *w, int nvar, int nbatch) {
 }
 
 void weighted_reserve(const ibh_weighted *w, int nvar) {
+    HandleScope hs_(w);
     if (nvar <= 0) return;
     size_scratch(w, nvar, 1);
 }
 
 void weighted_prepare(const ibh_weighted *w, int nvar, int nbatch) {
+    HandleScope hs_(w);
     if (nvar <= 0 || nbatch <= 0 || w->nrow == 0) return;
     const int nb = std::min(nbatch, IBH_MAX_BATCH);           // deeper batches are split into launches of IBH_MAX_BATCH
     build_structures(w, nvar, nb, true, nullptr);
@@ -1295,6 +1321,7 @@ void weighted_prepare(const ibh_weighted *w, int nvar, int nbatch) {
 // it has its class sums.  The pairing is worked out on the host (the second matrix is tiny: one entry per class) through the
 // SPARSE indices of the two matrices' shared dimension, so the two need not share a SparseSet object or a numbering.
 void weighted_pair_prepare(const ibh_weighted *first, const ibh_weighted *second, int nvar) {
+    HandleScope hs_(first);
     IBH_CHECK(first && second && first != second, "pair: two different matrices expected");
     IBH_CHECK(first->device == second->device, "pair: matrices live on different devices");
     IBH_CHECK(second->ncol == first->nrow || second->dims[1], "pair: the second matrix's columns are not the first one's rows");
@@ -1369,6 +1396,7 @@ void weighted_pair_prepare(const ibh_weighted *first, const ibh_weighted *second
 void spmm_launch_pair(const ibh_weighted *first, const ibh_weighted *second, const double *dA, int nvar, int64_t lda, double *dB1,
                       int64_t ldb1, double *dB2, int64_t ldb2, double fill, hipStream_t stream)
 {
+    HandleScope hs_(first);
     IBH_CHECK(first->pair_second == second && first->pair_uid == second->uid && first->grp_n > 0,
               "pair apply: call ibh_weighted_pair_prepare(first, second, nvar) first");
     if (nvar <= 0 || first->nrow == 0) return;
@@ -1532,6 +1560,7 @@ static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &
 void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA, int nvar, int64_t lda,
                       double *const *dB, int64_t ldb, double fill, int force_conservation, hipStream_t stream)
 {
+    HandleScope hs_(w);
     if (nvar <= 0 || w->nrow == 0 || nbatch <= 0) return;
     IBH_CHECK(lda >= w->ncol && ldb >= w->nrow, "apply: leading dimensions (%ld, %ld) smaller than (%d, %d)",
               (long)lda, (long)ldb, w->ncol, w->nrow);
@@ -1548,6 +1577,7 @@ void spmm_launch_many(const ibh_weighted *w, int nbatch, const double *const *dA
     // the column sweep addresses a wave's 16 field planes through one buffer descriptor (32-bit offsets)
     if (kernel == 4 && ((uint64_t)16 * (uint64_t)lda * 8 + (uint64_t)w->ncol * 8 >= (1ull << 32))) kernel = w->band_n > 0 ? 3 : 1;
     w->last_kernel = kernel;
+    w->last_sig[0] = 0;
     const bool correct = !w->conservative && force_conservation;
     if (correct) grow_scratch(w->consv, 2 * (size_t)nvar + weight_dot_scratch(std::max(w->nrow, w->ncol), nvar), stream, "conservation");
     for (int b0 = 0; b0 < nbatch; b0 += IBH_MAX_BATCH) {

@@ -360,6 +360,11 @@ class linear_Weighted:
     def set_kernel(self, name):
         check(lib().ibh_weighted_set_kernel(self._h, name.encode()))
 
+    def set_option(self, key, value):
+        """ibh_weighted_set_option: a launch option of THIS matrix (the apply-side ibh_set_tuning keys), read before the
+        process-wide map; value None removes it."""
+        check(lib().ibh_weighted_set_option(self._h, key.encode(), -2 ** 31 if value is None else int(value)))
+
     def built_fast(self):
         """True when the plan-based fast assembly path built this matrix (sorted exchange grids)."""
         v = C.c_int()
@@ -381,6 +386,12 @@ class linear_Weighted:
     def last_kernel(self):
         buf = C.create_string_buffer(32)
         check(lib().ibh_weighted_last_kernel(self._h, buf, 32))
+        return buf.value.decode()
+
+    def last_launch(self):
+        """The kernel instantiation of the last apply as rocprofv3 names it ("" when the kernel family does not record it)."""
+        buf = C.create_string_buffer(64)
+        check(lib().ibh_weighted_last_launch(self._h, buf, 64))
         return buf.value.decode()
 
 

@@ -365,12 +365,22 @@ int ibh_weighted_device_view_get(const ibh_weighted *w, ibh_weighted_device_view
 /* Tuning / introspection (not part of the reference interface). */
 int ibh_weighted_set_kernel(ibh_weighted *w, const char *name_or_auto);   /* "auto", "rowblock", "shortrow", "rowdual", "colsweep", "rowgroup" */
 int ibh_weighted_last_kernel(const ibh_weighted *w, char *buf, int buflen);
+/* The kernel INSTANTIATION the last apply launched, spelled as rocprofv3 prints it ("spmm_rowblock_kernel<1, 1, 14, 8, false>",
+ * "spmm_rowone_kernel<8, 14>"; "" for the other kernel families): bench.py checks it against the kernel a committed PMC profile
+ * was taken on before quoting that profile's traffic. */
+int ibh_weighted_last_launch(const ibh_weighted *w, char *buf, int buflen);
+/* A launch option of THIS matrix (the apply-side keys of ibh_set_tuning: rowblock_*, rowone*, rowgroup_*, shortrow_*, sweep_*,
+ * rowdual_*, lazy_structures): read before the process-wide map by every apply / prepare of this handle, so host threads that
+ * tune different matrices do not interfere.  value INT32_MIN removes the option.  Like every call on a handle: not concurrently
+ * with an apply of the same handle. */
+int ibh_weighted_set_option(ibh_weighted *w, const char *key, int value);
 /* 1 when the matrix was assembled by the plan-based fast path for sorted exchange grids (fastasm.inl), 3 when the ranks of a
  * communicator shared the streamed build (ibh_regrid_matrices_matrix_d_sharded), 2 when its streamed
  * variant did (streamasm.inl: grids of 2^20 exchange cells and more; ibh_set_tuning("assemble_stream", 0 | 1) overrides),
  * 0 when the general pipeline built it (ibh_set_tuning("assemble_fast", 0) forces the latter).  Results are bit-identical. */
 int ibh_weighted_built_fast(const ibh_weighted *w, int *out);
-/* Launch-heuristic overrides for measurements and tests (README.md lists the keys: assemble_fast, assemble_fast_eva,
+/* PROCESS-WIDE launch-heuristic overrides for measurements and tests -- experiments only; a product caller that needs a knob sets it
+ * on the handle (ibh_weighted_set_option).  (README.md lists the keys: assemble_fast, assemble_fast_eva,
  * assemble_range_shape, assemble_stream_count, assemble_static_count, rowgroup_*, rowone*, rowblock_*, shortrow_*, sweep_*,
  * lazy_structures ...).  No key changes a result beyond the documented tolerance of the kernel it selects; the assembly keys
  * change no bit.  value INT32_MIN: back to the built-in default. */

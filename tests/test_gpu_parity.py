@@ -815,7 +815,7 @@ def test_config5_antarctica_colsweep_agrees_with_rowblock_at_64_fields():
     del row, col, val
     x16 = x[:16].contiguous()
     ref = o.apply(x16.cpu().numpy(), fill=-1.0, force_conservation=False)
-    for kernel in ("auto", "rowblock", "colsweep"):
+    for kernel in ("auto", "rowblock", "colsweep", "rowgroup", "auto"):        # (auto: one launch of 16 fields now takes the row groups)
         w.set_kernel(kernel)
         y = w.apply_device(x16, fill=-1.0, force_conservation=False)
         torch.cuda.synchronize()
@@ -2145,3 +2145,25 @@ def test_random_exchange_grids_large_pieces(nA_real, nX):
     for name in ("AvI", "EvI", "IvE", "EvA", "XvE"):
         assert_same_weighted(rm.matrix_d(name, scale=True, correctA=True), rg.matrix_d(name, em, scale=True, correctA=True),
                              "%s nA=%d" % (name, nA_real))
+
+
+def test_per_handle_options_do_not_leak_between_matrices():
+    """ibh_weighted_set_option: a launch option set on ONE matrix changes the kernel its applies take and nothing about another
+    matrix's -- the process-wide ibh_set_tuning map is for experiments; the result stays within the documented tolerance."""
+    import torch
+    g, em, mm, rg = setup("g5")
+    rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
+    a, b = rm.matrix("EvI"), rm.matrix("EvI")
+    x = torch.from_numpy(syn.fields(16, a.ncol_d, seed=3)).cuda()
+    a.set_option("rowgroup_auto", 0)                       # this handle: no row groups
+    for w in (a, b):
+        w.prepare(16, 1)
+    ya, yb = a.apply_device(x, force_conservation=False), b.apply_device(x, force_conservation=False)
+    torch.cuda.synchronize()
+    assert b.last_kernel() == "rowgroup" and a.last_kernel() != "rowgroup", (a.last_kernel(), b.last_kernel())
+    assert rel_linf(ya.cpu().numpy(), yb.cpu().numpy()) <= FIELD_RTOL
+    a.set_option("rowgroup_auto", None)                    # removed: back to the default choice
+    a.prepare(16, 1)
+    a.apply_device(x, force_conservation=False)
+    torch.cuda.synchronize()
+    assert a.last_kernel() == "rowgroup"
