@@ -565,6 +565,8 @@ __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, 
     __shared__ double s_t[4][OLDSEG], s_t2[4][OLDSEG];
     constexpr int NV = 8;                                        // chunks of 64 values of a segment loaded up front and kept in registers
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (walking the ranges from the END of the slice first -- the segments the emit pass wrote last, the likeliest to be still in
+    // the Infinity Cache -- changes nothing, measured: this kernel is bound by its chains, not by its reads)
     const int r = sr0 + (int)blockIdx.x * 4 + wv;
     if (r >= sr1) return;
     const int ncls = (int)g.r_ncls[r];
@@ -685,6 +687,101 @@ __global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, 
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
+// ---- all exclusive scans of a build in TWO launches ------------------------------------------------------------------------------
+// (new P keys per 64 cells, row entries per 64 cells, classes and entries per range: four channels that the generic scans served
+// with three launches each -- every launch of this chain costs the ~4 us launch floor whatever it does.)  Tiles of 2048 elements;
+// pass A leaves one sum per tile, pass B has every workgroup add up the sums of the tiles before its own (at most a few hundred
+// values) and scan its tile; the last tile of a channel stores the channel's total (and, when asked, out[n] = total).
+struct MsCh { const void *in; uint32_t *out; uint32_t *total; long n; int u8; int close; };       // close: also write out[n]
+struct MsArgs { MsCh ch[4]; int tile0[5]; int nch; };
+constexpr int MS_T = 256, MS_I = 8, MS_TILE = MS_T * MS_I;
+__device__ __forceinline__ uint32_t ms_load(const MsCh &c, long i) {
+    return c.u8 ? (uint32_t)static_cast<const uint8_t *>(c.in)[i] : static_cast<const uint32_t *>(c.in)[i];
+}
+__device__ __forceinline__ uint32_t ms_block_sum(uint32_t v, uint32_t *s_w) {
+    v = sa_wave_sum_u32(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    return t;
+}
+__global__ __launch_bounds__(MS_T) void k_ms_sums(MsArgs a, uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_w[4];
+    int c = 0;
+    while (c + 1 < a.nch && (int)blockIdx.x >= a.tile0[c + 1]) ++c;
+    const MsCh ch = a.ch[c];
+    const long base = (long)((int)blockIdx.x - a.tile0[c]) * MS_TILE;
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < MS_I; ++i) {
+        const long k = base + (long)i * MS_T + threadIdx.x;
+        if (k < ch.n) v += ms_load(ch, k);
+    }
+    const uint32_t t = ms_block_sum(v, s_w);
+    if (threadIdx.x == 0) sums[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(MS_T) void k_ms_apply(MsArgs a, const uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t tile[MS_TILE + MS_T];                    // +1 pad per 8: thread t owns tile[9t .. 9t+7]
+    int c = 0;
+    while (c + 1 < a.nch && (int)blockIdx.x >= a.tile0[c + 1]) ++c;
+    const MsCh ch = a.ch[c];
+    const int tl = (int)blockIdx.x - a.tile0[c], ntile = a.tile0[c + 1] - a.tile0[c];
+    uint32_t before = 0;
+    for (int j = threadIdx.x; j < tl; j += MS_T) before += sums[a.tile0[c] + j];
+    before = ms_block_sum(before, s_w);
+    const long base = (long)tl * MS_TILE;
+#pragma unroll
+    for (int i = 0; i < MS_I; ++i) {
+        const int e = i * MS_T + threadIdx.x;
+        const long k = base + e;
+        tile[e + (e >> 3)] = k < ch.n ? ms_load(ch, k) : 0u;
+    }
+    __syncthreads();
+    uint32_t v[MS_I], sum = 0;
+#pragma unroll
+    for (int i = 0; i < MS_I; ++i) { v[i] = tile[threadIdx.x * 9 + i]; sum += v[i]; }
+    // exclusive scan of the per-thread sums over the workgroup
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ex = sa_wave_excl_u32(sum, lane);
+    if (lane == 63) s_w[wv] = ex + sum;
+    __syncthreads();
+    uint32_t run = before + ex;
+    for (int q = 0; q < wv; ++q) run += s_w[q];
+    const uint32_t tot = before + s_w[0] + s_w[1] + s_w[2] + s_w[3];
+#pragma unroll
+    for (int i = 0; i < MS_I; ++i) { tile[threadIdx.x * 9 + i] = run; run += v[i]; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MS_I; ++i) {
+        const int e = i * MS_T + threadIdx.x;
+        const long k = base + e;
+        if (k < ch.n) ch.out[k] = tile[e + (e >> 3)];
+    }
+    if (tl == ntile - 1 && threadIdx.x == 0) {
+        if (ch.total) *ch.total = tot;
+        if (ch.close) ch.out[ch.n] = tot;
+    }
+}
+static void sa_scan_channels(const MsCh *chs, int nch, hipStream_t st) {
+    MsArgs a{};
+    int t = 0, n = 0;
+    for (int i = 0; i < nch; ++i) {
+        if (chs[i].n <= 0) {                                     // an empty channel: its total (and closing entry) is zero
+            if (chs[i].total) IBH_HIP(hipMemsetAsync(chs[i].total, 0, sizeof(uint32_t), st));
+            if (chs[i].close) IBH_HIP(hipMemsetAsync(chs[i].out, 0, sizeof(uint32_t), st));
+            continue;
+        }
+        a.ch[n] = chs[i]; a.tile0[n] = t; t += (int)ceil_div(chs[i].n, (long)MS_TILE); ++n;
+    }
+    a.tile0[n] = t; a.nch = n;
+    if (n == 0) return;
+    uint32_t *sums = arena().get<uint32_t>((size_t)t);
+    hipLaunchKernelGGL(k_ms_sums, dim3(t), dim3(MS_T), 0, st, a, sums);
+    hipLaunchKernelGGL(k_ms_apply, dim3(t), dim3(MS_T), 0, st, a, (const uint32_t *)sums);
+}
+
 // sum of the row-length bytes before cell x inside its wave (the P-key counterpart is sa_prank_at)
 __device__ __forceinline__ uint32_t sa_lrank_at(const uint32_t *__restrict__ Lw, const uint8_t *__restrict__ rl, long x) {
     const long w = x >> 6;
@@ -825,26 +922,16 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         else { if (rel32) SA_LAUNCH_RANGES(false, uint32_t); else SA_LAUNCH_RANGES(false, uint16_t); }
 #undef SA_LAUNCH_RANGES
     }
-    // scans over the slice (numberings local to it until the offsets of the ranks are known)
-    if (world == 1) {
-        if (p.fresh) exclusive_scan_u8(sb.cntP, sb.Pw, (size_t)nW, d_cnt + 2, st);
-        if (!g_is_row) exclusive_scan_u32(sb.cntL, sb.Lw, (size_t)nW, d_cnt + 5, st);
-    } else {
-        if (p.fresh) exclusive_scan_u8(sb.cntP + gW0, sb.Pw + gW0, (size_t)nwl + 1, nullptr, st);
-        if (!g_is_row) exclusive_scan_u32(sb.cntL + gW0, sb.Lw + gW0, (size_t)nwl + 1, nullptr, st);
-    }
+    // scans over the slice (numberings local to it until the offsets of the ranks are known): four channels, two launches.
+    // (world > 1: one more wave than the slice has -- the zero count behind the last one makes the scan yield the totals in place)
     {
-        FaG gl = g;
-        gl.r_ncls += sb.sr0; gl.r_nent += sb.sr0; gl.gbase += sb.sr0; gl.ebase += sb.sr0;
-        if (nr > 4096 && fa_rscan_many(gl, nr, nullptr, d_cnt + 3, nullptr, st)) {
-        } else if (nr > 4096) {
-            exclusive_scan_u32(gl.r_ncls, gl.gbase, (size_t)nr, gl.gbase + nr, st);
-            exclusive_scan_u32(gl.r_nent, gl.ebase, (size_t)nr, gl.ebase + nr, st);
-            IBH_HIP(hipMemcpyAsync(d_cnt + 3, gl.gbase + nr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-            IBH_HIP(hipMemcpyAsync(d_cnt + 4, gl.ebase + nr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        } else {
-            hipLaunchKernelGGL(k_fa_rscan, dim3(1), dim3(1024), 0, st, gl.r_ncls, gl.r_nent, nr, gl.gbase, gl.ebase, d_cnt + 3);
-        }
+        const long nws = world == 1 ? nW : nwl + 1;
+        MsCh chs[4] = {
+            {p.fresh ? (const void *)(sb.cntP + gW0) : nullptr, sb.Pw + gW0, world == 1 ? d_cnt + 2 : nullptr, p.fresh ? nws : 0, 1, 0},
+            {!g_is_row ? (const void *)(sb.cntL + gW0) : nullptr, g_is_row ? nullptr : sb.Lw + gW0, world == 1 ? d_cnt + 5 : nullptr, g_is_row ? 0 : nws, 0, 0},
+            {g.r_ncls + sb.sr0, g.gbase + sb.sr0, d_cnt + 3, nr, 0, 1},
+            {g.r_nent + sb.sr0, g.ebase + sb.sr0, d_cnt + 4, nr, 0, 1}};
+        sa_scan_channels(chs, 4, st);
     }
     if (world > 1) hipLaunchKernelGGL(k_sa_slice_counts, dim3(1), dim3(64), 0, st, sb, p.fresh, g_is_row ? 0 : 1, d_cnt);
     IBH_HIP(hipGetLastError());

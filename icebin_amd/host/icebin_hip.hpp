@@ -333,6 +333,8 @@ public:
         only enqueue work (ibh_weighted_prepare).  Once per matrix, e.g. right after matrix_d() in a coupler that
         applies the matrix more than once per step, and before capturing applies into a hipGraph. */
     void prepare(int nvar, int nbatch = 1) const { check(ibh_weighted_prepare(h_, nvar, nbatch)); }
+    /** A launch option of THIS matrix (ibh_weighted_set_option): read before the process-wide ibh_set_tuning map. */
+    void set_option(std::string const &key, int value) { check(ibh_weighted_set_option(h_, key.c_str(), value)); }
     /** Fused pair B1 = (*this) * A, B2 = second * B1 in one launch (EvI then AvE; ibh_weighted_pair_prepare /
         ibh_weighted_apply_pair_device).  pair_prepare throws Exception(IBH_ENOTIMPL) when the matrices do not pair: make the two
         apply() calls of the reference then. */
@@ -440,6 +442,16 @@ public:
         check(ibh_regrid_matrices_matrix_d(h_, spec_name.c_str(), dims[0] ? dims[0]->handle() : nullptr,
                                            dims[1] ? dims[1]->handle() : nullptr, params.scale, params.correctA,
                                            params.sigma.data(), &w));
+        return std::unique_ptr<linear::Weighted_Eigen>(new linear::Weighted_Eigen(w));
+    }
+    /** matrix_d with the ASSEMBLY shared by the ranks of `comm` (ibh_regrid_matrices_matrix_d_sharded): collective -- every rank
+        makes the same call -- and every rank receives the whole matrix, bitwise what matrix_d builds.  Smoothing is not shared
+        (params.sigma must be zero here). */
+    std::unique_ptr<linear::Weighted_Eigen> matrix_d_sharded(Communicator const &comm, std::string const &spec_name,
+                                                             std::array<SparseSetT *, 2> dims, RegridParams const &params) const {
+        ibh_weighted *w = nullptr;
+        check(ibh_regrid_matrices_matrix_d_sharded(h_, comm.handle(), spec_name.c_str(), dims[0] ? dims[0]->handle() : nullptr,
+                                                   dims[1] ? dims[1]->handle() : nullptr, params.scale, params.correctA, &w));
         return std::unique_ptr<linear::Weighted_Eigen>(new linear::Weighted_Eigen(w));
     }
     /** The matrices of one coupling step in one call (IceCoupler.cpp:361-468 builds EvI, AvI, IvE, XvE every step): the
