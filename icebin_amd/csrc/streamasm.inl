@@ -19,8 +19,8 @@
 //                    row with its weight and scaling (I/X-row matrices: rows come out in x order) from the same pass
 //   S4  k_sa_pairs   the ice cells across one GCM-cell edge (two exchange cells: a few %): their Mw / their rows, one thread each
 //       k_fa_pelem   the rest of the ice cells with several exchange cells (corners, duplicates), from the static lists
-//   S5  k_sa_rows    one wave per (range, class): straddlers sorted into place, the sequential sum (spsparse sum() order)
-//                    through scalar loads, weights, scaling
+//   S5  k_sa_rows    a 16-lane row of a wave per (range, class): straddlers sorted into place, the sequential sums (spsparse sum()
+//                    order) of four segments in lock step through DPP row broadcasts, weights, scaling
 // Same sums in the same order as fastasm.inl, the general pipeline and the oracle: bit-identical (tests force either path).
 // Not served here (fastasm.inl's kernels take them): I-row matrices on an identity I set, plans with underflowing areas (the
 // elevation-class builds count by the sign of the area), EvA / AvE (fast_build_eva).
@@ -548,19 +548,175 @@ __global__ __launch_bounds__(256) void k_sa_pairs(RgView rg, PlanView pl, MatSpe
     }
 }
 
-// ---- S5: one wave per (range, class) -- straddlers into place, sequential sums, weights, scaling --------------------------------
+// ---- S5: FOUR segments per wave -- straddlers into place, sequential sums, weights, scaling -------------------------------------
 // A segment = the entries of one (range, class): a row of an A/E-row matrix, or the terms of one column of an I/X-row matrix
-// (scratch copy).  The sum must run in sequence (spsparse sum(): ascending column / row): the wave loads the segment coalesced
-// into registers -- every load issued before anything is consumed -- and replays the chain with v_readlane; the scaled values are
-// written from the same registers.  Tried and measured on 17.5 M values in 50 000 segments (scratch/sload_test.hip: chain 206 us,
-// wide SCALAR loads -- s_load_dwordx16 through the constant cache feeding v_add_f64 directly -- 106 us, a THREAD per segment
-// 40 us): inside this kernel the scalar chain brought nothing (a1h EvI 310 -> 334 us: eleven dependent L2 round trips per
-// segment where the register chain has none) and read every value twice; the thread per segment cannot scale the row in place
-// (its stores touch 64 lines per instruction: 600 us) and starves on long rows (1 km: 685 us).
+// (scratch copy).  The sum must run in sequence (spsparse sum(): ascending column / row).  One wave replaying ONE segment's chain
+// from registers (v_readlane) spends three wave-wide instructions per entry: VALU-bound (a1h AvI 139 us, EvI 310).  Here every
+// 16-lane row of a wave owns a segment -- the four rows of a range group (one-class matrices: four consecutive ranges; elevation
+// classes: four classes of one range) -- holds 16 consecutive values of it per register, and step j of the chain broadcasts lane j
+// of EVERY row to its row (DPP row_newbcast: two moves) before one add: three instructions serve four chains.  Shorter segments are
+// padded with +0.0 (a sum that starts from +0.0 is never -0.0, so sum + 0.0 == sum bitwise).  Loads stay coalesced (128 bytes per
+// row), everything of a segment is issued up front and kept in registers for the scaling.  scratch/sload_test.hip, 17.5 M values
+// in 50 000 segments: v_readlane chain 204 us, scalar-load chain 106, a thread per segment 40 (cannot scale in place: its stores
+// touch 64 lines per instruction), this form 48.5.
 // EMIT: the rows of an A/E-row matrix (CSR in place: o.colind / o.val).  Otherwise the column sums of an I/X-row matrix over the
 // scratch copy of the terms (o.val = scratch, sdid = the row ids of the straddling terms).
+template <int J> __device__ __forceinline__ double sa_rowbcast(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#define SA_CHAIN16(SUM, V)                                                                                           \
+    do {                                                                                                             \
+        SUM = SUM + sa_rowbcast<0>(V); SUM = SUM + sa_rowbcast<1>(V); SUM = SUM + sa_rowbcast<2>(V); SUM = SUM + sa_rowbcast<3>(V);     \
+        SUM = SUM + sa_rowbcast<4>(V); SUM = SUM + sa_rowbcast<5>(V); SUM = SUM + sa_rowbcast<6>(V); SUM = SUM + sa_rowbcast<7>(V);     \
+        SUM = SUM + sa_rowbcast<8>(V); SUM = SUM + sa_rowbcast<9>(V); SUM = SUM + sa_rowbcast<10>(V); SUM = SUM + sa_rowbcast<11>(V);   \
+        SUM = SUM + sa_rowbcast<12>(V); SUM = SUM + sa_rowbcast<13>(V); SUM = SUM + sa_rowbcast<14>(V); SUM = SUM + sa_rowbcast<15>(V); \
+    } while (0)
+__device__ __forceinline__ uint32_t sa_row_sum_u32(uint32_t v) {      // over the 16 lanes of a row
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ int sa_row_max_i32(int v) {
+    v = max(v, __shfl_xor(v, 1, 64)); v = max(v, __shfl_xor(v, 2, 64)); v = max(v, __shfl_xor(v, 4, 64)); v = max(v, __shfl_xor(v, 8, 64));
+    return v;
+}
+template <bool EMIT, int OLD, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_sa_rows(RgView rg, PlanView pl, FaG g, FaOut o, int32_t *__restrict__ sdid, int sr0, int sr1) {
+    __shared__ int s_did[WPB][4][OLD], s_did2[WPB][4][OLD];
+    __shared__ double s_t[WPB][4][OLD], s_t2[WPB][4][OLD];
+    constexpr int NV = 8;                                        // chunks of 16 values per segment loaded up front (and kept for the scaling)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane >> 4, li = lane & 15;
+    const int wid = (int)blockIdx.x * WPB + wv;
+    // one-class matrices: the rows of a wave take four consecutive ranges; elevation classes: four classes of one range, the
+    // groups of four dealt to grid dimension y
+    const bool one = g.NC == 1;
+    const int r = one ? sr0 + wid * 4 + sub : sr0 + wid;
+    const int q0 = one ? 0 : (int)blockIdx.y * 4 + sub, qstride = one ? (1 << 28) : (int)gridDim.y * 4;
+    const bool rvalid = r < sr1;
+    const int ncls = rvalid ? (int)g.r_ncls[r] : 0;
+    if (!__ballot(q0 < ncls)) return;                            // (wave-uniform: nothing for any row of this wave)
+    const uint32_t eb = rvalid ? g.ebase[r] : 0u;
+    const long iA = rvalid ? pl.riA[r] : 0;
+    // the class table of the row's range: lane li of the row looks after classes li, li + 16, li + 32, li + 48
+    int rk[4];
+    uint32_t sg[4], od[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = li + 16 * k;
+        rk[k] = -1; sg[k] = 0; od[k] = 0;
+        if (rvalid && c < g.NC) {
+            rk[k] = g.erank[(size_t)r * g.NC + c];
+            od[k] = g.ecnto[(size_t)r * g.NC + c];
+            sg[k] = g.ecntn[(size_t)r * g.NC + c] + od[k];
+        }
+    }
+    int32_t *__restrict__ ids = EMIT ? o.colind : sdid;
+    for (int q = q0;; q += qstride) {
+        const bool act = q < ncls;
+        if (!__ballot(act)) break;
+        int cls_l = -1;
+        uint32_t seg_l = 0, no_l = 0, start_l = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (rk[k] == q) { cls_l = li + 16 * k; seg_l = sg[k]; no_l = od[k]; }
+            if (rk[k] >= 0 && rk[k] < q) start_l += sg[k];
+        }
+        const int cls = sa_row_max_i32(cls_l);
+        uint32_t seg = sa_row_sum_u32(seg_l), no = sa_row_sum_u32(no_l);
+        const uint32_t start = sa_row_sum_u32(start_l);
+        if (!act || cls < 0) { seg = 0; no = 0; }
+        if (no > (uint32_t)OLD) no = OLD;                        // (the build is being discarded: FA_ERR_OLDOVER; stay inside the tables)
+        const uint32_t b = eb + start, e = b + seg, bn = b + no;
+        // every load of the segment is issued up front: the straddling entries (ice cells first seen in an earlier range: smaller
+        // ids; k_sa_ranges placed them at the segment's start in x order) and the first NV x 16 entries first seen in this range
+        for (uint32_t k = li; k < no; k += 16) { s_did[wv][sub][k] = ids[b + k]; s_t[wv][sub][k] = o.val[b + k]; }
+        double v[NV];
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            const uint32_t k = bn + 16u * c + li;
+            v[c] = k < e ? o.val[k] : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the straddlers into ascending id order -- inside a class the ids are distinct: rank by counting
+        for (uint32_t k = li; k < no; k += 16) {
+            const int did = s_did[wv][sub][k];
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < no; ++j) cnt += s_did[wv][sub][j] < did ? 1u : 0u;
+            s_did2[wv][sub][cnt] = did; s_t2[wv][sub][cnt] = s_t[wv][sub][k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double sum = 0.0;
+        for (uint32_t k = 0; k < no; ++k) sum = sum + s_t2[wv][sub][k];
+        // the chains of the wave's four segments, in lock step; the longest one bounds the loop (wave-uniform)
+        const uint32_t len = e - bn;
+        uint32_t mx = max(len, (uint32_t)__shfl_xor((int)len, 16, 64));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, 32, 64));
+        mx = (uint32_t)__builtin_amdgcn_readfirstlane((int)mx);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            if (16u * c < mx) SA_CHAIN16(sum, v[c]);             // (wave-uniform condition)
+        }
+        for (uint32_t base = 16u * NV; base < mx; base += 128) {          // longer segments: eight chunks in flight per step
+            double u8[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t k = bn + base + 16u * c + li;
+                u8[c] = k < e ? o.val[k] : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (base + 16u * c < mx) SA_CHAIN16(sum, u8[c]);
+            }
+        }
+        if (act && cls >= 0) {
+            const long gkey = g.key == KEY_E ? iA * rg.sA + (long)cls * rg.sHC : iA;
+            const int gd = fa_gdense(g, r, cls, gkey);
+            if (gd >= 0) {                                     // (< 0: a key the pre-populated set lacks -- the build is discarded, FA_ERR_MISSING)
+                if (EMIT) {                                    // FAM_AEVI rows (RegridMatrices_Dynamic.cpp:100-146)
+                    double wM, mul = 1.0;
+                    if (o.correctA) {
+                        const double rr = ratio_of(rg, g.key, gkey);
+                        wM = rr * sum;
+                        if (o.scale) mul = (1.0 / rr) * (1.0 / sum);
+                    } else {
+                        wM = sum;
+                        if (o.scale) mul = 1.0 / sum;
+                    }
+                    if (li == 0) {
+                        if (g.to_sparse) g.to_sparse[gd] = gkey;
+                        o.wM[gd] = wM;
+                        o.rowptr[gd] = (int32_t)b;
+                    }
+                    for (uint32_t k = li; k < no; k += 16) {
+                        o.colind[b + k] = s_did2[wv][sub][k];
+                        o.val[b + k] = o.scale ? mul * s_t2[wv][sub][k] : s_t2[wv][sub][k];
+                    }
+                    if (o.scale) {
+#pragma unroll
+                        for (int c = 0; c < NV; ++c) {
+                            const uint32_t k = bn + 16u * c + li;
+                            if (k < e) o.val[k] = mul * v[c];
+                        }
+                        for (uint32_t k = bn + 16u * NV + li; k < e; k += 16) o.val[k] = mul * o.val[k];
+                    }
+                } else if (li == 0) {                          // FAM_IVAE columns (:201-233)
+                    if (g.to_sparse) g.to_sparse[gd] = gkey;
+                    o.Mw[gd] = o.correctA ? ratio_of(rg, g.key, gkey) * sum : sum;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The same with ONE segment per wave (v_readlane chain, 8 x 64 values in registers): grids with long ranges -- few, long segments,
+// where four lock-stepped chains per wave only quarter the number of waves in flight (1 km Greenland, 1 143 segments of ~1 700
+// entries: 0.184 ms per AvI build with this kernel, 0.250 with the four-segment one).
 template <bool EMIT, int OLDSEG>
-__global__ __launch_bounds__(256) void k_sa_rows(RgView rg, PlanView pl, FaG g, FaOut o, int32_t *__restrict__ sdid, int sr0, int sr1) {
+__global__ __launch_bounds__(256) void k_sa_rows1(RgView rg, PlanView pl, FaG g, FaOut o, int32_t *__restrict__ sdid, int sr0, int sr1) {
     __shared__ int s_did[4][OLDSEG], s_did2[4][OLDSEG];
     __shared__ double s_t[4][OLDSEG], s_t2[4][OLDSEG];
     constexpr int NV = 8;                                        // chunks of 64 values of a segment loaded up front and kept in registers
@@ -981,8 +1137,18 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
     FaOut o{w->rowptr.p, w->colind.p, w->val.p, w->wM.p, w->Mw.p, sp->family, scale, correctA, 0};
     uint32_t *flags = d_cnt + 1;
-    // row kernel: a wave per (range, class); y = the classes a range has on average, rounded up, + 1 (the others loop)
-    const dim3 grq(ceil_div(nr, 4), g.NC == 1 ? 1 : std::max(1, std::min(std::min(g.NC, 16), (int)(hme[3] / (uint32_t)std::max(nr, 1)) + 2)));
+    // row kernel: a 16-lane row of a wave per segment.  One-class matrices: four consecutive ranges per wave; elevation classes: a
+    // wave per range and group of four classes, y = the groups a range has on average, + 1 (the others loop)
+    const int forced_r4 = get_tuning("assemble_stream_rows4", -1);
+    // (measured on the Antarctic sheet, same box, four segments per wave against one: AvI 0.684 / 0.686 ms, IvA 0.902 / 0.939, IvE
+    // 1.53 / 1.55, XvE 1.14 / 1.20 -- but EvI 1.33 / 1.25: a range has two or three classes there, a quarter to half of the rows idle)
+    const bool rows4 = oldseg == SA_OLDSEG_S && (forced_r4 >= 0 ? forced_r4 != 0 : !(g_is_row && uses_ep));
+    const int rows_wpb = 4;
+    const int rows_waves = g.NC == 1 ? ceil_div(nr, 4) : nr;
+    const int rows_y = g.NC == 1 ? 1 : std::max(1, std::min((std::min(g.NC, 16) + 3) / 4, ((int)(hme[3] / (uint32_t)std::max(nr, 1)) + 2 + 3) / 4));
+    const dim3 grq(ceil_div(rows_waves, rows_wpb), rows_y);
+    // (long ranges: one wave per (range, class), y = the classes a range has on average, rounded up, + 1)
+    const dim3 grq1(ceil_div(nr, 4), g.NC == 1 ? 1 : std::max(1, std::min(std::min(g.NC, 16), (int)(hme[3] / (uint32_t)std::max(nr, 1)) + 2)));
     double *sval = nullptr;
     int32_t *sdid = nullptr;
     const int ecpt = get_tuning("assemble_stream_emit_cpt", 2);      // cells per thread of the emit pass (measured: 4 / 2 / 1 -> a1h EvI 1.34 / 1.27 / 1.28 ms)
@@ -1008,8 +1174,9 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
             if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
             else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
         }
-        if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_S>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
-        else hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_L>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
+        if (rows4) hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_S, 4>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
+        else if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows1<true, SA_OLDSEG_S>), grq1, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
+        else hipLaunchKernelGGL((k_sa_rows1<true, SA_OLDSEG_L>), grq1, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
     } else {
         sval = A.get<double>(nnz); sdid = A.get<int32_t>(nnz);
         if (uses_ep) SA_LAUNCH_EMIT(true, false); else SA_LAUNCH_EMIT(false, false);
@@ -1031,8 +1198,9 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         if (!g_fresh && ncol) hipLaunchKernelGGL(k_fa_zero_identity, dim3(ceil_div(ncol, T)), dim3(T), 0, st, w->Mw.p, (long)ncol);
         FaOut os = o;
         os.val = sval;
-        if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_S>), grq, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
-        else hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_L>), grq, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
+        if (rows4) hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_S, 4>), grq, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
+        else if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows1<false, SA_OLDSEG_S>), grq1, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
+        else hipLaunchKernelGGL((k_sa_rows1<false, SA_OLDSEG_L>), grq1, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
     }
 #undef SA_LAUNCH_EMIT
     IBH_HIP(hipGetLastError());

@@ -2086,6 +2086,7 @@ def test_streamed_build_is_the_oracle_bitwise(config, variant):
         icebin_amd.set_tuning("assemble_stream_wpr", {("g20", "sorted"): 4, ("g20", "x_fastest"): 16, ("g50", "negative_area"): 16,
                                                       ("g50", "elev_class"): 4}.get((config, variant), -2 ** 31))
         icebin_amd.set_tuning("assemble_stream_oldseg", 512 if variant in ("x_fastest", "zero_area") else -2 ** 31)   # (the table size of the straddler sort)
+        icebin_amd.set_tuning("assemble_stream_rows4", {"sorted": 1, "negative_area": 0, "elev_class": 1}.get(variant, -2 ** 31))   # (segments per wave of the row kernel)
         for scale, correctA in ((True, True), (False, False), (True, False), (False, True)):
             rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
             for name in names:
@@ -2119,6 +2120,7 @@ def test_streamed_build_is_the_oracle_bitwise(config, variant):
         icebin_amd.set_tuning("assemble_stream", -2 ** 31)
         icebin_amd.set_tuning("assemble_stream_wpr", -2 ** 31)
         icebin_amd.set_tuning("assemble_stream_oldseg", -2 ** 31)
+        icebin_amd.set_tuning("assemble_stream_rows4", -2 ** 31)
 
 
 @pytest.mark.parametrize("nA_real,nX", [(12, 150000), (60, 200000)])
