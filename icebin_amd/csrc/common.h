@@ -184,6 +184,7 @@ struct ibh_plan {
     // the first one the first-seen cell (an ice cell across one GCM-cell edge: nearly all of them) -- as three parallel arrays
     // (first cell, second cell, ice cell), served by a lean kernel without list walks; the rest (corners, duplicates) in mlist3
     ibh::DevBuf<int32_t> px1, px2, piI, mlist3;
+    ibh::DevBuf<double> pa1, pa2;        // the (static) overlap areas of a pair's two cells, beside them: no gathers in k_sa_pairs
     int32_t npair = 0, nmulti3 = 0;
     std::vector<int32_t> arng_h;         // host copy of arng (the sharded build deals ranges to ranks), filled on first use
 };

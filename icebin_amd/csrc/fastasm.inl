@@ -140,9 +140,14 @@ __global__ void k_plan_pairflags(const int32_t *__restrict__ ilptr, const int32_
     m3[i] = (e - b > 1 && !pr) ? 1u : 0u;
 }
 __global__ void k_plan_pairs(const uint32_t *__restrict__ pair, const uint32_t *__restrict__ ppos, const int32_t *__restrict__ ilptr,
-                             const int32_t *__restrict__ ilist, long nI, int32_t *__restrict__ px1, int32_t *__restrict__ px2, int32_t *__restrict__ piI) {
+                             const int32_t *__restrict__ ilist, const double *__restrict__ area, long nI, int32_t *__restrict__ px1,
+                             int32_t *__restrict__ px2, int32_t *__restrict__ piI, double *__restrict__ pa1, double *__restrict__ pa2) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nI && pair[i]) { const uint32_t k = ppos[i]; const int b = ilptr[i]; px1[k] = ilist[b]; px2[k] = ilist[b + 1]; piI[k] = (int32_t)i; }
+    if (i < nI && pair[i]) {
+        const uint32_t k = ppos[i];
+        const int b = ilptr[i], x1 = ilist[b], x2 = ilist[b + 1];
+        px1[k] = x1; px2[k] = x2; piI[k] = (int32_t)i; pa1[k] = area[x1]; pa2[k] = area[x2];
+    }
 }
 __global__ void k_plan_mlist(const uint32_t *__restrict__ multi, const uint32_t *__restrict__ mpos, long nI, int32_t *__restrict__ mlist) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,7 +227,9 @@ static bool ensure_plan(const ibh_regridder *g, hipStream_t st) {
         readback_sync(h, d_cnt, sizeof(h), st);
         P.npair = (int32_t)h[0]; P.nmulti3 = (int32_t)h[1];
         P.px1.alloc((size_t)P.npair); P.px2.alloc((size_t)P.npair); P.piI.alloc((size_t)P.npair); P.mlist3.alloc((size_t)P.nmulti3);
-        if (P.npair) hipLaunchKernelGGL(k_plan_pairs, dim3(ceil_div(nI, T)), dim3(T), 0, st, pairf, ppos, P.ilptr.p, P.ilist.p, nI, P.px1.p, P.px2.p, P.piI.p);
+        P.pa1.alloc((size_t)P.npair); P.pa2.alloc((size_t)P.npair);
+        if (P.npair) hipLaunchKernelGGL(k_plan_pairs, dim3(ceil_div(nI, T)), dim3(T), 0, st, pairf, ppos, P.ilptr.p, P.ilist.p, g->ex_area.p, nI, P.px1.p, P.px2.p,
+                                        P.piI.p, P.pa1.p, P.pa2.p);
         if (P.nmulti3) hipLaunchKernelGGL(k_plan_mlist, dim3(ceil_div(nI, T)), dim3(T), 0, st, m3, m3pos, nI, P.mlist3.p);
     }
     IBH_HIP(hipGetLastError());

@@ -42,6 +42,11 @@ struct SaBuf {
     uint8_t *cntP;          // [nW]        new P keys per 64 cells
     uint32_t *cntL;         // [nW]        row entries per 64 cells (I/X-row matrices)
     uint32_t *Pw, *Lw;      // their exclusive scans
+    // one-class matrices (A rows / A columns): entries first seen in their range / straddling, per 64 cells, their scans, and the
+    // scans' values at the start of every range -- the position of an entry inside its range's block follows from these (the
+    // elevation-class matrices take it from `rel`, written by k_sa_ranges)
+    uint8_t *cntE, *cntO;
+    uint32_t *Ew, *Eow, *ewbase, *eobase;
     // the slice of the exchange grid this build works on (a whole sheet, or one rank's share of it -- ibh_regrid_matrices_matrix_d_sharded):
     // ranges [sr0, sr1) = cells [sx0, sx1); the per-cell passes cover whole waves, [gx0, gx1) = the slice rounded out to 64 cells
     long sx0, sx1, gx0, gx1;
@@ -163,6 +168,10 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
         const unsigned long long bp = __ballot(P);
         const long xw = cb + (long)u * SA_T + (tid & ~63);
         if (lane == 0 && xw < sb.gx1) sb.cntP[xw >> 6] = (uint8_t)__popcll(bp);
+        if (!WITH_EP) {
+            const unsigned long long bn = __ballot(ent && !old), bo = __ballot(old);
+            if (lane == 0 && xw < sb.gx1) { sb.cntE[xw >> 6] = (uint8_t)__popcll(bn); sb.cntO[xw >> 6] = (uint8_t)__popcll(bo); }
+        }
         if (prows) {
             // entries of the row this cell owns: a one-cell ice cell / an exchange cell -> its own entries; an ice cell with
             // several exchange cells -> (groups of duplicates with a contributing member: static, plan) x (classes)
@@ -176,6 +185,41 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
             if (lane == 0 && xw < sb.gx1) sb.cntL[xw >> 6] = tot;
         }
     }
+}
+
+// entries before cell x: `W` = the scan over whole waves of 64 cells, the rest from the code bytes of x's wave
+// (NEW: heads with entries first seen in their range -- ENT set, OLD clear; otherwise the straddlers -- OLD set)
+template <bool NEW>
+__device__ __forceinline__ uint32_t sa_erank_at(const uint32_t *__restrict__ W, const uint8_t *__restrict__ code, long x) {
+    const long w = x >> 6;
+    const int k = (int)(x & 63);
+    uint32_t rnk = W[w];
+    const unsigned long long *__restrict__ q = reinterpret_cast<const unsigned long long *>(code + (w << 6));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int nb = k - 8 * j;
+        if (nb <= 0) break;
+        const unsigned long long t = q[j];
+        const unsigned long long ent = (t >> 1) & 0x0101010101010101ull, old = (t >> 2) & 0x0101010101010101ull;
+        const unsigned long long word = NEW ? (ent & ~old) : old;
+        rnk += (uint32_t)__popcll(nb >= 8 ? word : (word & ((1ull << (8 * nb)) - 1)));
+    }
+    return rnk;
+}
+// ---- S2 of the one-class matrices: a thread per range -- its entries are differences of the scans at its two ends --------------
+__global__ void k_sa_rangecounts(PlanView pl, SaBuf sb, FaG g, uint32_t *__restrict__ flags, int oldseg) {
+    const int r = sb.sr0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r >= sb.sr1) return;
+    const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
+    const uint32_t n0 = sa_erank_at<true>(sb.Ew, sb.code, x0), n1 = sa_erank_at<true>(sb.Ew, sb.code, x1);
+    const uint32_t o0 = sa_erank_at<false>(sb.Eow, sb.code, x0), o1 = sa_erank_at<false>(sb.Eow, sb.code, x1);
+    const uint32_t cn = n1 - n0, co = o1 - o0;
+    const bool member = cn + co > 0;
+    g.erank[r] = member ? 0 : -1;
+    g.ecntn[r] = cn; g.ecnto[r] = co;
+    g.r_ncls[r] = member ? 1u : 0u; g.r_nent[r] = cn + co;
+    sb.ewbase[r] = n0; sb.eobase[r] = o0;
+    if (co > (uint32_t)oldseg) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
 }
 
 // ---- S2: over the bytes only; WPR waves per range (1: four ranges per workgroup; 4 / 16: one range per workgroup, every wave
@@ -331,7 +375,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const long cb = sb.gx0 + (long)blockIdx.x * (SA_T * CPT);
-    const REL *__restrict__ rel = static_cast<const REL *>(sb.rel);
+    const REL *__restrict__ rel = static_cast<const REL *>(sb.rel);      // (elevation classes only)
     constexpr int S = WITH_EP ? 2 : 1;
     const bool pkey_x = p.key == KEY_X;
     if (blockIdx.x == 0 && tid == 0) o.rowptr[sb.end_row] = (int32_t)sb.end_nnz;
@@ -359,6 +403,9 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
         // (the wave's ballots -- range heads here, new P keys below -- see every lane; the ROLES only the cells of the slice)
         const unsigned long long heads = __ballot((cd[u] & SA_RHEAD) != 0), pbits = __ballot((cd[u] & SA_P) != 0);
         bpv[u] = pbits;
+        // one class per range: an entry's place in its range's block = (entries of its kind before it in x order) - (those before
+        // the range) -- scans over whole waves + the wave's ballot; straddlers in front (in x order here, k_sa_rows sorts them)
+        const unsigned long long bnew = __ballot((cd[u] & SA_ENT) && !(cd[u] & SA_OLD)), bold = __ballot((cd[u] & SA_OLD) != 0);
         if (x < sb.sx0 || x >= sb.sx1) cd[u] = 0u;
         const bool want = (cd[u] & (SA_ENT | SA_P)) != 0, ent = (cd[u] & SA_ENT) != 0;
         rv[u] = rb[u] + (int)__popcll(heads & le & ~1ull);
@@ -366,8 +413,16 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
         av[u] = ent ? rg.area[x] : 0.0;
         ebv[u] = ent ? g.ebase[rv[u]] : 0u;
         iAv[u] = (ent && (WITH_EP || !G_ROWS)) ? pl.riA[rv[u]] : 0;      // (an A-row matrix without classes never looks at the atmosphere index here)
+        if (WITH_EP) {
 #pragma unroll
-        for (int j = 0; j < S; ++j) relv[u][j] = ent ? (uint32_t)rel[(size_t)S * x + j] : 0u;
+            for (int j = 0; j < S; ++j) relv[u][j] = ent ? (uint32_t)rel[(size_t)S * x + j] : 0u;
+        } else if (ent) {
+            const bool isold = (cd[u] & SA_OLD) != 0;
+            const int rr = rv[u];
+            const uint32_t wbase = xw < sb.gx1 ? (isold ? sb.Eow[xw >> 6] : sb.Ew[xw >> 6]) : 0u;
+            relv[u][0] = isold ? wbase + (uint32_t)__popcll(bold & lt) - sb.eobase[rr]
+                               : g.ecnto[rr] + wbase + (uint32_t)__popcll(bnew & lt) - sb.ewbase[rr];
+        } else relv[u][0] = 0u;
         lenv[u] = (!G_ROWS && x < sb.gx1) ? sb.rl[x] : 0u;
         hintv[u] = -1;
         if (WITH_EP && ent) {
@@ -474,7 +529,8 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
 // from zero); otherwise its row (ascending column, wM, scaling) at the offset k_sa_emit recorded.
 template <bool WITH_EP, bool G_ROWS>
 __global__ __launch_bounds__(256) void k_sa_pairs(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, SaBuf sb, const int32_t *__restrict__ px1,
-                                                   const int32_t *__restrict__ px2, const int32_t *__restrict__ piI, int npair, FaOut o) {
+                                                   const int32_t *__restrict__ px2, const int32_t *__restrict__ piI, const double *__restrict__ pa1,
+                                                   const double *__restrict__ pa2, int npair, FaOut o) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     stage_hc<WITH_EP>(rg, s_hc);
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -483,7 +539,7 @@ __global__ __launch_bounds__(256) void k_sa_pairs(RgView rg, PlanView pl, MatSpe
     if (x1 < sb.sx0 || x1 >= sb.sx1) return;                     // (the rank whose slice holds the first cell serves the ice cell)
     if (!(sb.code[x1] & SA_P)) return;                           // masked (or no area at all): not a member of the I set
     const double e = WITH_EP ? rg.em[iI] : 0.0;
-    const double a1 = rg.area[x1], a2 = rg.area[x2];
+    const double a1 = pa1[k], a2 = pa2[k];                       // (static: stored beside the pair)
     // (an A-row matrix without classes needs neither the ranges nor the atmosphere cells: its terms are functions of the areas)
     constexpr bool NEED_R = WITH_EP || !G_ROWS;
     const int r1 = NEED_R ? pl.aidx[x1] : 0, r2 = NEED_R ? pl.aidx[x2] : 0;
@@ -1045,7 +1101,12 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     sb.code = A.get<uint8_t>((size_t)nW * 64);
     if (uses_ep) sb.cls = A.get<uint8_t>((size_t)nW * 64);
     if (!g_is_row) { sb.rl = A.get<uint8_t>((size_t)nW * 64); sb.cntL = A.get<uint32_t>((size_t)nW + 1); sb.Lw = A.get<uint32_t>((size_t)nW + 1); }
-    sb.rel = A.get_bytes((size_t)nX * S * (rel32 ? 4 : 2));
+    if (uses_ep) sb.rel = A.get_bytes((size_t)nX * S * (rel32 ? 4 : 2));
+    else {
+        sb.cntE = A.get<uint8_t>((size_t)nW + 1); sb.cntO = A.get<uint8_t>((size_t)nW + 1);
+        sb.Ew = A.get<uint32_t>((size_t)nW + 1); sb.Eow = A.get<uint32_t>((size_t)nW + 1);
+        sb.ewbase = A.get<uint32_t>((size_t)nAr); sb.eobase = A.get<uint32_t>((size_t)nAr);
+    }
     sb.cntP = A.get<uint8_t>((size_t)nW + 1); sb.Pw = A.get<uint32_t>((size_t)nW + 1);
     p.Pw = sb.Pw; p.code = sb.code;
     // counters, 8 per rank, read back with one sync: [0] first out-of-range cell, [1] fallback flags, [2] new P keys, [3] G classes,
@@ -1057,6 +1118,10 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         IBH_HIP(hipMemsetAsync(sb.cntP + gW1, 0, 1, st));
         if (!g_is_row) IBH_HIP(hipMemsetAsync(sb.cntL + gW1, 0, sizeof(uint32_t), st));
     }
+    if (!uses_ep) {      // (the scans of the entry counts are read AT the end of the last range too)
+        IBH_HIP(hipMemsetAsync(sb.cntE + gW1, 0, 1, st));
+        IBH_HIP(hipMemsetAsync(sb.cntO + gW1, 0, 1, st));
+    }
     const dim3 gs(ceil_div(sb.gx1 - sb.gx0, (long)SA_TILE)), gr4(ceil_div(nr, 4));
     if (uses_ep) hipLaunchKernelGGL((k_sa_flags<true>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt);
     else hipLaunchKernelGGL((k_sa_flags<false>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt);
@@ -1064,30 +1129,39 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     // (straddlers of a range ~ its perimeter: a range of ~10^3 cells has a few dozen, one of 10^4 a few hundred)
     const int forced_os = get_tuning("assemble_stream_oldseg", -1);
     const int oldseg = (forced_os == SA_OLDSEG_S || forced_os == SA_OLDSEG_L) ? forced_os : mean <= 2048 ? SA_OLDSEG_S : SA_OLDSEG_L;
-    {
+    if (uses_ep) {
         // waves per range by the size of the ranges: one wave walks ~10^3 cells in a few round trips; longer ranges are cut
         const int forced = get_tuning("assemble_stream_wpr", -1);
         const int wpr = (forced == 1 || forced == 4 || forced == 16) ? forced : mean <= 1024 ? 1 : mean <= 4096 ? 4 : 16;
-#define SA_LAUNCH_RANGES(EP, RT)                                                                                               \
+#define SA_LAUNCH_RANGES(RT)                                                                                                    \
         do {                                                                                                                \
-            if (wpr == 1) hipLaunchKernelGGL((k_sa_ranges<EP, RT, 1>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg);    \
-            else if (wpr == 4) hipLaunchKernelGGL((k_sa_ranges<EP, RT, 4>), dim3(nr), dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg); \
-            else hipLaunchKernelGGL((k_sa_ranges<EP, RT, 16>), dim3(nr), dim3(1024), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg);     \
+            if (wpr == 1) hipLaunchKernelGGL((k_sa_ranges<true, RT, 1>), gr4, dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg);    \
+            else if (wpr == 4) hipLaunchKernelGGL((k_sa_ranges<true, RT, 4>), dim3(nr), dim3(256), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg); \
+            else hipLaunchKernelGGL((k_sa_ranges<true, RT, 16>), dim3(nr), dim3(1024), 0, st, rg, pl, sb, g, d_cnt + 1, oldseg);     \
         } while (0)
-        if (uses_ep) { if (rel32) SA_LAUNCH_RANGES(true, uint32_t); else SA_LAUNCH_RANGES(true, uint16_t); }
-        else { if (rel32) SA_LAUNCH_RANGES(false, uint32_t); else SA_LAUNCH_RANGES(false, uint16_t); }
+        if (rel32) SA_LAUNCH_RANGES(uint32_t); else SA_LAUNCH_RANGES(uint16_t);
 #undef SA_LAUNCH_RANGES
     }
-    // scans over the slice (numberings local to it until the offsets of the ranks are known): four channels, two launches.
+    // scans over the slice (numberings local to it until the offsets of the ranks are known), two launches per set of channels.
     // (world > 1: one more wave than the slice has -- the zero count behind the last one makes the scan yield the totals in place)
     {
         const long nws = world == 1 ? nW : nwl + 1;
-        MsCh chs[4] = {
-            {p.fresh ? (const void *)(sb.cntP + gW0) : nullptr, sb.Pw + gW0, world == 1 ? d_cnt + 2 : nullptr, p.fresh ? nws : 0, 1, 0},
-            {!g_is_row ? (const void *)(sb.cntL + gW0) : nullptr, g_is_row ? nullptr : sb.Lw + gW0, world == 1 ? d_cnt + 5 : nullptr, g_is_row ? 0 : nws, 0, 0},
-            {g.r_ncls + sb.sr0, g.gbase + sb.sr0, d_cnt + 3, nr, 0, 1},
-            {g.r_nent + sb.sr0, g.ebase + sb.sr0, d_cnt + 4, nr, 0, 1}};
-        sa_scan_channels(chs, 4, st);
+        const MsCh chP{p.fresh ? (const void *)(sb.cntP + gW0) : nullptr, sb.Pw + gW0, world == 1 ? d_cnt + 2 : nullptr, p.fresh ? nws : 0, 1, 0};
+        const MsCh chL{!g_is_row ? (const void *)(sb.cntL + gW0) : nullptr, g_is_row ? nullptr : sb.Lw + gW0, world == 1 ? d_cnt + 5 : nullptr, g_is_row ? 0 : nws, 0, 0};
+        const MsCh chG{g.r_ncls + sb.sr0, g.gbase + sb.sr0, d_cnt + 3, nr, 0, 1};
+        const MsCh chN{g.r_nent + sb.sr0, g.ebase + sb.sr0, d_cnt + 4, nr, 0, 1};
+        if (uses_ep) {
+            const MsCh chs[4] = {chP, chL, chG, chN};
+            sa_scan_channels(chs, 4, st);
+        } else {
+            // one class per range: the entries of a range are differences of two more scans at its ends (no pass over its bytes)
+            const MsCh chE{sb.cntE + gW0, sb.Ew + gW0, nullptr, nwl + 1, 1, 0}, chO{sb.cntO + gW0, sb.Eow + gW0, nullptr, nwl + 1, 1, 0};
+            const MsCh chs[4] = {chP, chL, chE, chO};
+            sa_scan_channels(chs, 4, st);
+            hipLaunchKernelGGL(k_sa_rangecounts, dim3(ceil_div(nr, 256)), dim3(256), 0, st, pl, sb, g, d_cnt + 1, oldseg);
+            const MsCh chs2[2] = {chG, chN};
+            sa_scan_channels(chs2, 2, st);
+        }
     }
     if (world > 1) hipLaunchKernelGGL(k_sa_slice_counts, dim3(1), dim3(64), 0, st, sb, p.fresh, g_is_row ? 0 : 1, d_cnt);
     IBH_HIP(hipGetLastError());
@@ -1140,9 +1214,11 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     // row kernel: a 16-lane row of a wave per segment.  One-class matrices: four consecutive ranges per wave; elevation classes: a
     // wave per range and group of four classes, y = the groups a range has on average, + 1 (the others loop)
     const int forced_r4 = get_tuning("assemble_stream_rows4", -1);
-    // (measured on the Antarctic sheet, same box, four segments per wave against one: AvI 0.684 / 0.686 ms, IvA 0.902 / 0.939, IvE
-    // 1.53 / 1.55, XvE 1.14 / 1.20 -- but EvI 1.33 / 1.25: a range has two or three classes there, a quarter to half of the rows idle)
-    const bool rows4 = oldseg == SA_OLDSEG_S && (forced_r4 >= 0 ? forced_r4 != 0 : !(g_is_row && uses_ep));
+    // (measured on the Antarctic sheet, same box, four segments per wave against one: the column sums of the I/X-row matrices win
+    // -- IvA 0.902 / 0.939 ms, IvE 1.53 / 1.55, XvE 1.14 / 1.20; the rows of AvI are even, 0.684 / 0.686, but with 128 values of a
+    // segment in registers -- more cost occupancy: 146 VGPRs at 256 -- the scaling re-reads the rest: 264 against 176 MB fetched; EvI
+    // loses, 1.33 / 1.25: a range has two or three classes there, a quarter to half of the rows idle.  So: column sums only.)
+    const bool rows4 = oldseg == SA_OLDSEG_S && (forced_r4 >= 0 ? forced_r4 != 0 : !g_is_row);
     const int rows_wpb = 4;
     const int rows_waves = g.NC == 1 ? ceil_div(nr, 4) : nr;
     const int rows_y = g.NC == 1 ? 1 : std::max(1, std::min((std::min(g.NC, 16) + 3) / 4, ((int)(hme[3] / (uint32_t)std::max(nr, 1)) + 2 + 3) / 4));
@@ -1166,8 +1242,8 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         if (uses_ep) SA_LAUNCH_EMIT(true, true); else SA_LAUNCH_EMIT(false, true);
         if (p.key == KEY_I && P.npair) {                      // Mw of the ice cells across one GCM-cell edge
             const dim3 gp2(ceil_div(P.npair, 256));
-            if (uses_ep) hipLaunchKernelGGL((k_sa_pairs<true, true>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.npair, o);
-            else hipLaunchKernelGGL((k_sa_pairs<false, true>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.npair, o);
+            if (uses_ep) hipLaunchKernelGGL((k_sa_pairs<true, true>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.pa1.p, P.pa2.p, P.npair, o);
+            else hipLaunchKernelGGL((k_sa_pairs<false, true>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.pa1.p, P.pa2.p, P.npair, o);
         }
         if (p.key == KEY_I && P.nmulti3) {                    // ... and of the rest of the ice cells with several exchange cells
             const dim3 gm(ceil_div(P.nmulti3, T));
@@ -1182,8 +1258,8 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         if (uses_ep) SA_LAUNCH_EMIT(true, false); else SA_LAUNCH_EMIT(false, false);
         if (p.key == KEY_I && P.npair) {                      // the rows of the ice cells across one GCM-cell edge
             const dim3 gp2(ceil_div(P.npair, 256));
-            if (uses_ep) hipLaunchKernelGGL((k_sa_pairs<true, false>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.npair, o);
-            else hipLaunchKernelGGL((k_sa_pairs<false, false>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.npair, o);
+            if (uses_ep) hipLaunchKernelGGL((k_sa_pairs<true, false>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.pa1.p, P.pa2.p, P.npair, o);
+            else hipLaunchKernelGGL((k_sa_pairs<false, false>), gp2, dim3(256), 0, st, rg, pl, *sp, g, p, sb, P.px1.p, P.px2.p, P.piI.p, P.pa1.p, P.pa2.p, P.npair, o);
         }
         if (p.key == KEY_I && P.nmulti3) {                    // ... and of the rest of the ice cells with several exchange cells
             const dim3 gm(ceil_div(P.nmulti3, T));
