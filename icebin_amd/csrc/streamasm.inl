@@ -22,8 +22,8 @@
 //   S5  k_sa_rows    a 16-lane row of a wave per (range, class): straddlers sorted into place, the sequential sums (spsparse sum()
 //                    order) of four segments in lock step through DPP row broadcasts, weights, scaling
 // Same sums in the same order as fastasm.inl, the general pipeline and the oracle: bit-identical (tests force either path).
-// Not served here (fastasm.inl's kernels take them): I-row matrices on an identity I set, plans with underflowing areas (the
-// elevation-class builds count by the sign of the area), EvA / AvE (fast_build_eva).
+// Not served here (fastasm.inl's kernels take them): plans with underflowing areas (the elevation-class builds count by the sign
+// of the area), EvA / AvE (fast_build_eva).
 
 constexpr int SA_T = 256, SA_CPT = 4, SA_TILE = SA_T * SA_CPT;
 // code byte: a P key is first seen here | this cell heads a group with entries | those entries straddle in from an earlier range |
@@ -38,6 +38,7 @@ struct SaBuf {
     uint8_t *code;          // [nW * 64]
     uint8_t *cls;           // [nW * 64]   elevation classes: first class | number of classes << 6 (heads of groups only)
     uint8_t *rl;            // [nW * 64]   I/X-row matrices: entries of the row owned by this cell
+    uint8_t *rli;           // [nI]        I-row matrix on an IDENTITY ice set: the same by ice cell (its rows lie in ice-cell order)
     void *rel;              // [nX * S]    position of every entry inside its range's block (uint16_t / uint32_t)
     uint8_t *cntP;          // [nW]        new P keys per 64 cells
     uint32_t *cntL;         // [nW]        row entries per 64 cells (I/X-row matrices)
@@ -181,8 +182,12 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
                 else len = WITH_EP ? (uint32_t)ncls_e * pl.icnt_nz[iIv[u]] : (uint32_t)pl.icnt_pos[iIv[u]];
             }
             if (in) sb.rl[x] = (uint8_t)len;
-            const uint32_t tot = sa_wave_sum_u32(len);
-            if (lane == 0 && xw < sb.gx1) sb.cntL[xw >> 6] = tot;
+            if (sb.rli) {                                        // identity ice set: rows by ice cell (zeroed beforehand: masked cells have empty rows)
+                if (P && len) sb.rli[iIv[u]] = (uint8_t)len;
+            } else {
+                const uint32_t tot = sa_wave_sum_u32(len);
+                if (lane == 0 && xw < sb.gx1) sb.cntL[xw >> 6] = tot;
+            }
         }
     }
 }
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
     const REL *__restrict__ rel = static_cast<const REL *>(sb.rel);      // (elevation classes only)
     constexpr int S = WITH_EP ? 2 : 1;
     const bool pkey_x = p.key == KEY_X;
-    if (blockIdx.x == 0 && tid == 0) o.rowptr[sb.end_row] = (int32_t)sb.end_nnz;
+    if (blockIdx.x == 0 && tid == 0 && !sb.rli) o.rowptr[sb.end_row] = (int32_t)sb.end_nnz;      // (identity ice rows: closed by the scan)
     // round 1: the code bytes and (one address per wave) the range of each wave's first cell; round 2: everything the cells with
     // entries / with a new P key need -- the range of a cell is its wave's first range + the range heads up to its lane (code bit
     // 7), so the per-range values are fetched in the same round as the cell itself; round 3: the mask value (elevation classes)
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
             hintv[u] = rg.interp == 0 ? (n == 2 ? c0 + 1 : (c0 == 0 ? 1 : c0)) : c0;
         }
         pwv[u] = (p.fresh && xw < sb.gx1) ? sb.Pw[xw >> 6] : 0u;
-        lwv[u] = (!G_ROWS && xw < sb.gx1) ? sb.Lw[xw >> 6] : 0u;
+        lwv[u] = (!G_ROWS && sb.Lw && xw < sb.gx1) ? sb.Lw[xw >> 6] : 0u;
     }
     double ev[CPT];
 #pragma unroll
@@ -495,10 +500,15 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
             }
         } else {
             // rows come out in x order of the cells that own them: offset = row entries before this wave + before this lane
-            const uint32_t before = sa_wave_excl_u32(lenv[u], lane);
-            const uint32_t b0 = lwv[u] + before;
-            if (in && (P || !p.fresh)) o.rowptr[pown] = (int32_t)b0;
-            if (in && !P && !p.fresh) o.wM[pown] = 0.0;                  // identity set: a cell that is no member has an empty row
+            // (an identity ICE set: rows lie in ice-cell order -- the row pointer is the scan over the ice cells, done before this pass,
+            // wM of the cells that are no members was cleared with it)
+            const bool by_ice = sb.rli != nullptr;
+            const uint32_t before = by_ice ? 0u : sa_wave_excl_u32(lenv[u], lane);
+            const uint32_t b0 = by_ice ? (P ? (uint32_t)o.rowptr[pown] : 0u) : lwv[u] + before;
+            if (!by_ice) {
+                if (in && (P || !p.fresh)) o.rowptr[pown] = (int32_t)b0;
+                if (in && !P && !p.fresh) o.wM[pown] = 0.0;              // identity set: a cell that is no member has an empty row
+            }
             if (P) {
                 if (p.fresh) p.to_sparse[pown] = pkey_x ? x : (long)iI;
                 if (pkey_x || (cd[u] & SA_ONE)) {
@@ -1052,7 +1062,9 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     const bool uses_ep = sp->row_list == LIST_EP || sp->col_list == LIST_EP;
     if (uses_ep && (P.tiny || !P.icnt_nz.p)) return false;         // classes are counted by the sign of the area here
     if (!P.icnt_pos.p) return false;
-    if (!g_is_row && pkey == KEY_I && pmode == 0) return false;    // rows in ice-cell order, not in first-seen order: fastasm.inl
+    // an I-row matrix on an identity ice set (the coupler's IvE, IceCoupler.cpp:462): its rows lie in ice-cell order, not in
+    // first-seen order -- row lengths are scattered by ice cell and scanned over the ice cells
+    const bool by_ice = !g_is_row && pkey == KEY_I && pmode == 0;
     // sharded: the pieces of a rank must be contiguous in every result array -- sets numbered by this build (an identity or a
     // pre-populated set indexes Mw by sparse position); at most 8 ranks (one 256-byte read-back carries all counters)
     if (world > 1 && (pmode != 1 || !g_fresh || world > 8 || P.nAr < world)) return false;
@@ -1100,7 +1112,13 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     p.key = pkey; p.list = plist; p.fresh = pmode;
     sb.code = A.get<uint8_t>((size_t)nW * 64);
     if (uses_ep) sb.cls = A.get<uint8_t>((size_t)nW * 64);
-    if (!g_is_row) { sb.rl = A.get<uint8_t>((size_t)nW * 64); sb.cntL = A.get<uint32_t>((size_t)nW + 1); sb.Lw = A.get<uint32_t>((size_t)nW + 1); }
+    if (!g_is_row) {
+        sb.rl = A.get<uint8_t>((size_t)nW * 64);
+        if (by_ice) {
+            sb.rli = A.get<uint8_t>((size_t)gr->nI);
+            IBH_HIP(hipMemsetAsync(sb.rli, 0, (size_t)gr->nI, st));
+        } else { sb.cntL = A.get<uint32_t>((size_t)nW + 1); sb.Lw = A.get<uint32_t>((size_t)nW + 1); }
+    }
     if (uses_ep) sb.rel = A.get_bytes((size_t)nX * S * (rel32 ? 4 : 2));
     else {
         sb.cntE = A.get<uint8_t>((size_t)nW + 1); sb.cntO = A.get<uint8_t>((size_t)nW + 1);
@@ -1116,7 +1134,7 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     if (world > 1) {     // (one more wave than the slice has: a zero count behind the last one, so that the scans also yield totals)
         IBH_HIP(hipMemsetAsync(sb.cntP + gW1, 0, 1, st));
-        if (!g_is_row) IBH_HIP(hipMemsetAsync(sb.cntL + gW1, 0, sizeof(uint32_t), st));
+        if (!g_is_row && !by_ice) IBH_HIP(hipMemsetAsync(sb.cntL + gW1, 0, sizeof(uint32_t), st));
     }
     if (!uses_ep) {      // (the scans of the entry counts are read AT the end of the last range too)
         IBH_HIP(hipMemsetAsync(sb.cntE + gW1, 0, 1, st));
@@ -1147,7 +1165,8 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     {
         const long nws = world == 1 ? nW : nwl + 1;
         const MsCh chP{p.fresh ? (const void *)(sb.cntP + gW0) : nullptr, sb.Pw + gW0, world == 1 ? d_cnt + 2 : nullptr, p.fresh ? nws : 0, 1, 0};
-        const MsCh chL{!g_is_row ? (const void *)(sb.cntL + gW0) : nullptr, g_is_row ? nullptr : sb.Lw + gW0, world == 1 ? d_cnt + 5 : nullptr, g_is_row ? 0 : nws, 0, 0};
+        const bool lch = !g_is_row && !by_ice;
+        const MsCh chL{lch ? (const void *)(sb.cntL + gW0) : nullptr, lch ? sb.Lw + gW0 : nullptr, world == 1 ? d_cnt + 5 : nullptr, lch ? nws : 0, 0, 0};
         const MsCh chG{g.r_ncls + sb.sr0, g.gbase + sb.sr0, d_cnt + 3, nr, 0, 1};
         const MsCh chN{g.r_nent + sb.sr0, g.ebase + sb.sr0, d_cnt + 4, nr, 0, 1};
         if (uses_ep) {
@@ -1237,6 +1256,11 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         else hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 4>), gs, dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid);       \
     } while (0)
     sb.end_row = nrow; sb.end_nnz = nnz;
+    if (by_ice) {                                                // the row pointer over the ice cells (closes itself: rowptr[nI] = nnz); wM of non-members
+        const MsCh chI{sb.rli, reinterpret_cast<uint32_t *>(w->rowptr.p), nullptr, (long)gr->nI, 1, 1};
+        sa_scan_channels(&chI, 1, st);
+        IBH_HIP(hipMemsetAsync(w->wM.p, 0, sizeof(double) * (size_t)nrow, st));
+    }
     if (g_is_row) {
         if (ncol && !p.fresh) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
         if (uses_ep) SA_LAUNCH_EMIT(true, true); else SA_LAUNCH_EMIT(false, true);

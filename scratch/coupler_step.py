@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import icebin_amd
 from icebin_amd import synthetic as syn
+for k, v in [kv.split("=") for kv in os.environ.get("TUNE", "").split(",") if kv]: icebin_amd.set_tuning(k, int(v))
 for cfg in sys.argv[1].split(","):
     g = syn.make_grids(cfg); em = syn.dome_elevmask(g)
     mm = icebin_amd.from_synthetic(g)

@@ -2094,20 +2094,21 @@ def test_streamed_build_is_the_oracle_bitwise(config, variant):
                 assert w.built_streamed(), name
                 assert_same_weighted(w, rg.matrix_d(name, em, scale=scale, correctA=correctA), "%s %s scale=%d correctA=%d" % (name, variant, scale, correctA))
         rm = mm.regrid_matrices("greenland", em)
-        # the coupler's step (IceCoupler.cpp:361-468): EvI / AvI on an identity dimI, XvE on the dimE EvI numbered and an identity
-        # dimX (IvE on an identity dimI keeps the per-range kernels: its rows lie in ice-cell order)
+        # the coupler's step (IceCoupler.cpp:361-468): EvI / AvI on an identity dimI, IvE on it and the dimE EvI numbered (its rows lie
+        # in ice-cell order: row lengths scattered by ice cell, scanned over the ice cells), XvE on that dimE and an identity dimX
         dimI, dimX, dimE = icebin_amd.SparseSet.identity(nI), icebin_amd.SparseSet.identity(nX), icebin_amd.SparseSet(nE)
         oI, oX, oE = orc.SparseSet(nI, init=np.arange(nI)), orc.SparseSet(nX, init=np.arange(nX)), orc.SparseSet(nE)
         for name, dims, odims, sc, cA, streamed in (("EvI", (dimE, dimI), (oE, oI), False, False, True), ("AvI", (None, dimI), (None, oI), False, True, True),
-                                                    ("IvE", (dimI, dimE), (oI, oE), True, True, False), ("XvE", (dimX, dimE), (oX, oE), False, True, True),
-                                                    ("IvE", (None, dimE), (None, oE), True, True, True), ("AvX", (None, dimX), (None, oX), True, True, True)):
+                                                    ("IvE", (dimI, dimE), (oI, oE), True, True, True), ("XvE", (dimX, dimE), (oX, oE), False, True, True),
+                                                    ("IvE", (None, dimE), (None, oE), True, True, True), ("AvX", (None, dimX), (None, oX), True, True, True),
+                                                    ("IvA", (dimI, None), (oI, None), True, False, True), ("IvE", (dimI, None), (oI, None), False, False, True)):
             w = rm.matrix_d(name, dims, scale=sc, correctA=cA)
             assert w.built_fast() and w.built_streamed() == streamed, name
             assert_same_weighted(w, rg.matrix_d(name, em, dims=odims, scale=sc, correctA=cA), "coupler %s %s" % (name, variant))
         E_keys = dimE.to_sparse()
         extra = np.setdiff1d(np.arange(nE), E_keys)[:7]
         perm = np.random.default_rng(5).permutation(np.concatenate([E_keys, extra]))
-        for name, rowset, orow in (("IvE", None, None), ("XvE", dimX, oX), ("XvE", None, None)):
+        for name, rowset, orow in (("IvE", None, None), ("XvE", dimX, oX), ("XvE", None, None), ("IvE", dimI, oI)):
             dE2, oE2 = icebin_amd.SparseSet(nE, perm), orc.SparseSet(nE, init=perm)
             w = rm.matrix_d(name, (rowset, dE2), scale=True, correctA=True)
             assert w.built_streamed(), name
