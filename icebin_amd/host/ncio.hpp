@@ -4,8 +4,9 @@
 // GCMRegridder.cpp:104-150 (`gcm.ncio(ncio, "m")`) bind to icebin_hip.hpp.  Same variable / dimension / attribute layout as
 // icebin_amd/ncio.py: a file written here is read by the Python side and vice versa (tests/test_ncio.py).
 // No NetCDF library is part of this image and the reference's own container is NetCDF-4 / HDF5: a list-of-strings attribute
-// (`m.info:sheets`, `BvA.info:dim_names`) is ONE char attribute with the names joined by ',' here, and files of the reference's
-// build need `nccopy -k cdf5` first.  Header-only, C++14, host code only (no HIP, no torch).
+// (`m.info:sheets`, `BvA.info:dim_names`) is ONE char attribute with the names joined by ',' here.  Files of the reference's
+// own build are READ when the translation unit defines ICEBIN_NCIO_HDF5 (pulls in hdf5.hpp, needs -lz); without the macro they
+// are refused with a message naming it.  Header-only, C++14, host code only (no HIP, no torch).
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -77,6 +78,11 @@ struct Var {
         return *a;
     }
 };
+
+class File;
+#ifdef ICEBIN_NCIO_HDF5
+File read_hdf5(std::string bytes);                              // hdf5.hpp, included at the end of this header
+#endif
 
 class File {
     static void swap_bytes(char *p, size_t n, size_t w) {
@@ -176,9 +182,18 @@ public:
         std::ifstream f(path, std::ios::binary);
         if (!f) throw std::runtime_error("ncio: cannot open " + path);
         std::stringstream ss; ss << f.rdbuf();
-        const std::string buf = ss.str();
-        if (buf.size() >= 4 && buf.compare(0, 4, "\x89HDF") == 0)
-            throw std::runtime_error("ncio: " + path + " is a NetCDF-4/HDF5 file; convert it with `nccopy -k cdf5` (HDF5 is out of scope)");
+        std::string buf = ss.str();
+        bool h5sig = false;                                      // the HDF5 signature sits at 0, 512, 1024, ... (a user block may precede it)
+        if (buf.compare(0, 3, "CDF") != 0)
+            for (size_t at = 0; at + 8 <= buf.size() && !h5sig; at = at ? at * 2 : 512) h5sig = buf.compare(at, 8, "\x89HDF\r\n\x1a\n") == 0;
+        if (h5sig) {
+#ifdef ICEBIN_NCIO_HDF5
+            try { return read_hdf5(std::move(buf)); }
+            catch (std::exception const &e) { throw std::runtime_error("ncio: " + path + ": " + e.what()); }
+#else
+            throw std::runtime_error("ncio: " + path + " is a NetCDF-4/HDF5 file; compile with -DICEBIN_NCIO_HDF5 -lz (hdf5.hpp) or convert it with `nccopy -k cdf5`");
+#endif
+        }
         if (buf.size() < 8 || buf.compare(0, 3, "CDF") != 0 || (buf[3] != 1 && buf[3] != 2 && buf[3] != 5))
             throw std::runtime_error("ncio: " + path + " is not a NetCDF classic file (CDF-1/2/5)");
         const int ver = buf[3];
@@ -248,6 +263,12 @@ inline std::vector<std::string> split_names(std::string const &s) {
 inline std::string join_names(std::vector<std::string> const &v) { std::string s; for (size_t k = 0; k < v.size(); ++k) s += (k ? "," : "") + v[k]; return s; }
 
 }   // namespace nc
+}   // namespace icebin
+#ifdef ICEBIN_NCIO_HDF5
+#include "hdf5.hpp"
+namespace icebin { namespace nc { inline File read_hdf5(std::string bytes) { return h5::read_netcdf4(std::move(bytes)); } } }
+#endif
+namespace icebin {
 
 /** ibmisc::NcIO as the regrid path uses it: NcIO ncio(fname, 'r' | 'w' | 'a'); objects ->ncio(ncio, vname, ...); the file is
     written when a 'w' / 'a' handle is closed or destroyed ('a' starts from the existing file, as global_ec.cpp:567-605 appends

@@ -107,7 +107,7 @@ def _ncio_exe():
     exe, src = os.path.join(root, "tests", "cpp", "test_ncio"), os.path.join(root, "tests", "cpp", "test_ncio.cpp")
     hdr = os.path.join(root, "icebin_amd", "host", "ncio.hpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-o", exe, src])
+        subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-DICEBIN_NCIO_HDF5", "-o", exe, src, "-lz"])
     return exe
 
 
@@ -141,4 +141,78 @@ def test_cpp_container_is_read_by_python_and_vice_versa(tmp_path):
     bad = str(tmp_path / "bad.nc")
     open(bad, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
     r = subprocess.run([exe, "dump", bad], capture_output=True, text=True)
-    assert r.returncode == 1 and "NetCDF-4/HDF5" in r.stdout
+    assert r.returncode == 1 and "hdf5:" in r.stdout              # handed to hdf5.hpp, which refuses the image loudly
+
+
+# ---- the C++ HDF5 reader (icebin_amd/host/hdf5.hpp) against the Python one (icebin_amd/hdf5.py) -------------------------------
+_NC_CODE = {"int8": 1, "int16": 3, "int32": 4, "float32": 5, "float64": 6, "uint8": 7, "uint16": 8, "uint32": 9, "int64": 10, "uint64": 11}
+
+
+def _dump_value(x):
+    """tests/cpp/test_ncio.cpp's dump_array() for what the Python readers return"""
+    if isinstance(x, (list, tuple)) and all(isinstance(s, str) for s in x):
+        x = ",".join(x)                                         # a list of strings is ONE comma-joined char attribute in C++
+    if isinstance(x, str):
+        return "char[%d] '%s'" % (len(x.encode()), x)
+    a = np.ascontiguousarray(x).reshape(-1)
+    if a.dtype.kind == "S":
+        b = a.tobytes()
+        return "char[%d] '%s'" % (len(b), b.decode())
+    w = (np.arange(a.size) % 7 + 1).astype(np.float64)
+    s = float(np.cumsum(a.astype(np.float64) * w)[-1]) if a.size else 0.0    # cumsum adds in order, like the C++ loop
+    return "type%d[%d] wsum=%s" % (_NC_CODE[a.dtype.name], a.size, "%.17g" % s)
+
+
+def _dump_dataset(ds):
+    out = ["dim %s %d" % kv for kv in ds.dims.items()]
+    out += ["gatt %s %s" % (k, _dump_value(v)) for k, v in ds.attrs.items()]
+    for name, v in ds.variables.items():
+        out.append("var %s (%s) %s" % (name, ",".join(v.dims), _dump_value(v.data)))
+        out += ["  att %s %s" % (k, _dump_value(x)) for k, x in v.attrs.items()]
+    return "\n".join(out) + "\n"
+
+
+def _cpp_dump(path):
+    import subprocess
+    return subprocess.run([_ncio_exe(), "dump", str(path)], capture_output=True, text=True)
+
+
+def test_cpp_hdf5_reader_agrees_with_the_python_reader(tmp_path):
+    from icebin_amd import hdf5
+    from test_hdf5 import _handmade_file_with_string_list_attributes
+    # (1) the hand-assembled image: superblock 0, version-1 header, a list of variable-length strings in a global heap
+    p1 = tmp_path / "handmade.nc"
+    p1.write_bytes(_handmade_file_with_string_list_attributes())
+    r = _cpp_dump(p1)
+    assert r.returncode == 0, r.stdout
+    assert r.stdout == _dump_dataset(hdf5.read_netcdf4(str(p1))[0])
+    assert "gatt sheets char[21] 'greenland,antarctica,'" in r.stdout and "gatt shape type4[2] wsum=153344" in r.stdout
+    # (2) scipy's MATLAB 7.3 test file: old-style group (symbol table, local heap), a 512-byte user block, contiguous layout
+    import scipy.io
+    p2 = os.path.join(os.path.dirname(scipy.io.__file__), "matlab", "tests", "data", "testhdf5_7.4_GLNX86.mat")
+    if os.path.exists(p2):
+        r = _cpp_dump(p2)
+        assert r.returncode == 0 and r.stdout == _dump_dataset(hdf5.read_netcdf4(p2)[0])
+        assert "var testdouble (phony_dim_0_9,phony_dim_1_1) type6[9]" in r.stdout
+    # (3) the reference's own NetCDF-4 files: superblock 2, version-2 headers, chunked + deflate + shuffle, dimension scales
+    ref = "/root/reference/examples/example1"
+    if os.path.isdir(ref):
+        for fn in sorted(os.listdir(ref)):
+            if not fn.endswith(".nc"):
+                continue
+            path = os.path.join(ref, fn)
+            r = _cpp_dump(path)
+            assert r.returncode == 0, r.stdout
+            assert r.stdout == _dump_dataset(hdf5.read_netcdf4(path)[0]), fn
+            raw = open(path, "rb").read()
+            # damage: a flipped metadata byte is caught by the checksum; truncation and a broken deflate stream fail loudly
+            bad = bytearray(raw)
+            bad[raw.index(b"OHDR") + 9] ^= 0x40
+            cases = {"flip": bytes(bad), "half": raw[:len(raw) // 2], "tail": raw[:len(raw) - 1000], "head": raw[:200]}
+            for key, img in cases.items():
+                q = tmp_path / (key + ".nc")
+                q.write_bytes(img)
+                r = _cpp_dump(q)
+                assert r.returncode == 1 and r.stdout.startswith("ERROR ncio:") and "hdf5:" in r.stdout, (fn, key, r.stdout)
+                if key == "flip":
+                    assert "checksum" in r.stdout
