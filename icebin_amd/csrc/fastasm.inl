@@ -258,28 +258,19 @@ struct FaP {
     uint32_t *poff;             // [nX] their exclusive scan: the dense id of a new key is
                                 //      poff[its first-seen position] -- for an ice cell poff[ifirst[iI]], no table needed
     int64_t *to_sparse;
-    // the streamed build (streamasm.inl) keeps no per-cell table of dense ids: Pw = new keys before every 64 cells, code = one
-    // byte per cell whose bit 0 says "a key is first seen here" -- the id at cell f is two small reads (sa_prank_at)
+    // the streamed build (streamasm.inl) keeps no per-cell table of dense ids: Pw = new keys before every 64 cells, pbits = one bit per
+    // cell, "a key is first seen here" (the ballots of k_sa_flags) -- the id at cell f is two independent 4 / 8-byte reads (sa_prank_at)
     const uint32_t *Pw;
-    const uint8_t *code;
+    const unsigned long long *pbits;
 };
 // number of P keys first seen before exchange cell f = dense id of the key first seen AT f
-__device__ __forceinline__ uint32_t sa_prank_at(const uint32_t *__restrict__ Pw, const uint8_t *__restrict__ code, long f) {
+__device__ __forceinline__ uint32_t sa_prank_at(const uint32_t *__restrict__ Pw, const unsigned long long *__restrict__ pbits, long f) {
     const long w = f >> 6;
     const int k = (int)(f & 63);
-    uint32_t rnk = Pw[w];
-    const unsigned long long *__restrict__ q = reinterpret_cast<const unsigned long long *>(code + (w << 6));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int nb = k - 8 * j;                                     // bytes of this word that lie before f
-        if (nb <= 0) break;
-        const unsigned long long word = q[j] & 0x0101010101010101ull;
-        rnk += (uint32_t)__popcll(nb >= 8 ? word : (word & ((1ull << (8 * nb)) - 1)));
-    }
-    return rnk;
+    return Pw[w] + (uint32_t)__popcll(pbits[w] & ((1ull << k) - 1ull));
 }
-__device__ __forceinline__ uint32_t fa_poff_at(const uint32_t *__restrict__ poff, const uint32_t *__restrict__ Pw, const uint8_t *__restrict__ code, long f) {
-    return Pw ? sa_prank_at(Pw, code, f) : poff[f];
+__device__ __forceinline__ uint32_t fa_poff_at(const uint32_t *__restrict__ poff, const uint32_t *__restrict__ Pw, const unsigned long long *__restrict__ pbits, long f) {
+    return Pw ? sa_prank_at(Pw, pbits, f) : poff[f];
 }
 __device__ __forceinline__ int fa_class(const RgView &rg, int gkey_kind, long key) {
     if (gkey_kind != KEY_E) return 0;
@@ -288,8 +279,8 @@ __device__ __forceinline__ int fa_class(const RgView &rg, int gkey_kind, long ke
     return (int)hc;
 }
 __device__ __forceinline__ int fa_pdense(const FaP &p, const PlanView &pl, long iI, long x) {
-    if (p.key == KEY_I) return p.fresh ? (int)fa_poff_at(p.poff, p.Pw, p.code, pl.ifirst[iI]) : (int)iI;
-    return p.fresh ? (int)fa_poff_at(p.poff, p.Pw, p.code, x) : (int)x;
+    if (p.key == KEY_I) return p.fresh ? (int)fa_poff_at(p.poff, p.Pw, p.pbits, pl.ifirst[iI]) : (int)iI;
+    return p.fresh ? (int)fa_poff_at(p.poff, p.Pw, p.pbits, x) : (int)x;
 }
 // is the P key of this entry numbered inside range [x0, ...)?  (then its dense ids ascend along x)
 __device__ __forceinline__ bool fa_pnew(const FaP &p, const PlanView &pl, long iI, long x0) {
@@ -907,7 +898,7 @@ __global__ __launch_bounds__(FA_T, (WITH_EP && MODE == 2) ? (ANYORDER ? 1 : 6) :
         const int f = pl.ifirst[q];
         if (only_multi && pl.sx1 > 0 && (f < pl.sx0 || f >= pl.sx1)) return;      // another rank's ice cell
         if (!p.fresh) d = (int)q;
-        else if (f >= 0) d = (int)fa_poff_at(p.poff, p.Pw, p.code, f);
+        else if (f >= 0) d = (int)fa_poff_at(p.poff, p.Pw, p.pbits, f);
         if (!masked) { lb = pl.ilptr[q]; le = pl.ilptr[q + 1]; }      // a masked cell has no entries (identity dims: an empty row / column)
     } else {
         d = p.fresh ? (p.pflag[q] ? (int)p.poff[q] : -1) : (int)q;

@@ -43,6 +43,7 @@ struct SaBuf {
     uint8_t *cntP;          // [nW]        new P keys per 64 cells
     uint32_t *cntL;         // [nW]        row entries per 64 cells (I/X-row matrices)
     uint32_t *Pw, *Lw;      // their exclusive scans
+    unsigned long long *pbits;   // [nW]   the cells of a wave where a P key is first seen (bit = lane): dense id = Pw + popcount below
     // one-class matrices (A rows / A columns): entries first seen in their range / straddling, per 64 cells, their scans, and the
     // scans' values at the start of every range -- the position of an entry inside its range's block follows from these (the
     // elevation-class matrices take it from `rel`, written by k_sa_ranges)
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
         }
         const unsigned long long bp = __ballot(P);
         const long xw = cb + (long)u * SA_T + (tid & ~63);
-        if (lane == 0 && xw < sb.gx1) sb.cntP[xw >> 6] = (uint8_t)__popcll(bp);
+        if (lane == 0 && xw < sb.gx1) { sb.cntP[xw >> 6] = (uint8_t)__popcll(bp); sb.pbits[xw >> 6] = bp; }
         if (!WITH_EP) {
             const unsigned long long bn = __ballot(ent && !old), bo = __ballot(old);
             if (lane == 0 && xw < sb.gx1) { sb.cntE[xw >> 6] = (uint8_t)__popcll(bn); sb.cntO[xw >> 6] = (uint8_t)__popcll(bo); }
@@ -379,7 +380,8 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
     stage_hc<WITH_EP>(rg, s_hc);
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    const long cb = sb.gx0 + (long)blockIdx.x * (SA_T * CPT);
+    long cb = sb.gx0 + (long)blockIdx.x * (SA_T * CPT);
+    const long stride = (long)gridDim.x * (SA_T * CPT);         // (a grid smaller than the slice: every workgroup walks several tiles)
     const REL *__restrict__ rel = static_cast<const REL *>(sb.rel);      // (elevation classes only)
     constexpr int S = WITH_EP ? 2 : 1;
     const bool pkey_x = p.key == KEY_X;
@@ -387,15 +389,25 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
     // round 1: the code bytes and (one address per wave) the range of each wave's first cell; round 2: everything the cells with
     // entries / with a new P key need -- the range of a cell is its wave's first range + the range heads up to its lane (code bit
     // 7), so the per-range values are fetched in the same round as the cell itself; round 3: the mask value (elevation classes)
+    // (a workgroup that walks several tiles issues round 1 of its next tile before it works on this one)
+    unsigned cdn[CPT];
+    int rbn[CPT];
+    auto round1 = [&](long c0) {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const long x = c0 + (long)u * SA_T + tid;
+            const long xw = c0 + (long)u * SA_T + (tid & ~63);
+            cdn[u] = x < sb.gx1 ? sb.code[x] : 0u;
+            rbn[u] = pl.aidx[xw < sb.gx1 ? xw : sb.gx1 - 1];
+        }
+    };
+    round1(cb);
+    for (; cb < sb.gx1; cb += stride) {
     unsigned cd[CPT];
     int rb[CPT];
 #pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-        const long x = cb + (long)u * SA_T + tid;
-        const long xw = cb + (long)u * SA_T + (tid & ~63);
-        cd[u] = x < sb.gx1 ? sb.code[x] : 0u;
-        rb[u] = pl.aidx[xw < sb.gx1 ? xw : sb.gx1 - 1];
-    }
+    for (int u = 0; u < CPT; ++u) { cd[u] = cdn[u]; rb[u] = rbn[u]; }
+    if (cb + stride < sb.gx1) round1(cb + stride);
     const unsigned long long le = lt | (1ull << lane);
     int iIv[CPT], rv[CPT], iAv[CPT], hintv[CPT];
     double av[CPT];
@@ -466,7 +478,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
             int did;
             if (!p.fresh) did = pkey_x ? (int)x : iI;
             else if (pkey_x || (cd[u] & SA_FIRST)) did = pown;
-            else did = (int)sa_prank_at(sb.Pw, sb.code, pl.ifirst[iI]);
+            else did = (int)sa_prank_at(sb.Pw, sb.pbits, pl.ifirst[iI]);
 #pragma unroll
             for (int j = 0; j < S; ++j) {
                 if (j >= ge.n) break;
@@ -530,6 +542,7 @@ __global__ __launch_bounds__(SA_T) void k_sa_emit(RgView rg, PlanView pl, MatSpe
             }
         }
     }
+    }
 }
 
 // ---- S4a: the ice cells across ONE GCM-cell edge (two exchange cells in two ranges: nearly all ice cells with several cells) -----
@@ -553,7 +566,7 @@ __global__ __launch_bounds__(256) void k_sa_pairs(RgView rg, PlanView pl, MatSpe
     // (an A-row matrix without classes needs neither the ranges nor the atmosphere cells: its terms are functions of the areas)
     constexpr bool NEED_R = WITH_EP || !G_ROWS;
     const int r1 = NEED_R ? pl.aidx[x1] : 0, r2 = NEED_R ? pl.aidx[x2] : 0;
-    const int did = p.fresh ? (int)sa_prank_at(sb.Pw, sb.code, x1) : iI;
+    const int did = p.fresh ? (int)sa_prank_at(sb.Pw, sb.pbits, x1) : iI;
     const long iA1 = NEED_R ? pl.riA[r1] : 0, iA2 = NEED_R ? pl.riA[r2] : 0;
     GEnt g1, g2;
     {
@@ -1017,7 +1030,7 @@ __device__ __forceinline__ uint32_t sa_lrank_at(const uint32_t *__restrict__ Lw,
 __global__ void k_sa_slice_counts(SaBuf sb, int p_fresh, int prows, uint32_t *__restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t p0 = 0, p1 = 0, l0 = 0, l1 = 0;
-    if (p_fresh) { p0 = sa_prank_at(sb.Pw, sb.code, sb.sx0); p1 = sa_prank_at(sb.Pw, sb.code, sb.sx1); }
+    if (p_fresh) { p0 = sa_prank_at(sb.Pw, sb.pbits, sb.sx0); p1 = sa_prank_at(sb.Pw, sb.pbits, sb.sx1); }
     if (prows) { l0 = sa_lrank_at(sb.Lw, sb.rl, sb.sx0); l1 = sa_lrank_at(sb.Lw, sb.rl, sb.sx1); }
     out[2] = p1 - p0; out[5] = l1 - l0; out[6] = p0; out[7] = l0;
 }
@@ -1126,7 +1139,8 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         sb.ewbase = A.get<uint32_t>((size_t)nAr); sb.eobase = A.get<uint32_t>((size_t)nAr);
     }
     sb.cntP = A.get<uint8_t>((size_t)nW + 1); sb.Pw = A.get<uint32_t>((size_t)nW + 1);
-    p.Pw = sb.Pw; p.code = sb.code;
+    sb.pbits = A.get<unsigned long long>((size_t)nW + 1);
+    p.Pw = sb.Pw; p.pbits = sb.pbits;
     // counters, 8 per rank, read back with one sync: [0] first out-of-range cell, [1] fallback flags, [2] new P keys, [3] G classes,
     // [4] entries, [5] row entries (I/X-row matrices), [6] / [7] where the slice starts in the local numberings
     uint32_t *d_tot = A.get<uint32_t>((size_t)8 * world);
@@ -1134,6 +1148,7 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     if (world > 1) {     // (one more wave than the slice has: a zero count behind the last one, so that the scans also yield totals)
         IBH_HIP(hipMemsetAsync(sb.cntP + gW1, 0, 1, st));
+        IBH_HIP(hipMemsetAsync(sb.pbits + gW1, 0, 8, st));
         if (!g_is_row && !by_ice) IBH_HIP(hipMemsetAsync(sb.cntL + gW1, 0, sizeof(uint32_t), st));
     }
     if (!uses_ep) {      // (the scans of the entry counts are read AT the end of the last range too)
@@ -1211,13 +1226,14 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     if (world > 1) hipLaunchKernelGGL(k_sa_shift, dim3(ceil_div(std::max<long>(nwl + 1, nr + 1), 256l)), dim3(256), 0, st, p.fresh ? sb.Pw : nullptr, g_is_row ? nullptr : sb.Lw,
                        gW0, nwl + 1, (uint32_t)(P0[rank] - hme[6]), (uint32_t)(L0[rank] - hme[7]), g.gbase, g.ebase, sb.sr0, nr, (uint32_t)G0[rank], (uint32_t)E0[rank]);
     if (world > 1) {                                             // exchange 2: what the ranks look up in each other's slices
-        std::vector<int64_t> oc(world + 1), op(world + 1), oe(world + 1), og(world + 1);
+        // (the code bytes stay at home: every pass reads them inside its own slice only)
+        std::vector<int64_t> op(world + 1), ob(world + 1), oe(world + 1), og(world + 1);
         for (int k = 0; k <= world; ++k) {
             const long wk = k == world ? nW : (X[k] >> 6);
-            oc[k] = wk * 64; op[k] = wk * 4; oe[k] = (int64_t)R[k] * g.NC; og[k] = (int64_t)R[k] * 4;
+            op[k] = wk * 4; ob[k] = wk * 8; oe[k] = (int64_t)R[k] * g.NC; og[k] = (int64_t)R[k] * 4;
         }
-        void *bases[4] = {sb.code, sb.Pw, g.erank, g.gbase};
-        const int64_t *offs[4] = {oc.data(), op.data(), oe.data(), og.data()};
+        void *bases[4] = {sb.Pw, sb.pbits, g.erank, g.gbase};
+        const int64_t *offs[4] = {op.data(), ob.data(), oe.data(), og.data()};
         comm_gatherv(comm, 4, bases, offs, st);
         hipLaunchKernelGGL(k_sa_set_u32, dim3(1), dim3(1), 0, st, g.gbase + nAr, (uint32_t)G0[world]);
     }
@@ -1246,14 +1262,22 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     const dim3 grq1(ceil_div(nr, 4), g.NC == 1 ? 1 : std::max(1, std::min(std::min(g.NC, 16), (int)(hme[3] / (uint32_t)std::max(nr, 1)) + 2)));
     double *sval = nullptr;
     int32_t *sdid = nullptr;
-    const int ecpt = get_tuning("assemble_stream_emit_cpt", 2);      // cells per thread of the emit pass (measured: 4 / 2 / 1 -> a1h EvI 1.34 / 1.27 / 1.28 ms)
+    // cells per thread of the emit pass x workgroups (0 = one per tile).  The pass is bound by instruction issue and latency, not by
+    // bandwidth (ablation on the Antarctic AvI: 129 us with every load of cell data, every term and every store removed; stores +95,
+    // the first-seen lookup of the straddlers +45 after the bitmask change, +115 before): a workgroup that walks several tiles has the
+    // code bytes of its next tile in flight while it works.  Measured, a1h AvI / IvA / EvI / IvE ms, same box: 2 x full grid 0.645 /
+    // 0.915 / 1.216 / 1.604; 1 x full 0.704 / 0.919 / 1.228 / 1.555; 1 x 8192 0.636 / 0.878 / 1.135 / 1.470; 2 x 8192 0.642 / 0.926 /
+    // 1.183 / 1.574; 4 x full 0.709 / 1.063 / 1.274 / 1.711
+    const int ecpt = get_tuning("assemble_stream_emit_cpt", 1);
     const long ncell = sb.gx1 - sb.gx0;
+    const long eblocks = get_tuning("assemble_stream_emit_blocks", 8192);
+    auto egrid = [&](int cpt) { const long full = ceil_div(ncell, (long)SA_T * cpt); return dim3((unsigned)(eblocks > 0 ? std::min(full, eblocks) : full)); };
 #define SA_LAUNCH_EMIT(EP, GR)                                                                                                  \
     do {                                                                                                                        \
-        if (rel32) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint32_t, 4>), gs, dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
-        else if (ecpt == 2) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 2>), dim3(ceil_div(ncell, (long)SA_T * 2)), dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
-        else if (ecpt == 1) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 1>), dim3(ceil_div(ncell, (long)SA_T)), dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
-        else hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 4>), gs, dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid);       \
+        if (rel32) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint32_t, 4>), egrid(4), dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
+        else if (ecpt == 2) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 2>), egrid(2), dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
+        else if (ecpt == 1) hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 1>), egrid(1), dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid); \
+        else hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 4>), egrid(4), dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid);       \
     } while (0)
     sb.end_row = nrow; sb.end_nnz = nnz;
     if (by_ice) {                                                // the row pointer over the ice cells (closes itself: rowptr[nI] = nnz); wM of non-members

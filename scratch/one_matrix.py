@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import icebin_amd
 from icebin_amd import _capi, synthetic as syn
-cfg, name, nf = sys.argv[1], sys.argv[2], 64
+cfg, name, nf = sys.argv[1], sys.argv[2], int(os.environ.get("NF", "64"))
 for k, v in [kv.split("=") for kv in os.environ.get("TUNE", "").split(",") if kv]: icebin_amd.set_tuning(k, int(v))
 g = syn.make_grids(cfg); em = syn.dome_elevmask(g)
 rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em, scale=True, correctA=True)
