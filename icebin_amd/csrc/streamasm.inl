@@ -921,6 +921,183 @@ __global__ __launch_bounds__(256) void k_sa_rows1(RgView rg, PlanView pl, FaG g,
     }
 }
 
+// ---- S5, lane-parallel: SIXTEEN segments per wave, one lane per chain ---------------------------------------------------------------
+// The two kernels above spend a whole 64-lane instruction on every term of a chain (v_readlane + v_add_f64: ~3 vector instructions
+// per term; the pass is bound by instruction issue, not by its reads -- 138 us for the 17.6 M terms of the Antarctic AvI).  Here a wave
+// takes R consecutive ranges and deals their segments to lanes 0..15, sixteen at a time: all 64 lanes fetch -- 128 consecutive values
+// (1 KB) of each of the sixteen segments per step -- and park them in LDS, row = segment (129 doubles apart: sixteen lanes reading
+// one column hit sixteen banks); lane s then adds row s in sequence.  A step moves 16 KB with 32 loads, 32 LDS writes, 128 LDS
+// reads and 128 dependent adds: ~0.15 instructions per term.  Lanes whose segment has ended add +0.0 (the chains start from +0.0, so no
+// partial sum is ever -0.0: adding +0.0 changes no bit).  The straddlers are sorted into place beforehand by k_sa_oldsort (a wave per
+// range: sixteen segments' sorts one after the other inside this kernel cost more than all its chains); scaling re-reads the segment.
+template <int OLDSEG>
+__global__ __launch_bounds__(256) void k_sa_oldsort(FaG g, int32_t *__restrict__ ids, double *__restrict__ val, int sr0, int sr1) {
+    __shared__ int s_did[4][OLDSEG];
+    __shared__ double s_t[4][OLDSEG];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = sr0 + (int)blockIdx.x * 4 + wv;
+    if (r >= sr1) return;
+    const int ncls = (int)g.r_ncls[r];
+    const uint32_t eb = g.ebase[r];
+    int rank = -1;
+    uint32_t seg = 0, nold_c = 0;
+    if (lane < g.NC) {
+        rank = g.erank[(size_t)r * g.NC + lane];
+        nold_c = g.ecnto[(size_t)r * g.NC + lane];
+        seg = g.ecntn[(size_t)r * g.NC + lane] + nold_c;
+    }
+    if (!__ballot(nold_c != 0)) return;
+    for (int q = 0; q < ncls; ++q) {
+        const unsigned long long mq = __ballot(rank == q);
+        if (!mq) break;
+        const int cls = __builtin_ctzll(mq);
+        uint32_t no = (uint32_t)__builtin_amdgcn_readlane((int)nold_c, cls);
+        if (no == 0) continue;
+        if (no > (uint32_t)OLDSEG) no = OLDSEG;                  // (the build is being discarded: FA_ERR_OLDOVER; stay inside the tables)
+        const uint32_t b = eb + (uint32_t)__builtin_amdgcn_readfirstlane((int)sa_wave_sum_u32((rank >= 0 && rank < q) ? seg : 0u));
+        for (uint32_t k = lane; k < no; k += 64) { s_did[wv][k] = ids[b + k]; s_t[wv][k] = val[b + k]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = lane; k < no; k += 64) {               // inside a class the ids are distinct: rank by counting
+            const int did = s_did[wv][k];
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < no; ++j) cnt += s_did[wv][j] < did ? 1u : 0u;
+            ids[b + cnt] = did; val[b + cnt] = s_t[wv][k];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_sa_rowsL(RgView rg, PlanView pl, FaG g, FaOut o, int sr0, int sr1, int R) {
+    constexpr int K = 128, SEGS = 16;
+    __shared__ double s_buf[4][SEGS][K + 1];
+    __shared__ double s_mul[4][SEGS];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = sr0 + ((int)blockIdx.x * 4 + wv) * R;
+    if (r0 >= sr1) return;
+    const int nrange = min(R, sr1 - r0);
+    // the segments of these ranges, in (range, first-seen rank of the class) order: `off` = segments of the ranges before lane's
+    const uint32_t ncls_l = lane < nrange ? g.r_ncls[r0 + lane] : 0u;
+    const uint32_t off_l = sa_wave_excl_u32(ncls_l, lane);
+    const int T = (int)__builtin_amdgcn_readfirstlane((int)sa_wave_sum_u32(ncls_l));
+    for (int base = 0; base < T; base += SEGS) {
+        const int j = base + lane;
+        const bool valid = lane < SEGS && j < T;
+        int ri = 0, q = 0;
+        for (int i = 0; i < nrange; ++i) {
+            const int oi = __builtin_amdgcn_readlane((int)off_l, i), ni = __builtin_amdgcn_readlane((int)ncls_l, i);
+            if (j >= oi && j < oi + ni) { ri = i; q = j - oi; }
+        }
+        const int r = r0 + ri;
+        int cls = 0;
+        uint32_t start = 0, sg = 0, no = 0;
+        if (valid) {
+            if (g.NC == 1) { no = g.ecnto[r]; sg = g.ecntn[r] + no; }
+            else {
+                for (int c = 0; c < g.NC; ++c) {
+                    const int rk = g.erank[(size_t)r * g.NC + c];
+                    if (rk < 0 || rk > q) continue;
+                    const uint32_t co = g.ecnto[(size_t)r * g.NC + c], cn = g.ecntn[(size_t)r * g.NC + c];
+                    if (rk < q) start += cn + co;
+                    else { cls = c; no = co; sg = cn + co; }
+                }
+            }
+        }
+        const uint32_t b = valid ? g.ebase[r] + start : 0u, e = b + sg;
+        const long iA = valid ? pl.riA[r] : 0;
+        const long gkey = g.key == KEY_E ? iA * rg.sA + (long)cls * rg.sHC : iA;
+        const int gd = valid ? fa_gdense(g, r, cls, gkey) : -1;
+        double sum = 0.0;
+        // the chains (the straddlers, sorted into place by k_sa_oldsort, then the entries first seen in the range): a step = the next K
+        // values of each of the sixteen segments, fetched
+        // by whole-wave loads (64 consecutive values of ONE segment per instruction; position and remaining length of a segment are
+        // read from its lane into scalar registers), issued one step ahead of the adds
+        uint32_t cur = b, left = e - b;                          // (this lane's own chain)
+        double v[2 * SEGS];
+        auto fetch = [&]() {
+#pragma unroll
+            for (int i = 0; i < 2 * SEGS; ++i) {
+                const uint32_t c_s = (uint32_t)__builtin_amdgcn_readlane((int)cur, i >> 1), l_s = (uint32_t)__builtin_amdgcn_readlane((int)left, i >> 1);
+                const uint32_t k = (uint32_t)((i & 1) * 64 + lane);
+                v[i] = k < l_s ? o.val[c_s + k] : 0.0;
+            }
+            cur += K;
+            left = left > (uint32_t)K ? left - K : 0u;
+        };
+        bool more = __ballot(left != 0) != 0;
+        if (more) fetch();
+        while (more) {
+#pragma unroll
+            for (int i = 0; i < 2 * SEGS; ++i) s_buf[wv][i >> 1][(i & 1) * 64 + lane] = v[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            more = __ballot(left != 0) != 0;
+            if (more) fetch();                                   // (the next step's values fly while this one's are added)
+            if (lane < SEGS) {
+#pragma unroll
+                for (int h = 0; h < K; h += 32) {
+                    double t[32];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) t[k] = s_buf[wv][lane][h + k];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) sum = sum + t[k];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // weights, scaling
+        double mul = 1.0;
+        const bool live = valid && gd >= 0;                      // (a key the pre-populated set lacks: the build is discarded, FA_ERR_MISSING)
+        if (live) {
+            if (g.to_sparse) g.to_sparse[gd] = gkey;
+            if (EMIT) {                                          // FAM_AEVI rows (RegridMatrices_Dynamic.cpp:100-146)
+                double wM;
+                if (o.correctA) {
+                    const double rr = ratio_of(rg, g.key, gkey);
+                    wM = rr * sum;
+                    if (o.scale) mul = (1.0 / rr) * (1.0 / sum);
+                } else {
+                    wM = sum;
+                    if (o.scale) mul = 1.0 / sum;
+                }
+                o.wM[gd] = wM;
+                o.rowptr[gd] = (int32_t)b;
+            } else o.Mw[gd] = o.correctA ? ratio_of(rg, g.key, gkey) * sum : sum;      // FAM_IVAE columns (:201-233)
+        }
+        if (EMIT && o.scale) {
+            // the sixteen segments of a round are one contiguous block of entries: the wave streams over it, eight loads in flight per
+            // lane, every entry times the factor of the segment it lies in (ends of the segments in scalar registers, factors in LDS)
+            const int nv = min(SEGS, T - base);
+            if (lane < SEGS) s_mul[wv][lane] = live ? mul : 1.0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t es[SEGS];
+#pragma unroll
+            for (int q2 = 0; q2 < SEGS; ++q2) es[q2] = q2 < nv ? (uint32_t)__builtin_amdgcn_readlane((int)e, q2) : 0xffffffffu;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b, 0), hi = (uint32_t)__builtin_amdgcn_readlane((int)e, nv - 1);
+            for (uint32_t k0 = lo; k0 < hi; k0 += 512) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t k = k0 + 64u * u + lane;
+                    x[u] = k < hi ? o.val[k] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t k = k0 + 64u * u + lane;
+                    int sgi = 0;
+#pragma unroll
+                    for (int q2 = 0; q2 < SEGS - 1; ++q2) sgi += es[q2] <= k ? 1 : 0;
+                    if (k < hi) o.val[k] = s_mul[wv][sgi] * x[u];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 // ---- all exclusive scans of a build in TWO launches ------------------------------------------------------------------------------
 // (new P keys per 64 cells, row entries per 64 cells, classes and entries per range: four channels that the generic scans served
@@ -1260,6 +1437,16 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     const dim3 grq(ceil_div(rows_waves, rows_wpb), rows_y);
     // (long ranges: one wave per (range, class), y = the classes a range has on average, rounded up, + 1)
     const dim3 grq1(ceil_div(nr, 4), g.NC == 1 ? 1 : std::max(1, std::min(std::min(g.NC, 16), (int)(hme[3] / (uint32_t)std::max(nr, 1)) + 2)));
+    // the lane-parallel row kernel (k_sa_oldsort + k_sa_rowsL), R ranges per wave.  Measured on the Antarctic sheet, same box, against
+    // the kernels above: the column sums of IvE 42 + 149 us against 231 (IvE 1.55 -> 1.43 ms, IvA 0.937 -> 0.910), the rows of AvI 25 +
+    // 143 against 138, of EvI 42 + 340 against 270 -- a wave with sixteen chains waits for its memory round trips with two waves per
+    // SIMD (66 KB of LDS per workgroup), and R = 4 beats 16: more waves matter more than full lanes.  1 km Greenland (1 143 long
+    // ranges) loses by 2 x.  So: column sums of grids with many ranges only.
+    const int forced_rl = get_tuning("assemble_stream_rowsl", -1);
+    const bool rowsl = forced_rl >= 0 ? forced_rl != 0 : (!g_is_row && nr >= 16384);
+    const int avg_cls = g.NC == 1 ? 1 : std::max(1, (int)((hme[3] + (uint32_t)std::max(nr, 1) - 1) / (uint32_t)std::max(nr, 1)));
+    const int rows_R = std::max(1, std::min(16, get_tuning("assemble_stream_rowsl_r", std::min(4, 16 / avg_cls))));
+    const dim3 grl(ceil_div(nr, 4 * rows_R));
     double *sval = nullptr;
     int32_t *sdid = nullptr;
     // cells per thread of the emit pass x workgroups (0 = one per tile).  The pass is bound by instruction issue and latency, not by
@@ -1298,7 +1485,11 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
             if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
             else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl3, *sp, g, p, merge, (long)P.nmulti3, o, (uint32_t *)nullptr, flags, 1);
         }
-        if (rows4) hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_S, 4>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
+        if (rowsl) {
+            if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_oldsort<SA_OLDSEG_S>), gr4, dim3(256), 0, st, g, o.colind, o.val, sb.sr0, sb.sr1);
+            else hipLaunchKernelGGL((k_sa_oldsort<SA_OLDSEG_L>), gr4, dim3(256), 0, st, g, o.colind, o.val, sb.sr0, sb.sr1);
+            hipLaunchKernelGGL((k_sa_rowsL<true>), grl, dim3(256), 0, st, rg, pl, g, o, sb.sr0, sb.sr1, rows_R);
+        } else if (rows4) hipLaunchKernelGGL((k_sa_rows<true, SA_OLDSEG_S, 4>), grq, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
         else if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows1<true, SA_OLDSEG_S>), grq1, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
         else hipLaunchKernelGGL((k_sa_rows1<true, SA_OLDSEG_L>), grq1, dim3(256), 0, st, rg, pl, g, o, (int32_t *)nullptr, sb.sr0, sb.sr1);
     } else {
@@ -1322,7 +1513,11 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         if (!g_fresh && ncol) hipLaunchKernelGGL(k_fa_zero_identity, dim3(ceil_div(ncol, T)), dim3(T), 0, st, w->Mw.p, (long)ncol);
         FaOut os = o;
         os.val = sval;
-        if (rows4) hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_S, 4>), grq, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
+        if (rowsl) {
+            if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_oldsort<SA_OLDSEG_S>), gr4, dim3(256), 0, st, g, sdid, sval, sb.sr0, sb.sr1);
+            else hipLaunchKernelGGL((k_sa_oldsort<SA_OLDSEG_L>), gr4, dim3(256), 0, st, g, sdid, sval, sb.sr0, sb.sr1);
+            hipLaunchKernelGGL((k_sa_rowsL<false>), grl, dim3(256), 0, st, rg, pl, g, os, sb.sr0, sb.sr1, rows_R);
+        } else if (rows4) hipLaunchKernelGGL((k_sa_rows<false, SA_OLDSEG_S, 4>), grq, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
         else if (oldseg == SA_OLDSEG_S) hipLaunchKernelGGL((k_sa_rows1<false, SA_OLDSEG_S>), grq1, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
         else hipLaunchKernelGGL((k_sa_rows1<false, SA_OLDSEG_L>), grq1, dim3(256), 0, st, rg, pl, g, os, sdid, sb.sr0, sb.sr1);
     }

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out/s25
+timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "streamed_build or random_sorted_grids" > gpurun_out/s25/pytest.log 2>&1
+rc=$?; echo "pytest rc=$rc"; tail -15 gpurun_out/s25/pytest.log
+[ $rc -eq 0 ] || exit 1
+o=gpurun_out/s25/rows.txt; : > $o
+for t in "" "assemble_stream_rowsl=1" "assemble_stream_rowsl=1,assemble_stream_rowsl_r=8" "assemble_stream_rowsl=1,assemble_stream_rowsl_r=4"; do
+  echo "== $t" >> $o
+  TUNE=$t python scratch/time_assembly.py a1h AvI,IvA,EvI,IvE 2>&1 | grep -v amdgpu >> $o
+  TUNE=$t python scratch/time_assembly.py g1 AvI,IvA,EvI,IvE 2>&1 | grep -v amdgpu >> $o
+done
+cat $o

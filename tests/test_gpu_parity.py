@@ -2043,6 +2043,8 @@ def test_random_sorted_grids_on_every_variant_of_the_plan_based_build(seed):
         icebin_amd.set_tuning("assemble_stream_count", 1)
         icebin_amd.set_tuning("assemble_range_shape", seed % 3)
         icebin_amd.set_tuning("assemble_static_count", seed % 2)
+        icebin_amd.set_tuning("assemble_stream_rowsl", (seed // 2) % 2)        # (the lane-parallel row kernel of the streamed build ...
+        icebin_amd.set_tuning("assemble_stream_rowsl_r", (1, 3, 16, 5, 2)[seed % 5])      # ... and its ranges per wave)
         for stream in (0, 1):                   # the per-range kernels (fastasm.inl), then the streamed build (streamasm.inl)
             icebin_amd.set_tuning("assemble_stream", stream)
             fast = streamed = 0
@@ -2055,13 +2057,14 @@ def test_random_sorted_grids_on_every_variant_of_the_plan_based_build(seed):
             assert fast >= 12, fast             # (EvA / AvE with negative areas, and little else, go to the general pipeline)
             assert streamed == (16 if stream else 0), (stream, streamed)       # all but EvA / AvE
     finally:
-        for k in ("assemble_stream_count", "assemble_range_shape", "assemble_static_count", "assemble_stream"):
+        for k in ("assemble_stream_count", "assemble_range_shape", "assemble_static_count", "assemble_stream", "assemble_stream_rowsl", "assemble_stream_rowsl_r"):
             icebin_amd.set_tuning(k, -2 ** 31)
 
 
+@pytest.mark.parametrize("rowsl", [0, 1])
 @pytest.mark.parametrize("config,variant", [("g50", "sorted"), ("g50", "zero_area"), ("g50", "negative_area"), ("g50", "elev_class"),
                                             ("g20", "sorted"), ("g20", "x_fastest"), ("g5", "sorted")])
-def test_streamed_build_is_the_oracle_bitwise(config, variant):
+def test_streamed_build_is_the_oracle_bitwise(config, variant, rowsl):
     """The streamed build (streamasm.inl: what grids of 2^20 exchange cells and more take) forced on the oracle-sized grids:
     the eight matrices it serves x the four (scale, correctA) branches, own dims; identity I / X sets where it serves them;
     the coupler's shared dimE, also permuted and incomplete -- every bit of dims / CSR / wM / Mw against the oracle."""
@@ -2087,6 +2090,7 @@ def test_streamed_build_is_the_oracle_bitwise(config, variant):
                                                       ("g50", "elev_class"): 4}.get((config, variant), -2 ** 31))
         icebin_amd.set_tuning("assemble_stream_oldseg", 512 if variant in ("x_fastest", "zero_area") else -2 ** 31)   # (the table size of the straddler sort)
         icebin_amd.set_tuning("assemble_stream_rows4", {"sorted": 1, "negative_area": 0, "elev_class": 1}.get(variant, -2 ** 31))   # (segments per wave of the row kernel)
+        icebin_amd.set_tuning("assemble_stream_rowsl", rowsl)       # (1: the lane-parallel row kernel, sixteen chains per wave)
         for scale, correctA in ((True, True), (False, False), (True, False), (False, True)):
             rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
             for name in names:
@@ -2122,6 +2126,7 @@ def test_streamed_build_is_the_oracle_bitwise(config, variant):
         icebin_amd.set_tuning("assemble_stream_wpr", -2 ** 31)
         icebin_amd.set_tuning("assemble_stream_oldseg", -2 ** 31)
         icebin_amd.set_tuning("assemble_stream_rows4", -2 ** 31)
+        icebin_amd.set_tuning("assemble_stream_rowsl", -2 ** 31)
 
 
 @pytest.mark.parametrize("nA_real,nX", [(12, 150000), (60, 200000)])
