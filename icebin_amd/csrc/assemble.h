@@ -11,6 +11,9 @@ namespace ibh {
 // whole matrix; the ranks share the work when the build is one the streamed path serves, and build redundantly otherwise
 bool assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_sparse_set *dim0, ibh_sparse_set *dim1,
                      int scale, int correctA, const double sigma[3], ibh_weighted **out, bool fast_only = false, ibh_comm *comm = nullptr);
+// the per-ice-cell class bytes of an elevmask (ibh_regrid_matrices::em_cls), made on `stream` when the streamed build will serve this grid
+// (returns false otherwise); d_src != nullptr: read the elevations there and fill rm->elevmaskI (allocated) in the same pass
+bool elevmask_classes(const ibh_regrid_matrices *rm, hipStream_t stream, const double *d_src = nullptr);
 // n builds with the results of n matrix_d calls in order; independent ones run concurrently (assemble.hip assemble_batch)
 void assemble_batch(const ibh_regrid_matrices *rm, int n, const char *const *specs, ibh_sparse_set *const *dim0,
                     ibh_sparse_set *const *dim1, const int32_t *scale, const int32_t *correctA, const double sigma[3],

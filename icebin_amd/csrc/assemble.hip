@@ -1991,6 +1991,13 @@ bool build_groups_from_csr(const ibh_weighted *cw, hipStream_t st) {
 #include "fastasm.inl"
 #include "streamasm.inl"
 
+bool elevmask_classes(const ibh_regrid_matrices *rm, hipStream_t stream, const double *d_src) {
+    const ibh_regridder *gr = rm->rg;
+    if (gr->nhc > 64 || !get_tuning("assemble_stream", gr->nX >= (1l << 20) ? 1 : 0)) return false;      // (not a grid of the streamed build: the first build that wants the bytes makes them)
+    elevmask_classes_impl(rm, stream, d_src);
+    return true;
+}
+
 // ---- RegridMatrices_Dynamic::matrix_d ----------------------------------------------------------
 static const MatSpec *find_spec(const char *spec_name) {
     const MatSpec *sp = nullptr;

@@ -325,6 +325,7 @@ int ibh_regrid_matrices_create(const ibh_regridder *rg, const double *elevmaskI,
         if (sigma) for (int k = 0; k < 3; ++k) rm->sigma[k] = sigma[k];
         rm->elevmaskI.upload(elevmaskI, (size_t)n);
         IBH_HIP(hipStreamSynchronize(nullptr));
+        elevmask_classes(rm.get(), nullptr);
         *out = rm.release();
     });
 }
@@ -342,7 +343,8 @@ int ibh_regrid_matrices_create_device(const ibh_regridder *rg, const double *d_e
         if (sigma) for (int k = 0; k < 3; ++k) rm->sigma[k] = sigma[k];
         hipStream_t st = static_cast<hipStream_t>(stream);
         rm->elevmaskI.alloc((size_t)n);
-        IBH_HIP(hipMemcpyAsync(rm->elevmaskI.p, d_elevmaskI, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        if (!elevmask_classes(rm.get(), st, d_elevmaskI))       // (large grids: the copy and the class bytes in one pass)
+            IBH_HIP(hipMemcpyAsync(rm->elevmaskI.p, d_elevmaskI, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
         IBH_HIP(hipStreamSynchronize(st));
         *out = rm.release();
     });

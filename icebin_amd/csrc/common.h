@@ -1,6 +1,7 @@
 // common.h -- internal helpers of libicebin_hip.so (error channel, device buffers, handle layouts).
 #pragma once
 #include <atomic>
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -212,6 +213,13 @@ struct ibh_regrid_matrices {
     ibh::DevBuf<double> elevmaskI;      // [nI] copy (RegridMatrices_Dynamic.cpp:352)
     int scale = 1, correctA = 0;
     double sigma[3] = {0, 0, 0};
+    // one byte per ice cell, a function of its elevation and the regridder's elevation classes alone (ibh::elevmask_classes,
+    // streamasm.inl): 0xFF masked, 0xFE elevation beyond the last class (linterp_1d_b's error), else first class | classes << 6.
+    // Made once per elevmask -- at creation for grids the streamed build serves, else by the first build that wants it -- and read by
+    // every matrix of this object in place of the 8-byte elevation wherever only the mask or the class pattern matters.
+    mutable ibh::DevBuf<uint8_t> em_cls;
+    mutable int em_cls_nhc = -1, em_cls_interp = -1;
+    mutable std::mutex em_cls_mu;
 };
 
 namespace ibh {

@@ -120,18 +120,52 @@ __device__ __forceinline__ SaCls sa_classes(const RgView &rg, double e) {
     return k;
 }
 
+// The same per ICE cell, once per elevmask (ibh_regrid_matrices::em_cls): what k_sa_flags needs of an elevation is its mask bit and
+// its class pattern, so the per-matrix pass gathers one byte per exchange cell instead of eight (the Antarctic AvI: 558 -> ~230 MB
+// fetched by that pass) and does no class search.
+__global__ __launch_bounds__(256) void k_em_classes(RgView rg, long nI, uint8_t *__restrict__ out, double *__restrict__ copy_to) {
+    __shared__ double s_hc[HC_LDS];
+    stage_hc<true>(rg, s_hc);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nI) return;
+    const double e = rg.em[i];
+    if (copy_to) copy_to[i] = e;                                 // (creation from a device array: the object's own copy in the same pass)
+    uint8_t b;
+    if (e != e) b = 0xFF;
+    else if (rg.nhc < 1) b = 0;
+    else {
+        const SaCls k = sa_classes(rg, e);
+        b = k.err ? (uint8_t)0xFE : (uint8_t)(k.c0 | (k.ncls << 6));
+    }
+    out[i] = b;
+}
+// src: the caller's device array when the object's own copy is still to be made (then it is made here)
+static const uint8_t *elevmask_classes_impl(const ibh_regrid_matrices *rm, hipStream_t st, const double *src = nullptr) {
+    const ibh_regridder *gr = rm->rg;
+    std::lock_guard<std::mutex> lk(rm->em_cls_mu);
+    if (!src && rm->em_cls.p && rm->em_cls_nhc == gr->nhc && rm->em_cls_interp == gr->interp_style) return rm->em_cls.p;
+    IBH_CHECK(gr->nhc <= 64, "more than 64 elevation classes");
+    if (!rm->em_cls.p) rm->em_cls.alloc((size_t)std::max<int64_t>(gr->nI, 1));
+    RgView rg{};
+    rg.em = src ? src : rm->elevmaskI.p; rg.hc = gr->hcdefs.p; rg.nhc = gr->nhc; rg.interp = gr->interp_style;
+    if (gr->nI) hipLaunchKernelGGL(k_em_classes, dim3((unsigned)ceil_div(gr->nI, 256l)), dim3(256), 0, st, rg, (long)gr->nI, rm->em_cls.p,
+                                   src ? rm->elevmaskI.p : (double *)nullptr);
+    IBH_HIP(hipGetLastError());
+    IBH_HIP(hipStreamSynchronize(st));                           // (builds on other streams read it next)
+    rm->em_cls_nhc = gr->nhc; rm->em_cls_interp = gr->interp_style;
+    return rm->em_cls.p;
+}
+
 // pkey_x: the P side is keyed by exchange cells (nothing merges); p_list: the list that makes an exchange cell a member of an X
 // set (LIST_AP / LIST_EP); prows: I/X-row matrix (row lengths wanted)
 template <bool WITH_EP>
 __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf sb, int pkey_x, int p_fresh, int p_list, int prows,
-                                                   uint32_t *__restrict__ err_x) {
-    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
-    stage_hc<WITH_EP>(rg, s_hc);
+                                                   uint32_t *__restrict__ err_x, const uint8_t *__restrict__ emc) {
     const int tid = threadIdx.x, lane = tid & 63;
     const long cb = sb.gx0 + (long)blockIdx.x * SA_TILE;
     int iIv[SA_CPT];
     unsigned fl[SA_CPT];
-    double ev[SA_CPT];
+    unsigned ev[SA_CPT];                                         // the ice cell's byte: mask and class pattern (k_em_classes)
 #pragma unroll
     for (int u = 0; u < SA_CPT; ++u) {
         const long x = cb + (long)u * SA_T + tid;
@@ -139,12 +173,12 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
         iIv[u] = pl.exI[xx]; fl[u] = pl.isdup[xx];
     }
 #pragma unroll
-    for (int u = 0; u < SA_CPT; ++u) ev[u] = rg.em[iIv[u]];
+    for (int u = 0; u < SA_CPT; ++u) ev[u] = emc[iIv[u]];
 #pragma unroll
     for (int u = 0; u < SA_CPT; ++u) {
         const long x = cb + (long)u * SA_T + tid;
         const bool in = x < sb.gx1;
-        const bool unm = in && !(ev[u] != ev[u]);
+        const bool unm = in && ev[u] != 0xFFu;
         const bool head = pkey_x || !(fl[u] & 1);
         unsigned ga = fl[u] & 24;                                  // sign classes of the areas of the group this cell heads
         if (!pkey_x && head && (fl[u] & 128))
@@ -152,9 +186,8 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
         const bool gpos = (ga & 8) != 0, gnz = ga != 0;
         int n = 0, c0 = 0, ncls_e = 0;
         if (WITH_EP && unm) {
-            const SaCls k = sa_classes(rg, ev[u]);
-            if (k.err) atomicMin(err_x, (uint32_t)x);
-            else { ncls_e = k.ncls; c0 = k.c0; n = (head && gnz) ? k.ncls : 0; }
+            if (ev[u] == 0xFEu) atomicMin(err_x, (uint32_t)x);
+            else { ncls_e = (int)(ev[u] >> 6); c0 = (int)(ev[u] & 63u); n = (head && gnz) ? ncls_e : 0; }
         }
         const bool ent = head && unm && (WITH_EP ? n > 0 : gpos);
         bool P;
@@ -1260,6 +1293,8 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     if (world > 1 && (pmode != 1 || !g_fresh || world > 8 || P.nAr < world)) return false;
     const int merge = (sp->row_key != KEY_X && sp->col_key != KEY_X) ? 1 : 0;
     const int S = uses_ep ? 2 : 1;
+    if (gr->nhc > 64) return false;
+    const uint8_t *emc = elevmask_classes_impl(rm, st);          // (made when the object was created, or here by the first build)
     const bool rel32 = (int64_t)S * P.maxrange > 65535;
 
     Arena &A = arena();
@@ -1333,8 +1368,8 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         IBH_HIP(hipMemsetAsync(sb.cntO + gW1, 0, 1, st));
     }
     const dim3 gs(ceil_div(sb.gx1 - sb.gx0, (long)SA_TILE)), gr4(ceil_div(nr, 4));
-    if (uses_ep) hipLaunchKernelGGL((k_sa_flags<true>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt);
-    else hipLaunchKernelGGL((k_sa_flags<false>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt);
+    if (uses_ep) hipLaunchKernelGGL((k_sa_flags<true>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt, emc);
+    else hipLaunchKernelGGL((k_sa_flags<false>), gs, dim3(SA_T), 0, st, rg, pl, sb, pkey == KEY_X ? 1 : 0, p.fresh, plist, g_is_row ? 0 : 1, d_cnt, emc);
     const long mean = nX / std::max(nAr, 1);
     // (straddlers of a range ~ its perimeter: a range of ~10^3 cells has a few dozen, one of 10^4 a few hundred)
     const int forced_os = get_tuning("assemble_stream_oldseg", -1);

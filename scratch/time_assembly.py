@@ -10,6 +10,11 @@ for cfg in sys.argv[1].split(","):
     mm = icebin_amd.from_synthetic(g)
     rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
     nX, nI = len(g["ex_area"]), g["nI"]
+    # what every matrix of an elevmask shares: the object's copy of the mask and (grids of the streamed build) one class byte per ice cell
+    em_dev = torch.from_numpy(em).cuda(); tc = []
+    for _ in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); rm2 = mm.regrid_matrices("greenland", em_dev, scale=True, correctA=True); torch.cuda.synchronize(); tc.append(time.perf_counter() - t0); del rm2
+    print("%-5s regrid_matrices(elevmask in HBM), once per elevmask: %9.3f ms  (copy of %.1f MB%s)" % (cfg, min(tc) * 1e3, 8 * nI / 1e6, " + class bytes" if nX >= 1 << 20 else ""), flush=True)
     for name in sys.argv[2].split(","):
         w = rm.matrix(name); torch.cuda.synchronize()
         ts = []
