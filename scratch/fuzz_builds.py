@@ -20,6 +20,13 @@ for seed in range(first, first + count):
         icebin_amd.set_tuning("assemble_stream_count", seed % 2)
         icebin_amd.set_tuning("assemble_range_shape", seed % 3)
         icebin_amd.set_tuning("assemble_static_count", (seed // 2) % 2)
+        # the streamed build (what grids of 2^20 cells and more take) on every third seed, its row kernels and tile walk varied
+        icebin_amd.set_tuning("assemble_stream", 1 if seed % 3 == 0 else -2 ** 31)
+        icebin_amd.set_tuning("assemble_stream_rowsl", (seed // 3) % 2)
+        icebin_amd.set_tuning("assemble_stream_rowsl_r", (1, 4, 16, 7)[(seed // 6) % 4])
+        icebin_amd.set_tuning("assemble_stream_rows4", (seed // 12) % 2)
+        icebin_amd.set_tuning("assemble_stream_emit_blocks", (0, 1, 3, 8192)[(seed // 3) % 4])
+        icebin_amd.set_tuning("assemble_stream_emit_cpt", (1, 2, 4)[(seed // 9) % 3])
         nfast = 0
         for name in T.ALL:
             for scale, correctA in ((True, True), (False, False), (True, False)):
