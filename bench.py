@@ -394,6 +394,22 @@ def main():
                     ks += [ms / m for ms, (m, _, _, _) in zip(read_pairs(kev), pc)]
                 cc[nb] = ks
             extras["cold_check"] = cc
+            # what this box's HBM delivers to plain streams ("also report vs a measured device copy / triad bandwidth"):
+            # torch's own kernels over 2 GiB, far beyond the 256 MB Infinity Cache -- a read-only sum, a write-only fill, a copy
+            try:
+                n64 = (2 << 30) // 8
+                sa = torch.empty(n64, dtype=torch.float64, device=dev).fill_(1.0)
+                sb_ = torch.empty(n64, dtype=torch.float64, device=dev)
+                def stream_rate(fn, nbytes):
+                    fn(); torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); fn(); fn(); fn(); e1.record(); torch.cuda.synchronize()
+                    return 3 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                extras["streams"] = {"read_GBs": stream_rate(lambda: sa.sum(), 8 * n64), "write_GBs": stream_rate(lambda: sb_.fill_(2.0), 8 * n64),
+                                     "copy_GBs": stream_rate(lambda: sb_.copy_(sa), 16 * n64)}
+                del sa, sb_
+            except Exception as e:      # noqa: BLE001  (a side measurement: never fails the bench)
+                extras["streams"] = {"error": str(e)[:120]}
 
     # ---- cross-rank correctness of the gathered results (N > 1 path; also at N = 1 under torchrun) -----------------
     gather_check = None
@@ -470,6 +486,12 @@ def main():
                                      "achieved": B / (k_us * 1e-6) / 1e9, "kernel_us_min": min(ks) * 1e3, "kernel_us_max": max(ks) * 1e3,
                                      "samples": len(ks), "wall_us_per_apply": median(ws) * 1e6, "kernel": W.last_kernel(),
                                      "what": "ONE apply() per launch (ibh_weighted_apply_device), same matrix, same rotating batches"}
+        if extras.get("streams"):
+            st_ = dict(extras["streams"])
+            if "read_GBs" in st_:
+                st_["achieved_over_measured_read"] = roof["achieved"] / st_["read_GBs"] if roof.get("achieved") else None
+                st_["what"] = "plain streams on this box, torch kernels over 2 GiB (read-only sum / write-only fill / copy, bytes moved per second): the practical ceilings beside the 8 TB/s spec peak `frac` is priced against"
+            roof["measured_streams"] = st_
         if extras.get("cold_check"):
             roof["cold_check"] = {"kernel_us_per_apply_by_rotating_batches": {str(nb): median(v) * 1e3 for nb, v in extras["cold_check"].items()},
                                   "batch_MB": xbytes / 1e6, "infinity_cache_MB": 256,
