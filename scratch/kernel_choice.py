@@ -6,6 +6,7 @@ import numpy as np, torch
 import icebin_amd
 from icebin_amd import _capi, synthetic as syn
 cfg, name = sys.argv[1], sys.argv[2]
+for k, v in [kv.split("=") for kv in os.environ.get("TUNE", "").split(",") if kv]: icebin_amd.set_tuning(k, int(v))
 nfs = [int(v) for v in sys.argv[3].split(",")]
 kernels = (sys.argv[4] if len(sys.argv) > 4 else "auto,rowblock,rowdual,colsweep,rowgroup").split(",")
 g = syn.make_grids(cfg); em = syn.dome_elevmask(g)

@@ -36,13 +36,18 @@ __global__ __launch_bounds__(256) void k_chain(const int *__restrict__ rowptr, c
     if (r >= nrow) return;
     int c; double v;
     const int beg = rowptr[r], end = rowptr[r + 1];
-    if (MODE == 0) { c = colind[beg]; v = vals[beg]; } else { c = col0[r]; v = val0[r]; }
+    if (MODE != 1) { c = colind[beg]; v = vals[beg]; } else { c = col0[r]; v = val0[r]; }
     if (end - beg != 1) v = 0.0;
     for (int f0 = 0; f0 < nf; f0 += G) {
         double a[G];
         const d2 *p = reinterpret_cast<const d2 *>(XT + (long)c * ldt + f0);
 #pragma unroll
         for (int g = 0; g < G; g += 2) { const d2 x = p[g >> 1]; a[g] = v * x.x; a[g + 1] = v * x.y; }
+        if (MODE == 2) {                                             // a second entry per row (IvE: the two classes of an ice cell)
+            const d2 *q = reinterpret_cast<const d2 *>(XT + (long)(c + 7 + (r & 1)) * ldt + f0);
+#pragma unroll
+            for (int g = 0; g < G; g += 2) { const d2 x = q[g >> 1]; a[g] = fma(v, x.x, a[g]); a[g + 1] = fma(v, x.y, a[g + 1]); }
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) __builtin_nontemporal_store(a[g], Y + (long)(f0 + g) * ldy + r);
     }
@@ -80,7 +85,7 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL(k_fill_chain, dim3((unsigned)((nrow + 256) / 256)), dim3(256), 0, 0, rowptr, colind, vals, col0, val0, nrow, ncol);
         const double Bc = 8.0 * nrow * nf + 16.0 * nrow;
 #define RUNC(G, MODE) time([&](int i) { hipLaunchKernelGGL((k_chain<G, MODE>), dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, 0, rowptr, colind, vals, col0, val0, XT, ldt, Y + (long)(i % nbuf) * ldy * nf, ldy, nrow, nf); }, "chain mode " #MODE " planes/phase " #G, Bc)
-        RUNC(4, 0); RUNC(8, 0); RUNC(16, 0); RUNC(4, 1); RUNC(8, 1); RUNC(16, 1);
+        RUNC(4, 0); RUNC(8, 0); RUNC(16, 0); RUNC(4, 1); RUNC(8, 1); RUNC(16, 1); RUNC(4, 2); RUNC(8, 2); RUNC(16, 2);
     }
     time([&](int i) { hipLaunchKernelGGL(k_flat, dim3((unsigned)((ldy * nf / 2 + 255) / 256)), dim3(256), 0, 0, Y + (long)(i % nbuf) * ldy * nf, ldy * nf); }, "flat stream, 16 B per thread", 8.0 * ldy * nf);
     time([&](int i) { hipMemsetAsync(Y + (long)(i % nbuf) * ldy * nf, 0, 8 * ldy * nf, 0); }, "hipMemsetAsync", 8.0 * ldy * nf);
