@@ -136,7 +136,12 @@ typedef struct ibh_weighted ibh_weighted;
 
 /* RegridMatrices: GCMRegridder_Standard::regrid_matrices
  * (RegridMatrices_Dynamic.cpp:334-402; Cython shim new_regrid_matrices,
- * icebin_cython.cpp:215-236).  Copies elevmaskI (length must equal nI) to HBM. */
+ * icebin_cython.cpp:215-236).  Copies elevmaskI (length must equal nI) to HBM.  For a grid of 2^20
+ * exchange cells and more the call also derives one byte per ice cell from its elevation (masked /
+ * beyond the last elevation class / first class and class count): every matrix built from this
+ * object reads that byte where only the mask or the class pattern matters (36 M ice cells: 0.22 ms
+ * for copy + bytes against 0.13 ms for the copy alone; smaller grids make the bytes when a build
+ * first asks).  Results are unaffected. */
 typedef struct ibh_regrid_matrices ibh_regrid_matrices;
 int ibh_regrid_matrices_create(const ibh_regridder *rg, const double *elevmaskI, int64_t n,
                                int scale, int correctA, const double sigma[3],
