@@ -715,9 +715,80 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     // loads and stores together in issue order, so a gather issued after a store would wait for that
     // store's (long) write acknowledgement; with G == fields per thread there is one load phase and
     // one store phase per thread.
+    // SHARED columns (XT, groups of <= 8 fields): rows of one GCM cell follow each other in a fresh ice dimension, so for every entry
+    // slot most lanes of a wave name the SAME column.  That column's X values come through scalar loads and feed the FMAs as scalar
+    // operands; only the lanes that differ (the ice cells along the cell's edge: two per grid-row segment) gather theirs, and a gather
+    // costs the texture path by its ACTIVE lanes.  A full-wave gather of 16 bytes per lane is 16 cycles per CU whatever the addresses:
+    // the time of this kernel followed the entries of the longest row of a wave, not the bytes (16.3 M rows, 128 fields: 3.0 / 4.0 /
+    // 5.3 ms at 1 / 2 / 4 entries in every row; 4.9 with 2 and 4 in 7 % of the rows, scattered: the Antarctic IvE).
+    constexpr bool SHARED = XT && G <= 4;
+    int ucA[4] = {0, 0, 0, 0}, ucB[4] = {0, 0, 0, 0};
+    bool mineA[4] = {false, false, false, false}, mineB[4] = {false, false, false, false};     // this lane's entry e sits in shared column A / B
+    bool hasB[4] = {false, false, false, false};     // (wave-uniform) a second shared column
+    bool leftover = false;                           // (wave-uniform) lanes in neither: the wave takes the gather form below
+    int nmax = 0;
+    bool shared_ok = SHARED && __ballot(n > 4) == 0;      // (a smoothed matrix has longer rows: the gather form, too)
+    if (shared_ok) {
+        const int cc[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long he = __ballot(n > e);
+            if (!he) break;
+            nmax = e + 1;
+            // A: the column of the first or of the last lane that has the entry, whichever more lanes name; B: the column of the
+            // first lane outside A (a class boundary or a cell edge inside the wave)
+            const int ca = __builtin_amdgcn_readlane(cc[e], __builtin_ctzll(he)), cb = __builtin_amdgcn_readlane(cc[e], 63 - __builtin_clzll(he));
+            const unsigned long long ma = __ballot(n > e && cc[e] == ca), mb = __ballot(n > e && cc[e] == cb);
+            ucA[e] = __popcll(ma) >= __popcll(mb) ? ca : cb;
+            mineA[e] = n > e && cc[e] == ucA[e];
+            const unsigned long long rest = __ballot(n > e && !mineA[e]);
+            if (rest) {
+                hasB[e] = true;
+                ucB[e] = __builtin_amdgcn_readlane(cc[e], __builtin_ctzll(rest));
+                mineB[e] = n > e && !mineA[e] && cc[e] == ucB[e];
+                leftover = leftover || __ballot(n > e && !mineA[e] && !mineB[e]) != 0;
+            }
+        }
+    }
+    shared_ok = shared_ok && !leftover;
     for (int f0 = fbeg; f0 < fend; f0 += G) {
         double acc[G];
-        if (XT) {
+        if (shared_ok) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = 0.0;
+            const double vv[4] = {v0, v1, v2, v3};
+            // all loads of the group first (scalar: wave-uniform addresses)
+            double sa[4][G], sb[4][G];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e >= nmax) break;
+                const double *__restrict__ pa = X + (long)ucA[e] * ldx + f0;     // (wave-uniform addresses: scalar loads)
+#pragma unroll
+                for (int g = 0; g < G; ++g) sa[e][g] = pa[g];
+                if (hasB[e]) {
+                    const double *__restrict__ pb = X + (long)ucB[e] * ldx + f0;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) sb[e][g] = pb[g];
+                }
+            }
+            // the products, entry by entry in every lane (the row's order): never multiplied by a padded zero (0*NaN)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e >= nmax) break;
+                if (mineA[e]) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g] = e == 0 ? vv[e] * sa[e][g] : fma(vv[e], sa[e][g], acc[g]);
+                }
+                if (hasB[e] && mineB[e]) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g] = e == 0 ? vv[e] * sb[e][g] : fma(vv[e], sb[e][g], acc[g]);
+                }
+            }
+            if (dead) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = fill;
+            }
+        } else if (XT) {
             // entry by entry, G fields at a time (f0 is a multiple of G, rows of XT are padded to 16 fields)
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[g] = 0.0;

@@ -17,7 +17,23 @@ wM = np.ones(nrow); Mw = np.ones(ncol)
 rowptr = np.asarray(rowptr); colind = np.asarray(colind); val = np.asarray(val)
 print(cfg, name, "nrow", nrow, "ncol", ncol, "nnz", len(val), "entries/row", len(val) / nrow, "distinct col changes along the entries: %.3f per entry" % (np.count_nonzero(np.diff(colind)) / len(colind)), flush=True)
 d = np.abs(np.diff(colind.astype(np.int64)))
+cnt = np.diff(rowptr); print("   row lengths:", np.bincount(cnt)[:12], "waves (64 rows) with a row > 4:", float(np.mean(np.maximum.reduceat(cnt, np.arange(0, len(cnt), 64)) > 4)), flush=True)
 print("   |delta col| between consecutive entries: median %d, 90%% %d, max %d" % (np.median(d), np.percentile(d, 90), d.max()), flush=True)
+# per wave of 64 rows and entry slot: how many rows name the column the kernel would share (first / last row's, the more frequent)
+nw = nrow // 64
+for e in range(4):
+    has = cnt[:nw * 64] > e
+    ce = np.where(has, colind[np.minimum(rowptr[:nw * 64] + e, len(colind) - 1)], -1).reshape(nw, 64)
+    first = ce[:, 0]; last = ce[:, -1]
+    ma = (ce == first[:, None]).sum(1); mb = (ce == last[:, None]).sum(1)
+    best = np.maximum(ma, mb)
+    A = np.where(ma >= mb, first, last)        # (first / last lane having the entry would be exact; lanes 0 / 63 as a stand-in)
+    restm = (ce != A[:, None]) & (ce >= 0)
+    idx = restm.argmax(1); Bc = np.where(restm.any(1), ce[np.arange(nw), idx], -2)
+    left = restm & (ce != Bc[:, None])
+    print("   entry %d: waves that have it %.3f; with lanes outside A %.3f; outside A and B %.3f (mean %.1f lanes there)" % (e, float(np.mean((ce >= 0).any(1))), float(np.mean(restm.any(1))), float(np.mean(left.any(1))), float(left.sum(1)[left.any(1)].mean()) if left.any() else 0.0), flush=True)
+    print("   entry %d: rows per wave in the shared column: mean %.1f of 64; waves with >= 56: %.3f; distinct columns per wave: mean %.2f" % (e, best.mean(), float(np.mean(best >= 56)), float(np.mean([len(np.unique(r)) for r in ce[::997]]))), flush=True)
+print("   first rows, (row: cols):", [(int(r), colind[rowptr[r]:rowptr[r + 1]].tolist()) for r in range(100000, 100012)], flush=True)
 L = _capi.lib(); fn = L.ibh_weighted_apply_device
 cs = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 rng = np.random.default_rng(1)
