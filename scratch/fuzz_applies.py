@@ -9,6 +9,7 @@ import icebin_amd
 import test_gpu_parity as T
 from icebin_amd import synthetic as syn
 orc = T.orc
+for k, v in [kv.split("=") for kv in os.environ.get("TUNE", "").split(",") if kv]: icebin_amd.set_tuning(k, int(v))      # e.g. shortrow_xt=1,shortrow_group=4
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 30
