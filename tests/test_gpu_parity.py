@@ -1530,6 +1530,54 @@ def test_shortrow_variants_on_edge_sizes(nrow):
         set_tuning("shortrow_xt", -1)
 
 
+@pytest.mark.parametrize("pattern", ["cell_by_cell", "two_columns", "scattered", "long_rows"])
+def test_shortrow_shared_columns_are_bitwise_the_gather_form(pattern):
+    """The I-row kernel with groups of four fields takes, wave by wave, the X values of the <= 2 columns per entry slot that its
+    lanes share through scalar loads (spmm.hip "SHARED"); groups of eight never do.  Rows numbered cell by cell with edge rows of
+    2-4 entries (the Antarctic IvA / IvE shape), waves with exactly two columns per slot, scattered columns (every wave falls
+    back), rows of more than four entries (fallback), NaN fields, a dead row, a partial last wave: the two forms agree bit for bit
+    and with numpy."""
+    import torch
+    from icebin_amd.linear import linear_Weighted
+    rng = np.random.default_rng({"cell_by_cell": 1, "two_columns": 2, "scattered": 3, "long_rows": 4}[pattern])
+    nrow, ncol, nf = 64 * 37 + 19, 300, 20
+    r = np.arange(nrow)
+    if pattern == "cell_by_cell":       # runs of 45 rows per "GCM cell" x 2 classes, the first and last row of a run with four entries
+        cell = r // 45
+        cols = [[2 * c, 2 * c + 1] if (k % 45) not in (0, 44) else ([2 * c - 2, 2 * c - 1, 2 * c, 2 * c + 1] if k % 45 == 0 and c > 0 else [2 * c, 2 * c + 1, 2 * c + 2, 2 * c + 3])
+                for k, c in zip(r, cell)]
+    elif pattern == "two_columns":      # every wave: lanes < 40 one column pair, the others another
+        cols = [[(k // 64) % 100, 100 + (k // 64) % 100] if k % 64 < 40 else [(k // 64) % 100 + 1, 200 + (k // 64) % 90] for k in r]
+    elif pattern == "scattered":
+        cols = [sorted(rng.choice(ncol, rng.integers(0, 5), replace=False).tolist()) for _ in r]
+    else:                               # most rows one entry in the wave's column, one row in 50 with seven
+        cols = [[(k // 64) % ncol] if k % 50 else sorted(rng.choice(ncol, 7, replace=False).tolist()) for k in r]
+    cnt = np.array([len(c) for c in cols])
+    rowptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    colind = np.array([c for cc in cols for c in cc], np.int32)
+    val = rng.standard_normal(len(colind))
+    wM = np.ones(nrow); wM[777] = 0.0
+    W = linear_Weighted.from_csr((nrow, ncol), rowptr, colind, val, wM, np.ones(ncol))
+    W.set_kernel("shortrow")
+    x = rng.standard_normal((nf, ncol)); x[3, ::7] = np.nan
+    xd = torch.from_numpy(x).cuda()
+    out = {}
+    for grp in (4, 8):
+        W.set_option("shortrow_xt", 1); W.set_option("shortrow_group", grp); W.set_option("shortrow_fper", 8)
+        out[grp] = W.apply_device(xd, fill=-3.0).cpu().numpy().copy()
+    assert np.array_equal(out[4], out[8], equal_nan=True)
+    ref = np.full((nf, nrow), 0.0)
+    for k in range(nrow):
+        acc = np.zeros(nf)
+        for j in range(rowptr[k], rowptr[k + 1]):
+            acc = (val[j] * x[:, colind[j]]) if j == rowptr[k] else acc + val[j] * x[:, colind[j]]
+        ref[:, k] = acc
+    ref[:, 777] = -3.0
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isnan(out[4]), np.isnan(ref))
+    assert np.max(np.abs(out[4][ok] - ref[ok])) <= 1e-13 * max(1.0, np.max(np.abs(ref[ok])))
+
+
 def test_column_sums_with_long_columns():
     """Mw (column sums in ascending row order) when a few ice cells are overlapped by MANY atmosphere
     cells: the short-column path (assemble.hip k_col_sums) takes its selection branch (3..64 entries)
