@@ -57,6 +57,7 @@ if has a1h; then
   done
   timeout -k 10 600 python3 scratch/kernel_choice.py a1h AvI 16,128 auto 2>&1 | grep nf= > $out/apply_a1h_one_launch.txt
   timeout -k 10 600 python3 scratch/kernel_choice.py a1h IvA 16,128 auto 2>&1 | grep nf= >> $out/apply_a1h_one_launch.txt
+  timeout -k 10 600 python3 scratch/kernel_choice.py a1h IvE 16,128 auto 2>&1 | grep nf= >> $out/apply_a1h_one_launch.txt
   timeout -k 10 600 python3 scratch/kernel_choice.py a1h EvI 16,128 auto,rowblock,colsweep,rowgroup 2>&1 | grep nf= >> $out/apply_a1h_one_launch.txt
 fi
 if has table; then
