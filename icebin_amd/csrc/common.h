@@ -106,6 +106,9 @@ struct DevBuf {
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 constexpr int IBH_GSLOTS = 32;      // most rows (elevation classes of one GCM cell) in a row group (spmm.hip rowgroup)
+// tiles of a row group (spmm.hip grouptile): seg = items (distinct columns) of a tile, 256 or 128 by the matrix (ibh_weighted::gt_seg)
+constexpr int ibh_gt_ecap(int seg) { return 2 * seg + 4 * IBH_GSLOTS; }   // entries of a tile: <= 2 per item, every slot's list padded to a multiple of 4
+constexpr int IBH_GT_EP = IBH_GSLOTS + 2;   // u16 entry offsets of a tile: one per slot + the end, padded to whole dwords
 inline int bits_for(uint64_t n) {   // bits needed to represent values in [0, n)
     int b = 0;
     while (b < 64 && (n > (1ull << b))) ++b;
@@ -290,6 +293,13 @@ struct ibh_weighted {
     mutable ibh::DevBuf<int32_t> grp_ptr, grp_ns, grp_slotrow, grp_col; // [grp_n+1] items of a group; [grp_n] rows of a group; [grp_n*IBH_GSLOTS]; [nitems]
     mutable ibh::DevBuf<uint32_t> grp_meta;
     mutable ibh::DevBuf<double> grp_v0, grp_v1;
+    // grouptile (spmm.hip): the items of a group cut into TILES of gt_seg columns; per tile the columns (padded by repeating
+    // the last) and the entries sorted by (slot, column) as {8 x local item index, weight} with u16 offsets per slot -- the rows of
+    // the CSR restricted to the tile, in CSR order.  Entries of tile t start at ibh_gt_ecap(gt_seg) * t.
+    mutable int32_t gt_ntile = 0, gt_seg = 0;            // 0: not built
+    mutable ibh::DevBuf<int32_t> gt_ptr, gt_col;         // [grp_n+1] tiles of a group; [gt_ntile * gt_seg]
+    mutable ibh::DevBuf<uint16_t> gt_ek, gt_eptr;        // [gt_ntile * ecap]; [gt_ntile * IBH_GT_EP]
+    mutable ibh::DevBuf<double> gt_ev;                   // [gt_ntile * ecap]
     mutable bool have_rowsum1 = false;
     mutable ibh::DevBuf<int32_t> rowperm;                // rows by descending length (batched rowblock launches)
     mutable bool have_rowperm = false;

@@ -640,6 +640,260 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView 
 // tables), 24-29 with full tables (two workgroups per CU).  What bounds this kernel is the LDS pipe, not the gathers: per item
 // and field it moves ~56 bytes through LDS (col, meta, two weights, two read-modify-write adds) where the A-row kernel moves 12.
 
+// ---- grouptile: the row groups with X staged through LDS and register sums (round 5) ---------------------------------------------
+// What bounded the row-group kernel above was the LDS pipe: wave = field, lane = column, so every wave re-read each item's
+// {col, meta, v0, v1} and issued two ds_add_f64 per item (~56 B through LDS per item and field).  Here the roles are turned:
+// the columns of a group are cut into TILES of SEG = 256 or 128 items (assemble.hip build_group_tiles); a workgroup serves (group, F
+// fields, F = 16 or 32) and for every tile
+//   1. gathers X[f, col[k]] for the tile's items -- lane = item, one field per load, exactly the gathers of the kernel above:
+//      every X element once per GCM cell, whole lines -- into an LDS tile s_x[f][k];
+//   2. walks the tile's ENTRIES, sorted by (slot, item) = the rows of the CSR restricted to the tile, in QUADS of four entries
+//      of one slot (the lists are padded to fours with {zero column, weight 0}): lane = (sublane j, field f), J = 64 / F sublanes;
+//      a sublane reads its entry of the quad -- {8 k, v}, two LDS reads broadcast within the sublane -- then x = s_x[f][k] (one
+//      conflict-free ds_read_b64) and does one FMA into a REGISTER: the slot of a quad is wave-uniform.  ~20 B through LDS per
+//      entry and field, no atomics, no read-modify-write, no predicate.
+// Which wave sums what is static, so the sums stay in registers across tiles: every slot's list of a tile is cut into SP parts
+// (SP = the largest power of two with SP * ns <= 32, by the group's number of rows ns -- a GCM cell of two classes keeps all
+// waves busy as one of sixteen does); the units u = s * SP + part, in this order, are dealt to the waves in contiguous, balanced
+// ranges -- consecutive units are consecutive quads of the tile's list, so a wave walks ONE run of quads per tile and only
+// switches its accumulator on the way.
+// Summation order of (row, field): entry e of a part's run of the tile goes to partial sum e mod 4, tiles ascending; per part
+// (p0 + p1) + (p2 + p3); parts ascending -- fixed by the matrix alone, so one apply, a batch, every field count and both F
+// agree bitwise.
+struct TileView {
+    const int *gptr, *tptr, *tcol;
+    const unsigned short *ek, *eptr;
+    const double *ev;
+    const int *ns, *slotrow;
+    int ngrp;
+    long long *dbg;     // scratch/r05 timeline builds only (GT_TIMELINE): 16 stamps per workgroup
+};
+#ifdef GT_TIMELINE
+#define GT_STAMP(i) do { if (tv.dbg && threadIdx.x == 0 && blockIdx.y == 0) tv.dbg[(long)blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define GT_STAMP_W(i) do { if (tv.dbg && lane == 0 && blockIdx.y == 0) tv.dbg[(long)blockIdx.x * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define GT_STAMP(i) do {} while (0)
+#define GT_STAMP_W(i) do {} while (0)
+#endif
+#ifndef GT_WPS
+#define GT_WPS 4
+#endif
+#ifndef GT_ULIMIT
+#define GT_ULIMIT 16
+#endif
+#ifndef GT_BATCH
+#define GT_BATCH 4
+#endif
+constexpr int GT_TABP = 65;          // row stride of the epilogue's table of partial sums [unit][lane]
+template <int F, int SEG>
+constexpr size_t grouptile_lds() { return (size_t)F * (SEG + 2) * 8 + ibh_gt_ecap(SEG) * 10 + 256; }     // (+ slack: a batch reads a few steps past its run)
+// sums of the two 32-lane halves of a wave: lo = lanes 0..31, hi = lanes 32..63, each in the order wave_sum adds a wave whose
+// other half is zero
+__device__ __forceinline__ void wave_half_sums(double v, double &lo, double &hi) {
+    v += dpp_move<0xB1, 0xf>(v);
+    v += dpp_move<0x4E, 0xf>(v);
+    v += dpp_move<0x141, 0xf>(v);
+    v += dpp_move<0x140, 0xf>(v);
+    v += dpp_move<0x142, 0xa>(v);    // row_bcast15 into rows 1,3: lane 31 = rows 0+1, lane 63 = rows 2+3
+    lo = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 31), __builtin_amdgcn_readlane(__double2loint(v), 31));
+    hi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+template <int F, int NS, int SEG, int NW, bool PAIR = false>
+__global__ __launch_bounds__(NW * 64, GT_WPS) void spmm_grouptile_kernel(const TileView tv, const BatchPtrs bp, long ldx, int ncol, long ldy, int nf,
+                                                                            int nfc, int xcd_mode, const double *__restrict__ wM, double fill,
+                                                                            const PairView pv = PairView{})
+{
+    constexpr int NB = SEG / 64, T = NW * 64, SEGP = SEG + 2, ECAP = ibh_gt_ecap(SEG);
+    constexpr int FW = F / (NW / NB);                   // fields a wave gathers for its 64 items
+    constexpr int EPT = (ECAP + T - 1) / T;      // entries staged per thread
+    constexpr int J = 64 / F, R = 4 / J;                // sublanes; entries of a quad per sublane = partial sums per lane and unit
+    constexpr int OS = ((NS > GT_ULIMIT ? NS : GT_ULIMIT) + NW - 1) / NW;     // most units (slot, part) of a wave: groups of <= NS rows
+    static_assert(F == 16 || F == 32, "fields per workgroup");
+    static_assert(NW % NB == 0 && F % (NW / NB) == 0, "shape");
+    extern __shared__ double gt_lds[];
+    double *s_x = gt_lds;                                                // [F][SEGP]; columns SEG, SEG + 1 stay zero
+    double *s_ev = s_x + F * SEGP;                                       // [ECAP]
+    unsigned short *s_ek = reinterpret_cast<unsigned short *>(s_ev + ECAP);      // [ECAP]
+    double *s_tab = gt_lds;                                              // epilogue: [R][32 units][GT_TABP], over s_x
+    int g, fc;
+    if (!block_to_task(blockIdx.x, tv.ngrp, nfc, xcd_mode, g, fc)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    GT_STAMP(0);
+    const double *__restrict__ X = bp.x[blockIdx.y];
+    double *__restrict__ Y = bp.y[blockIdx.y];
+    const int t0 = tv.tptr[g], t1 = tv.tptr[g + 1], ns = tv.ns[g];
+    const int nitems = tv.gptr[g + 1] - tv.gptr[g];
+    GT_STAMP(1 + 0 * (t0 + t1 + ns + nitems));
+    const int ib = wave % NB, fg = wave / NB;           // this wave gathers items [64 ib, 64 ib + 64) for fields [FW fg, FW fg + FW)
+    const int j = lane / F, f = lane % F;
+    // parts per slot: the largest power of two with sp * ns <= 32; this wave's units [ub, ue)
+    constexpr int UL = GT_ULIMIT;                       // most units of a group
+    static_assert(UL == 32 || UL == 16, "units");
+    const int lsp = ns * 16 <= UL ? 4 : ns * 8 <= UL ? 3 : ns * 4 <= UL ? 2 : ns * 2 <= UL ? 1 : 0;
+    const int nunit = ns << lsp;
+    const int ub = (wave * nunit) / NW, ue = ((wave + 1) * nunit) / NW;
+    if (threadIdx.x < 2 * F) s_x[(threadIdx.x >> 1) * SEGP + SEG + (threadIdx.x & 1)] = 0.0;
+
+    double x[FW];
+    double evv[EPT];
+    unsigned short ekk[EPT];
+    // The HEAD of a tile -- the columns of this wave's 64 items and the tile's row of entry offsets (one per slot, lane i of every
+    // wave holds offset i) -- is fetched one tile BEFORE its X values and entries are: inside the loop a tile costs one memory
+    // round trip (its gathers, issued with addresses already in registers), not two, and the unit boundaries come out of
+    // registers (v_readlane) instead of LDS.
+    int c_nxt = 0, ep_nxt = 0;
+    auto tile_n = [&](int t) { return min(SEG, nitems - (t - t0) * SEG); };
+    auto load_head = [&](int t) {
+        if (ib * 64 < tile_n(t)) c_nxt = tv.tcol[(long)t * SEG + ib * 64 + lane];
+        ep_nxt = tv.eptr[(long)t * IBH_GT_EP + min(lane, IBH_GT_EP - 1)];
+    };
+    auto load_tile = [&](int t, int c, int ne) {        // into registers; flies while the previous tile is summed
+        if (ib * 64 < tile_n(t)) {
+            const int off = c << 3;
+#pragma unroll
+            for (int i = 0; i < FW; ++i) {
+                const int fw = fc * F + fg * FW + i;
+                const __amdgpu_buffer_rsrc_t rs =
+                    __builtin_amdgcn_make_buffer_rsrc((void *)(X + (long)(fw < nf ? fw : nf - 1) * ldx), 0, ncol * 8, 0x00020000);
+                x[i] = xload(rs, off);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = threadIdx.x + i * T;
+            if (e < ne) { ekk[i] = tv.ek[(long)t * ECAP + e]; evv[i] = tv.ev[(long)t * ECAP + e]; }
+        }
+    };
+    auto store_tile = [&](int t) {
+        if (ib * 64 < tile_n(t)) {
+#pragma unroll
+            for (int i = 0; i < FW; ++i) s_x[(fg * FW + i) * SEGP + ib * 64 + lane] = x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {                 // (beyond the tile's entries: stale values nobody uses)
+            const int e = threadIdx.x + i * T;
+            if (e < ECAP) { s_ek[e] = ekk[i]; s_ev[e] = evv[i]; }
+        }
+    };
+
+    double acc[OS][R];
+#pragma unroll
+    for (int o = 0; o < OS; ++o)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[o][r] = 0.0;
+    // per lane: field f's row of the X tile; this sublane's entry of step 0 (weights); the entry whose item a lane fetches for a batch
+    const char *a_x = reinterpret_cast<const char *>(s_x) + f * SEGP * 8;
+    const char *a_ev = reinterpret_cast<const char *>(s_ev) + j * 8;
+    const char *a_ek = reinterpret_cast<const char *>(s_ek) + (J * (lane & 15) + j) * 2;
+
+    int ep_cur = 0;
+    if (t0 < t1) {
+        load_head(t0);
+        const int c0 = c_nxt;
+        ep_cur = ep_nxt;
+        if (t0 + 1 < t1) load_head(t0 + 1);
+        load_tile(t0, c0, __builtin_amdgcn_readlane(ep_cur, IBH_GSLOTS));
+    }
+    for (int t = t0; t < t1; ++t) {
+        if (t != t0) __syncthreads();                   // every wave is done with the previous tile
+        if (t == t0) GT_STAMP(2); else if (t == t0 + 1) GT_STAMP(6);
+        store_tile(t);
+        if (t == t0) GT_STAMP(3); else if (t == t0 + 1) GT_STAMP(7);
+        __syncthreads();
+        if (t == t0) GT_STAMP(4); else if (t == t0 + 1) GT_STAMP(8);
+        const int ep = ep_cur;
+        if (t + 1 < t1) {
+            const int c = c_nxt;
+            ep_cur = ep_nxt;
+            if (t + 2 < t1) load_head(t + 2);
+            load_tile(t + 1, c, __builtin_amdgcn_readlane(ep_cur, IBH_GSLOTS));
+        }
+        __builtin_amdgcn_sched_barrier(0);              // (the loads above fly while the tile is summed: nothing of them sinks below)
+        if (t == t0) GT_STAMP(13);
+        // Unit o of this wave = steps [B[o], B[o + 1]) of the tile's list (a step = J entries x F fields), walked in batches of
+        // 8 steps: lane 16 r + i fetches the item index 8 k of the entry that step i of the batch hands to sublane r / (F / 16) --
+        // one LDS read per lane and batch; a DPP row broadcast folded into the address add then gives every step its X
+        // address, the weights come as broadcast reads at fixed offsets, and the 16 reads of a batch are in flight together.
+        int B[OS + 1];
+#pragma unroll
+        for (int o = 0; o <= OS; ++o) {
+            const int u = min(ub + o, ue);              // (o past this wave's units: the end of its run)
+            const int uu = min(u, nunit - 1);
+            const int sl = uu >> lsp, part = u >= nunit ? (1 << lsp) : (u & ((1 << lsp) - 1));
+            const int lb = __builtin_amdgcn_readlane(ep, sl) >> 2, nq = (__builtin_amdgcn_readlane(ep, sl + 1) >> 2) - lb;
+            B[o] = (lb + ((nq * part) >> lsp)) * R;
+        }
+        if (t == t0) { GT_STAMP(14); if (tv.dbg && threadIdx.x == 0 && blockIdx.y == 0) tv.dbg[(long)blockIdx.x * 16 + 15] = ((long long)(B[OS] - B[0]) << 32) | (unsigned)(B[1] - B[0]); }
+#pragma unroll
+        for (int o = 0; o < OS; ++o) {
+            for (int p0 = B[o]; p0 < B[o + 1]; p0 += GT_BATCH) {
+                const int nb = B[o + 1] - p0;
+                const int mk = *reinterpret_cast<const unsigned short *>(a_ek + p0 * J * 2);
+                const char *pv = a_ev + p0 * J * 8;
+                double xx[GT_BATCH], vv[GT_BATCH];
+#define GT_XR(S)                                                                                                                          \
+                xx[S] = *reinterpret_cast<const double *>(a_x + __builtin_amdgcn_update_dpp(0, mk, 0x150 + (S), 0xf, 0xf, false));        \
+                vv[S] = *reinterpret_cast<const double *>(pv + (S) * J * 8)
+#define GT_FM(S) if ((S) < nb) acc[o][(S) % R] = fma(vv[S], xx[S], acc[o][(S) % R])
+                GT_XR(0); GT_XR(1); GT_XR(2); GT_XR(3);
+#if GT_BATCH == 8
+                if (nb > 4) { GT_XR(4); GT_XR(5); GT_XR(6); GT_XR(7); }
+#endif
+                GT_FM(0); GT_FM(1); GT_FM(2); GT_FM(3);
+#if GT_BATCH == 8
+                if (nb > 4) { GT_FM(4); GT_FM(5); GT_FM(6); GT_FM(7); }
+#endif
+#undef GT_XR
+#undef GT_FM
+            }
+        }
+        if (t == t0) GT_STAMP(5); else if (t == t0 + 1) GT_STAMP(9);
+    }
+    GT_STAMP(10);
+    __syncthreads();                                    // s_x is done: the partial sums take its place
+    GT_STAMP(11);
+#pragma unroll
+    for (int o = 0; o < OS; ++o)
+        if (ub + o < ue) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) s_tab[(r * 32 + ub + o) * GT_TABP + lane] = acc[o][r];
+        }
+    __syncthreads();
+    // thread -> (field, slot): lanes 0..31 of a wave are the slots of one field, lanes 32..63 those of the next
+    const int sl = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < F / (2 * NW); ++i) {
+        const int fl = 2 * (wave * (F / (2 * NW)) + i) + half, fw = fc * F + fl;
+        double y1 = 0.0;
+        if (sl < ns) {
+            double tot = 0.0;
+            for (int p = 0; p < (1 << lsp); ++p) {
+                const double *row = s_tab + ((sl << lsp) + p) * GT_TABP + fl;
+                double pp;
+                if constexpr (J == 4) pp = (row[0] + row[16]) + (row[32] + row[48]);
+                else pp = (row[0] + row[32]) + (row[32 * GT_TABP] + row[32 * GT_TABP + 32]);
+                tot = p == 0 ? pp : tot + pp;
+            }
+            const int r = tv.slotrow[g * IBH_GSLOTS + sl];
+            y1 = wM[r] == 0.0 ? fill : tot;             // mask_result, IceCoupler.cpp:186-201
+            if (fw < nf) Y[(long)fw * ldy + r] = y1;
+        }
+        if (PAIR) {                                     // the second matrix's row of this group, as in spmm_rowgroup_kernel
+            const int a2 = pv.row[g];
+            if (a2 >= 0) {
+                double v2 = 0.0;
+                if (sl < ns && ((pv.mask[g] >> sl) & 1u)) v2 = pv.w[g * IBH_GSLOTS + sl] * y1;
+                double s_lo, s_hi;
+                wave_half_sums(v2, s_lo, s_hi);
+                const double s2 = half ? s_hi : s_lo;
+                if (sl == 0 && fw < nf) pv.Y2[(long)fw * pv.ldy2 + a2] = pv.wM2[a2] == 0.0 ? fill : s2;
+            }
+        }
+    }
+    GT_STAMP(12);
+}
+
 constexpr int SR_THREADS = 256;
 
 // XT[c*ldt + f] = X[f*ldx + c]; pad columns f in [nf, ldt) are zeroed (read for tail fields, never stored)
@@ -1063,6 +1317,7 @@ static void launch_rowgroup(const ibh_weighted *w, const BatchPtrs &bp, int nbat
             raised[w->device & 63] = true;
         }
     }
+    snprintf(w->last_sig, sizeof(w->last_sig), "spmm_rowgroup_kernel<%d, %d, %d, %s>", NW, U, TW, pair ? "true" : "false");
     if (pair) {
         IBH_CHECK(lds <= 64 * 1024 && nbatch == 1, "fused pair apply: %zu bytes of LDS / %d batches not supported", lds, nbatch);
         hipExtLaunchKernelGGL((spmm_rowgroup_kernel<NW, U, TW, true>), dim3((unsigned)nb, 1u), dim3(NW * 64), lds, stream, ev0, ev1, 0, gv, bp,
@@ -1071,6 +1326,59 @@ static void launch_rowgroup(const ibh_weighted *w, const BatchPtrs &bp, int nbat
         hipExtLaunchKernelGGL((spmm_rowgroup_kernel<NW, U, TW>), dim3((unsigned)nb, (unsigned)nbatch), dim3(NW * 64), lds, stream, ev0, ev1, 0, gv, bp,
                               lda, w->ncol, ldb, nvar, nfc, xcd_mode, w->wM.p, fill, PairView{});
     IBH_HIP(hipGetLastError());
+}
+
+template <int F, int NS, int SEG, int NW>
+static void launch_grouptile(const ibh_weighted *w, const BatchPtrs &bp, int nbatch, int nvar, long lda, long ldb, double fill, hipStream_t stream,
+                             const PairView *pair = nullptr)
+{
+    const int nfc = ceil_div(nvar, F);
+    int xcd_mode;
+    const long nb = rowblock_grid(w->grp_n, nfc, xcd_mode);
+    IBH_CHECK(nb < (1l << 31), "spmm grid too large (%ld blocks)", nb);
+    IBH_CHECK((long)w->ncol * 8 < (1l << 31), "ncol too large for 32-bit buffer offsets");
+    IBH_CHECK(w->grp_nslot <= NS && w->gt_seg == SEG, "row groups of %d rows / tiles of %d in a kernel for %d / %d", w->grp_nslot, w->gt_seg, NS, SEG);
+    TileView tv{w->grp_ptr.p, w->gt_ptr.p, w->gt_col.p, w->gt_ek.p, w->gt_eptr.p, w->gt_ev.p, w->grp_ns.p, w->grp_slotrow.p, w->grp_n, nullptr};
+#ifdef GT_TIMELINE
+    tv.dbg = reinterpret_cast<long long *>(((unsigned long long)(unsigned)get_tuning("gt_dbg_hi", 0) << 32) | (unsigned)get_tuning("gt_dbg_lo", 0));
+#endif
+    constexpr size_t lds = grouptile_lds<F, SEG>();
+    static_assert(lds <= 64 * 1024, "within the default dynamic-LDS limit");
+    hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+    snprintf(w->last_sig, sizeof(w->last_sig), "spmm_grouptile_kernel<%d, %d, %d, %d, %s>", F, NS, SEG, NW, pair ? "true" : "false");
+    if (pair) {
+        IBH_CHECK(nbatch == 1, "fused pair apply: %d batches not supported", nbatch);
+        hipExtLaunchKernelGGL((spmm_grouptile_kernel<F, NS, SEG, NW, true>), dim3((unsigned)nb, 1u), dim3(NW * 64), lds, stream, ev0, ev1, 0, tv, bp,
+                              lda, w->ncol, ldb, nvar, nfc, xcd_mode, w->wM.p, fill, *pair);
+    } else
+        hipExtLaunchKernelGGL((spmm_grouptile_kernel<F, NS, SEG, NW, false>), dim3((unsigned)nb, (unsigned)nbatch), dim3(NW * 64), lds, stream, ev0, ev1, 0,
+                              tv, bp, lda, w->ncol, ldb, nvar, nfc, xcd_mode, w->wM.p, fill, PairView{});
+    IBH_HIP(hipGetLastError());
+}
+// (rows per group, tile size) -> instantiation; 16 fields per workgroup (32 lost everywhere it was measured: 1 km 269 against 218 us,
+// the Antarctic sheet 3.67 against 3.62 ms, 5 km 22 against 18 us)
+static void launch_grouptile_any(const ibh_weighted *w, const BatchPtrs &bp, int nbatch, int nvar, long lda, long ldb, double fill, hipStream_t stream,
+                                 const PairView *pair = nullptr)
+{
+    const bool few = w->grp_nslot <= 16;
+    if (w->gt_seg == 128) {
+        if (few) launch_grouptile<16, 16, 128, 4>(w, bp, nbatch, nvar, lda, ldb, fill, stream, pair);
+        else launch_grouptile<16, 32, 128, 4>(w, bp, nbatch, nvar, lda, ldb, fill, stream, pair);
+    } else {
+        if (few) launch_grouptile<16, 16, 256, 8>(w, bp, nbatch, nvar, lda, ldb, fill, stream, pair);
+        else launch_grouptile<16, 32, 256, 8>(w, bp, nbatch, nvar, lda, ldb, fill, stream, pair);
+    }
+}
+// Which form of the row groups: the tiles (grouptile) for bandwidth-sized matrices -- measured, one apply per launch, tiles
+// against LDS atomics: the Antarctic sheet (35 M entries) 16 fields 503 against 672 us, 128 fields 3.62 against 4.34 ms; 1 km
+// Greenland (4 M entries) 64 fields 218 against 220 us, 16 fields 82 against 74; 5 km (166 k entries: latency-bound, three
+// tiles in sequence per GCM cell) 12.4 against 7.6 and 18.1 against 17.4 us.  ibh_set_tuning("rowgroup_form", 0 / 1) forces one.
+static bool use_grouptile(const ibh_weighted *w, int nvar) {
+    if (w->gt_ntile <= 0) return false;
+    const int form = get_tuning("rowgroup_form", -1);
+    if (form >= 0) return form == 1;
+    return w->nnz >= (1l << 24) || (w->nnz >= (1l << 21) && nvar >= 48);
 }
 
 // B[f, r] = lower-class sum of band r + upper-class sum of the band below it (rb1[r], -1: none)
@@ -1316,6 +1624,8 @@ static void drop_groups(const ibh_weighted *w) {
     w->pair_second = nullptr;                                 // (a pairing indexes the group table)
     w->grp_ptr.release(); w->grp_ns.release(); w->grp_slotrow.release(); w->grp_col.release(); w->grp_meta.release();
     w->grp_v0.release(); w->grp_v1.release();
+    w->gt_ntile = 0; w->gt_seg = 0;
+    w->gt_ptr.release(); w->gt_col.release(); w->gt_ek.release(); w->gt_eptr.release(); w->gt_ev.release();
 }
 static void drop_sweep(const ibh_weighted *w) {
     w->sweep_ntask = 0;
@@ -1479,7 +1789,9 @@ void spmm_launch_pair(const ibh_weighted *first, const ibh_weighted *second, con
     const PairView pv{first->pair_w.p, first->pair_mask.p, first->pair_row.p, second->wM.p, dB2, (long)ldb2};
     const int nw = get_tuning("rowgroup_waves", nvar >= 32 ? 8 : 4), tw = get_tuning("rowgroup_tw", first->nnz < (1 << 20) ? 32 : 64);
 #define IBH_RGP(N, TT) launch_rowgroup<N, 8, TT>(first, bp, 1, nvar, (long)lda, (long)ldb1, fill, stream, &pv)
-    if (nw == 8) { if (tw == 32) IBH_RGP(8, 32); else IBH_RGP(8, 64); }
+    if (use_grouptile(first, nvar)) {
+        launch_grouptile_any(first, bp, 1, nvar, (long)lda, (long)ldb1, fill, stream, &pv);
+    } else if (nw == 8) { if (tw == 32) IBH_RGP(8, 32); else IBH_RGP(8, 64); }
     else { if (tw == 32) IBH_RGP(4, 32); else IBH_RGP(4, 64); }
 #undef IBH_RGP
     first->last_kernel = 5;
@@ -1515,7 +1827,9 @@ static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &
         // at 1 km the doubled atomic instructions cost 223 -> 238 us.  By the matrix alone, so one apply and a batch agree bitwise.
         const int tw = get_tuning("rowgroup_tw", w->nnz < (1 << 20) ? 32 : 64);
 #define IBH_RG(N, UU, TT) launch_rowgroup<N, UU, TT>(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream)
-        if (tw == 32) { if (nw == 8) { if (u <= 8) IBH_RG(8, 8, 32); else IBH_RG(8, 16, 32); } else { if (u <= 4) IBH_RG(4, 4, 32); else IBH_RG(4, 8, 32); } }
+        if (use_grouptile(w, nvar)) {
+            launch_grouptile_any(w, bp, nbatch, nvar, (long)lda, (long)ldb, fill, stream);
+        } else if (tw == 32) { if (nw == 8) { if (u <= 8) IBH_RG(8, 8, 32); else IBH_RG(8, 16, 32); } else { if (u <= 4) IBH_RG(4, 4, 32); else IBH_RG(4, 8, 32); } }
         else if (nw == 8) { if (u <= 8) IBH_RG(8, 8, 64); else IBH_RG(8, 16, 64); }
         else { if (u <= 4) IBH_RG(4, 4, 64); else if (u <= 8) IBH_RG(4, 8, 64); else IBH_RG(4, 16, 64); }
 #undef IBH_RG

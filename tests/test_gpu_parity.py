@@ -113,7 +113,7 @@ def test_fast_and_general_assembly_paths_agree_with_the_oracle(config):
 
 
 @pytest.mark.parametrize("config,kw", [("g5", {}), ("g20", {}), ("g20", dict(x_fastest=True))])
-def test_fused_pair_evi_then_ave_is_the_two_applies(config, kw):
+def test_fused_pair_evi_then_ave_is_the_two_applies(config, kw, rowgroup_form):
     """ibh_weighted_apply_pair_device: E = EvI * I and A = AvE * E in one launch (BASELINE config 3's chain) against the two
     separate applies and the oracle: B1 bitwise the EvI apply, B2 within 1e-12 of AvE applied to it; NaN fields, fill for rows
     without weight, 1..40 fields, matrices with their own dims (different numberings of E: paired through sparse indices) and
@@ -1723,13 +1723,26 @@ def test_colsweep_on_grid_variants(variant):
     assert w.last_kernel() in ("rowblock", "shortrow")
 
 
+@pytest.fixture(params=["atomics", "tiles256", "tiles128"])
+def rowgroup_form(request):
+    """Both forms of the row-group apply (spmm.hip): the class sums in LDS tables through ds_add_f64 (spmm_rowgroup_kernel), and
+    the tiled form with register sums (spmm_grouptile_kernel) in its two tile sizes -- whatever the automatic choice would be."""
+    form = request.param
+    icebin_amd.set_tuning("rowgroup_form", 0 if form == "atomics" else 1)
+    if form != "atomics":
+        icebin_amd.set_tuning("grouptile_seg", int(form[5:]))
+    yield form
+    icebin_amd.set_tuning("rowgroup_form", -2 ** 31)
+    icebin_amd.set_tuning("grouptile_seg", -2 ** 31)
+
+
 @pytest.mark.parametrize("variant", ["sorted", "shuffled", "elev_class", "x_fastest", "g20"])
-def test_rowgroup_on_grid_variants(variant):
-    """The row-group apply of the E-row matrices (spmm.hip rowgroup: the elevation classes of one GCM cell form a group whose
-    columns are gathered once) against the oracle: 1..130 fields, NaN-carrying fields, fill, both interpolation styles, both
-    ice index orders, shuffled exchange cells (general assembly path), a coarse grid (few cells per class), batched launches
-    bitwise equal to separate applies, inside a hipGraph, and a shared dimE in a scrambled order (the rows of a group are
-    not consecutive)."""
+def test_rowgroup_on_grid_variants(variant, rowgroup_form):
+    """The row-group apply of the E-row matrices (spmm.hip rowgroup / grouptile: the elevation classes of one GCM cell form a
+    group whose columns are gathered once) against the oracle: 1..130 fields, NaN-carrying fields, fill, both interpolation
+    styles, both ice index orders, shuffled exchange cells (general assembly path), a coarse grid (few cells per class), batched
+    launches bitwise equal to separate applies, inside a hipGraph, and a shared dimE in a scrambled order (the rows of a group
+    are not consecutive)."""
     import torch
     kw = dict(sorted={}, shuffled=dict(order="shuffled"), elev_class={}, x_fastest=dict(x_fastest=True), g20={})[variant]
     g = syn.make_grids("g20" if variant == "g20" else "g5", **kw)
@@ -1754,6 +1767,7 @@ def test_rowgroup_on_grid_variants(variant):
                 finally:
                     icebin_amd.set_tuning("rowgroup_tw", -2 ** 31)
                 assert w.last_kernel() == "rowgroup", (name, nvar)
+                assert ("grouptile" in w.last_launch()) == (rowgroup_form != "atomics"), w.last_launch()
                 assert rel_linf(y, ref) <= FIELD_RTOL, (name, nvar, tw)
         if name == "EvI":
             xs = [torch.from_numpy(syn.fields(16, w.ncol_d, seed=400 + q)).cuda() for q in range(5)]
