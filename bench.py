@@ -195,16 +195,19 @@ def main():
     # results of `depth` applies share ONE all-gather while they are small (a [64, 122] AvI result is 62 KB:
     # a collective of that size is latency-bound); a result of megabytes (I-row matrices) is gathered per apply
     gsteps = depth if 8 * nf * ldy < (4 << 20) else 1
-    # The gathers go through the library's own RCCL calls by default (ibh_comm, ibh_weighted_apply_*_sharded_device: direct
-    # peer-to-peer exchange) -- the path a C++ host takes (north_star: "host code stays C++").  ICEBIN_BENCH_SHARDED=torch opts
-    # out (torch.distributed's all_gather_into_tensor); `gather_via` in the JSON line says which one ran.  If the C-ABI
-    # communicator cannot be created, or its first gathered result is not bitwise the locally recomputed shards, EVERY rank
-    # falls back to the torch path together (the decision is all-reduced) and `gather_via_fallback` says why.
+    # The gathers go through torch.distributed's all_gather_into_tensor by default; ICEBIN_BENCH_SHARDED=cabi takes the library's
+    # own RCCL calls (ibh_comm, ibh_weighted_apply_*_sharded_device: direct peer-to-peer exchange) -- the path a C++ host takes
+    # (north_star: "host code stays C++"); `gather_via` in the JSON line says which one ran.  The communicator's bootstrap is
+    # decided collectively (every rank probes RCCL, the flags are all-reduced before the id is broadcast); if the communicator
+    # cannot be created, or its first gathered result is not bitwise the locally recomputed shards, EVERY rank falls back to
+    # the torch path together (all-reduced again) and `gather_via_fallback` says why.
     sharded = None
     sharded_via = None
     sharded_fallback = None
     if use_dist:
-        want_cabi = os.environ.get("ICEBIN_BENCH_SHARDED", "cabi") == "cabi" and backend == "nccl"
+        # (torch.distributed stays the default until a recorded run with more than one rank over RCCL has passed the
+        # bitwise gather check through the library's own exchange; ICEBIN_BENCH_SHARDED=cabi asks for that path)
+        want_cabi = os.environ.get("ICEBIN_BENCH_SHARDED", "torch") == "cabi" and backend == "nccl"
         if want_cabi:
             from icebin_amd.distributed import CabiFieldShardedApply, Communicator
             why = None

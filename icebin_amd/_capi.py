@@ -107,6 +107,8 @@ _SIGS = {
     "ibh_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ibh_comm_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ibh_comm_set_custom_gatherv": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ibh_comm_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ibh_comm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "ibh_regrid_matrices_matrix_d_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                        C.POINTER(C.c_void_p)]),
     "ibh_weighted_apply_many_sharded_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,

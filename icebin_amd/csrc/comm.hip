@@ -97,6 +97,8 @@ struct ibh_comm {
     ibh_gatherv_fn custom_v = nullptr;       // pieces of unequal size (the sharded assembly); nullptr: the transport cannot carry them
     void *custom_user = nullptr;
     hipStream_t xs = nullptr;            // the exchange stream
+    bool owns_xs = true;                 // false: the caller's (ibh_comm_set_stream) -- never destroyed here
+    bool planes_padded = false;          // ibh_comm_set_option("planes_padded"): the gap [nrow, ldb) of a result plane belongs to the call
     hipEvent_t ready = nullptr;
     // exchanges in flight: the byte range of the result array each one writes and the event behind it.  A later apply whose
     // results overlap such a range is ordered behind THAT exchange only -- so with two alternating result arrays the SpMM of
@@ -141,12 +143,13 @@ static void record_flight(ibh_comm *c, const void *lo, const void *hi, hipStream
 
 // for every base of the list: every rank's block of `nplane` planes (nrow doubles each, ldb apart) at base + rank*stride
 // reaches base + rank*stride on every peer; enqueued on the exchange stream as ONE group (one RCCL launch however many
-// results travel).  Rows [nrow, ldb) of a plane travel along only when they are the library's own kind of padding (planes
-// rounded up to 512 bytes: at most 63 doubles) -- the header gives those to the call; a wider gap means ldb is a true
-// leading dimension (a column view of a larger array whose other columns are live data) and every plane travels by itself.
+// results travel).  Rows [nrow, ldb) of a plane travel along only when the caller has SAID that they are padding it owns
+// (ibh_comm_set_option "planes_padded": the library's own wrappers round planes up to 512 bytes); otherwise ldb is a true
+// leading dimension (a column view of a larger array whose other columns are live data) and every plane travels by itself:
+// nothing outside [0, nrow) of a plane is touched on any rank.  No guessing from the size of the gap.
 static void exchange(ibh_comm *c, double *const *d_bases, int nbase, int nplane, int64_t nrow, int64_t ldb, int64_t stride) {
     if (c->world == 1 || nplane <= 0 || nrow <= 0 || nbase == 0) return;
-    const bool whole = (ldb - nrow) < 64 || nplane == 1;
+    const bool whole = ldb == nrow || c->planes_padded || nplane == 1;
     const int npiece = whole ? 1 : nplane;
     const int64_t count = whole ? (int64_t)(nplane - 1) * ldb + nrow : nrow;
     if (c->custom) {
@@ -274,8 +277,26 @@ int ibh_comm_destroy(ibh_comm *c) {
         if (c->nccl && rccl().CommDestroy) (void)rccl().CommDestroy(c->nccl);
         if (c->ready) (void)hipEventDestroy(c->ready);
         for (auto &f : c->ring) if (f.ev) (void)hipEventDestroy(f.ev);
-        if (c->xs) (void)hipStreamDestroy(c->xs);
+        if (c->xs && c->owns_xs) (void)hipStreamDestroy(c->xs);      // (a caller's stream, ibh_comm_set_stream, stays the caller's)
         delete c;
+    });
+}
+
+int ibh_comm_set_stream(ibh_comm *c, void *stream) {
+    return guarded([&] {
+        IBH_CHECK(c != nullptr && stream != nullptr, "null argument");
+        if (c->xs) IBH_HIP(hipStreamSynchronize(c->xs));           // nothing of ours is left on the old stream
+        if (c->xs && c->owns_xs) IBH_HIP(hipStreamDestroy(c->xs));
+        c->xs = static_cast<hipStream_t>(stream);
+        c->owns_xs = false;
+    });
+}
+
+int ibh_comm_set_option(ibh_comm *c, const char *key, int value) {
+    return guarded([&] {
+        IBH_CHECK(c != nullptr && key != nullptr, "null argument");
+        if (!strcmp(key, "planes_padded")) c->planes_padded = value != 0;
+        else fail(IBH_ENOKEY, "unknown communicator option '%s' (expected: planes_padded)", key);
     });
 }
 

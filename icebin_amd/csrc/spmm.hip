@@ -969,7 +969,7 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     // loads and stores together in issue order, so a gather issued after a store would wait for that
     // store's (long) write acknowledgement; with G == fields per thread there is one load phase and
     // one store phase per thread.
-    // SHARED columns (XT, groups of <= 8 fields): rows of one GCM cell follow each other in a fresh ice dimension, so for every entry
+    // SHARED columns (XT, groups of <= 4 fields): rows of one GCM cell follow each other in a fresh ice dimension, so for every entry
     // slot most lanes of a wave name the SAME column.  That column's X values come through scalar loads and feed the FMAs as scalar
     // operands; only the lanes that differ (the ice cells along the cell's edge: two per grid-row segment) gather theirs, and a gather
     // costs the texture path by its ACTIVE lanes.  A full-wave gather of 16 bytes per lane is 16 cycles per CU whatever the addresses:

@@ -301,16 +301,21 @@ class Communicator:
     backend: it only carries 128 bytes); a C++ host would use its own channel (ModelE: MPI_Bcast).  world == 1 needs nothing.
     `exchange` (a Python callable, tests only) replaces RCCL by a custom transport (ibh_comm_create_custom)."""
 
-    def __init__(self, world=1, rank=0, bootstrap=None, exchange=None, rccl=None, gatherv=None):
+    def __init__(self, world=1, rank=0, bootstrap=None, exchange=None, rccl=None, gatherv=None, stream=None, planes_padded=False):
         """rccl: None = only when world > 1; True = also at world 1 (a one-rank RCCL communicator: exercises the library's
         RCCL binding on a single GPU).  gatherv (custom transports, tests): callable(d_base, offsets, world, rank, stream) for
-        pieces of unequal size -- offsets is a list of world + 1 byte offsets (ibh_comm_set_custom_gatherv: the sharded assembly)."""
+        pieces of unequal size -- offsets is a list of world + 1 byte offsets (ibh_comm_set_custom_gatherv: the sharded assembly).
+        stream: a torch.cuda.Stream the exchanges run on instead of a stream the communicator creates and destroys
+        (ibh_comm_set_stream: the caller's stream outlives the communicator -- what a transport whose allocator keeps
+        per-stream state wants); planes_padded: the gap between nrow_d and the row stride of the result arrays is padding
+        (ibh_comm_set_option)."""
         import ctypes as C
         from . import _capi
         self._capi, self._C = _capi, C
         L = _capi.lib()
         h = C.c_void_p()
         self._cb = self._cbv = None
+        self._stream = stream
         if exchange is not None:
             proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p)
 
@@ -341,25 +346,53 @@ class Communicator:
             _capi.check(L.ibh_comm_create(1, 0, None, C.byref(h)))
         else:
             buf = C.create_string_buffer(128)
-            if rank == 0:
+            # EVERY rank asks for an id first (rank 0's is the one that counts): a rank that cannot load RCCL finds out here,
+            # before any collective -- and with the default bootstrap the ranks agree on that (all-reduce) before the broadcast,
+            # so one failing rank makes all of them raise instead of leaving the others inside a broadcast it never joins
+            err = None
+            try:
                 _capi.check(L.ibh_comm_unique_id(buf))
+            except Exception as e:      # noqa: BLE001
+                err = e
             if world == 1:
+                if err is not None:
+                    raise err
                 uid = buf.raw
             elif bootstrap is None:
+                dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+                ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) != 1:
+                    raise RuntimeError("ibh_comm: RCCL is not usable on every rank (this rank: %s)" % (err if err is not None else "fine"))
                 box = [buf.raw]
                 dist.broadcast_object_list(box, src=0)
                 uid = box[0]
             else:
+                if err is not None:
+                    raise err
                 uid = bootstrap(buf.raw if rank == 0 else None)
             _capi.check(L.ibh_comm_create(world, rank, uid, C.byref(h)))
         self._h, self.world, self.rank = h, world, rank
+        if stream is not None:
+            _capi.check(L.ibh_comm_set_stream(h, C.c_void_p(stream.cuda_stream)))
+        if planes_padded:
+            _capi.check(L.ibh_comm_set_option(h, b"planes_padded", 1))
+
+    def set_option(self, key, value):
+        """ibh_comm_set_option, e.g. ("planes_padded", 1)"""
+        self._capi.check(self._capi.lib().ibh_comm_set_option(self._h, key.encode(), int(value)))
+
+    def close(self):
+        """Synchronise the exchanges and destroy the communicator now (idempotent; `del` does the same)."""
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None:
+            self._capi.destroy("ibh_comm_destroy", h)
 
     def __del__(self):
         try:
-            self._capi.destroy("ibh_comm_destroy", getattr(self, "_h", None))
+            self.close()
         except Exception:      # interpreter shutdown
             pass
-        self._h = None
 
     def wait(self, stream=None):
         """Make `stream` (a raw stream handle; default torch's current stream) wait for the exchanges enqueued so far."""
@@ -421,6 +454,7 @@ class CabiFieldShardedApply:
         self.ld = (self.nrow + 63) // 64 * 64
         self.device = device
         self._out = [torch.zeros((self.G, nf_total, self.ld), dtype=torch.float64, device=device) for _ in range(2)]
+        comm.set_option("planes_padded", 1)        # (the planes of these arrays are rounded up to 512 bytes: the gap is ours)
         self._i = 0
 
     def _stream(self):

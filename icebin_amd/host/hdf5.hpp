@@ -519,7 +519,7 @@ class File {
         }
         return raw;
     }
-    struct Chunk { std::vector<uint64_t> offs; uint64_t addr; uint32_t size, mask; };
+    struct Chunk { std::vector<uint64_t> offs; uint64_t addr, size; uint32_t mask; };
     void chunks(uint64_t btree, int rank, std::vector<Chunk> &out, int depth) const {
         if (btree == undef()) return;
         if (depth > 32) throw Error("chunk B-tree too deep");
@@ -580,11 +580,20 @@ class File {
         }
     }
     static bool host_little() { const uint16_t one = 1; return *reinterpret_cast<const uint8_t *>(&one) == 1; }
+    /** product of extents (times an element size) with overflow turned into an Error: the sizes come from an untrusted file */
+    static uint64_t checked_count(std::vector<uint64_t> const &shape, uint64_t es = 1) {
+        uint64_t count = es;
+        for (auto s : shape) {
+            if (s != 0 && count > UINT64_MAX / s) throw Error("dataspace too large (extent product overflows)");
+            count *= s;
+        }
+        return count;
+    }
     Value decode(const uint8_t *raw, size_t nbytes, DType const &dt, std::vector<uint64_t> const &shape) {
         Value v;
         v.shape = shape;
-        uint64_t count = 1;
-        for (auto s : shape) count *= s;
+        const uint64_t count = checked_count(shape);
+        if (count != 0 && dt.size > UINT64_MAX / count) throw Error("dataspace too large (byte size overflows)");
         if (dt.kind != DType::NUM && dt.kind != DType::STR && dt.kind != DType::VSTR && dt.kind != DType::VLEN && dt.kind != DType::REF) {
             v.arr.type = nc::UBYTE;                            // compound / opaque / array: raw bytes
             v.arr.raw.assign(reinterpret_cast<const char *>(raw), reinterpret_cast<const char *>(raw) + std::min<size_t>(nbytes, (size_t)count * dt.size));
@@ -664,7 +673,8 @@ class File {
         parse_datatype(ap.tpos, dt);
         std::vector<uint64_t> shape;
         uint64_t count = 0;
-        if (attribute_space(ap.spos, shape)) { count = 1; for (auto s : shape) count *= s; }
+        if (attribute_space(ap.spos, shape)) count = checked_count(shape);
+        if (count != 0 && dt.size > UINT64_MAX / count) throw Error("attribute too large (byte size overflows)");
         return ap.p + (size_t)(count * dt.size);
     }
     std::pair<std::string, Value> parse_attribute(size_t d) {
@@ -675,8 +685,8 @@ class File {
         parse_datatype(ap.tpos, dt);
         std::vector<uint64_t> shape;
         if (!attribute_space(ap.spos, shape)) { Value v; v.null = true; return {ap.name, v}; }
-        uint64_t count = 1;
-        for (auto s : shape) count *= s;
+        const uint64_t count = checked_count(shape);
+        if (count != 0 && dt.size > UINT64_MAX / count) throw Error("attribute too large (byte size overflows)");
         need(ap.p, (size_t)(count * dt.size));
         return {ap.name, decode(b_ + ap.p, (size_t)(count * dt.size), dt, shape)};
     }
@@ -765,8 +775,7 @@ public:
         if (!o.is_dataset()) throw Error("object is not a dataset");
         DType const &dt = o.dtype;
         std::vector<uint64_t> shape = o.null_space ? std::vector<uint64_t>{0} : o.shape;
-        uint64_t count = 1;
-        for (auto s : shape) count *= s;
+        const uint64_t count = checked_count(shape);
         const size_t es = dt.size;
         // deflate expands at most ~1032 : 1, so a dataset larger than that multiple of the file is a corrupt dataspace, not data
         if (es == 0 || count > ((uint64_t)n_ * 1100 + (1u << 20)) / es) throw Error("dataset larger than the file can hold (corrupt dataspace?)");
@@ -784,9 +793,11 @@ public:
             if (o.layout.kind == 3) {
                 cdims = o.layout.dims;
                 if (o.layout.a != undef()) {
-                    uint64_t n = es;
-                    for (auto c : cdims) n *= c;
-                    Chunk c; c.offs.assign((size_t)rank, 0); c.addr = o.layout.a; c.size = (uint32_t)(o.layout.has_fsize ? o.layout.fsize : n); c.mask = o.layout.fmask;
+                    const uint64_t n = checked_count(cdims, es);
+                    const uint64_t csz = o.layout.has_fsize ? o.layout.fsize : n;
+                    if (csz > n_) throw Error("single chunk larger than the file");
+                    Chunk c; c.offs.assign((size_t)rank, 0); c.addr = o.layout.a; c.size = (decltype(c.size))csz; c.mask = o.layout.fmask;
+                    if ((uint64_t)c.size != csz) throw Error("single chunk too large for this reader");
                     cl.push_back(c);
                 }
             } else {
@@ -794,10 +805,11 @@ public:
                 chunks(o.layout.a, rank, cl, 0);
             }
             if ((int)cdims.size() != rank) throw Error("chunk rank does not match the dataspace");
+            for (auto c : cdims) if (c == 0) throw Error("chunk dimension of zero");
             raw.assign((size_t)count * es, '\0');
             if (o.has_fill && o.fill.size() == es) for (uint64_t k = 0; k < count; ++k) std::memcpy(&raw[k * es], o.fill.data(), es);
-            uint64_t celems = 1;
-            for (auto c : cdims) celems *= c;
+            const uint64_t celems = checked_count(cdims);
+            if (celems > UINT64_MAX / (es ? es : 1)) throw Error("chunk too large (byte size overflows)");
             std::vector<uint64_t> stride((size_t)rank, 1), cstride((size_t)rank, 1);
             for (int i = rank - 2; i >= 0; --i) { stride[(size_t)i] = stride[(size_t)i + 1] * shape[(size_t)i + 1]; cstride[(size_t)i] = cstride[(size_t)i + 1] * cdims[(size_t)i + 1]; }
             for (Chunk const &c : cl) {

@@ -147,6 +147,10 @@ public:
     int rank() const { int r; check(ibh_comm_info(h_, nullptr, &r)); return r; }
     /** make `stream` wait for the exchanges enqueued so far: the gathered results are complete behind it */
     void wait(void *stream) const { check(ibh_comm_wait(h_, stream)); }
+    /** run the exchanges on the caller's stream (which outlives this object and is never destroyed by it) */
+    void set_stream(void *stream) { check(ibh_comm_set_stream(h_, stream)); }
+    /** "planes_padded": the gap between nrow_d and ldb of the result planes is padding the caller owns */
+    void set_option(const char *key, int value) { check(ibh_comm_set_option(h_, key, value)); }
     ibh_comm *handle() const { return h_; }
 };
 

@@ -320,6 +320,22 @@ int ibh_comm_create_custom(int world, int rank, ibh_exchange_fn fn, void *user, 
  * [offsets[q], offsets[q+1]) of d_base to the same place on every peer, ordered on `stream`; 0 = success. */
 typedef int (*ibh_gatherv_fn)(void *user, void *d_base, const int64_t *offsets, int world, int rank, void *stream);
 int ibh_comm_set_custom_gatherv(ibh_comm *c, ibh_gatherv_fn fn);
+/* The exchange stream.  By default the communicator creates its own (non-blocking) stream and DESTROYS it in ibh_comm_destroy:
+ * the `stream` a custom transport's callbacks receive for the field exchanges is that stream, and it is invalid once
+ * ibh_comm_destroy has returned -- a transport whose allocator keeps per-stream state (torch's pinned-host cache records the
+ * streams a block was used on) must drop that state before it destroys the communicator, or hand in a stream of its own:
+ * ibh_comm_set_stream makes the communicator enqueue its exchanges on the CALLER's stream, which the caller keeps alive until
+ * after ibh_comm_destroy and destroys itself (the library synchronises it in ibh_comm_destroy, never destroys it).  Call it
+ * before the first apply; a stream that also carries the SpMMs serialises exchange and compute.  (The callbacks of the sharded
+ * ASSEMBLY, ibh_gatherv_fn and the 32-byte ibh_exchange_fn call of ibh_regrid_matrices_matrix_d_sharded, always receive the
+ * caller's build stream.) */
+int ibh_comm_set_stream(ibh_comm *c, void *stream);
+/* Options of one communicator.  "planes_padded" (default 0): 1 = the caller owns the gap [nrow_d, ldb) of every result plane of
+ * the sharded applies on this communicator as padding (planes rounded up to whole 512-byte lines, as the library's own wrappers
+ * allocate them): the planes of a field block then travel as ONE piece and the padding of the peers' planes is overwritten.
+ * With 0 nothing outside [0, nrow_d) of a plane is touched on any rank: planes travel one by one unless ldb == nrow_d.
+ * Unknown key: IBH_ENOKEY. */
+int ibh_comm_set_option(ibh_comm *c, const char *key, int value);
 int ibh_comm_destroy(ibh_comm *c);
 int ibh_comm_info(const ibh_comm *c, int *world, int *rank);
 /* Weighted::apply of world*nvar_local fields, sharded by field: dB_all [world*nvar_local x ldb] (device, the same
@@ -330,9 +346,9 @@ int ibh_comm_info(const ibh_comm *c, int *world, int *rank);
  * the I-row matrices) so that it overlaps the SpMM of the following block and of the following apply.  dB_all is complete once
  * ibh_comm_wait(c, s) has made stream s wait for the exchanges enqueued so far.  Same results as ibh_weighted_apply_device
  * on each rank's fields (bitwise), conservative matrices only (no force_conservation).
- * ldb: when ldb - nrow_d < 64 the gap is taken to be plane padding owned by the call (the library's own buffers round planes
- * up to 512 bytes) and travels with the planes -- peers' padding is overwritten; a wider gap is a true leading dimension
- * (a column view of a larger array): every plane then travels by itself and nothing outside [0, nrow_d) of a plane is touched.
+ * ldb > nrow_d: a true leading dimension (a column view of a larger array) unless the communicator says otherwise -- every plane
+ * travels by itself and nothing outside [0, nrow_d) of a plane is touched on any rank; ibh_comm_set_option(c, "planes_padded", 1)
+ * declares the gap padding owned by the caller, the planes of a block then travel as one piece (fewer, larger transfers).
  * Streams: any stream may issue applies and waits on one communicator; an apply whose results overlap an exchange still in
  * flight is ordered behind it whichever stream enqueued that exchange (the last 8 exchanges are tracked individually, older
  * unfinished ones through the range hull of their successor). */

@@ -272,7 +272,12 @@ def _worker_sharded(rank, world, port, q):
                         flat[off + p * stride: off + p * stride + count].copy_(parts[p], non_blocking=True)
             state["calls"] = state.get("calls", 0) + 1
             state.setdefault("counts", []).append(int(count))
-        comm = Communicator(world, rank, exchange=exchange)
+        # the exchanges run on a stream THIS process owns (ibh_comm_set_stream): torch's pinned-host allocator remembers the streams
+        # a block was used on, and a stream the communicator created would die in ibh_comm_destroy with such blocks still alive
+        # (round 4: a segmentation fault in the allocator's garbage collection).  The planes of the result arrays below are
+        # rounded up to 512 bytes and the gap is this test's: planes_padded.
+        xstream = torch.cuda.Stream()
+        comm = Communicator(world, rank, exchange=exchange, stream=xstream, planes_padded=True)
         state["pin"], state["pin_off"] = torch.empty(1 << 21, dtype=torch.float64).pin_memory(), 0
         ok = True
         ncalls = []
@@ -299,21 +304,26 @@ def _worker_sharded(rank, world, port, q):
                 ok = ok and bool(np.array_equal(got.view(np.uint64), ref.view(np.uint64)))
         # ldb as a TRUE leading dimension: the result is a column view of a wider array whose other columns are live data
         # (ADVICE r03): every plane travels by itself (nrow doubles), nothing outside the view changes on any rank
+        # -- the default of a communicator, planes_padded = 0, whatever the width of the gap: 200 live columns and 10 (a
+        # threshold on the gap used to decide, and a gap below 64 was overwritten on every peer)
+        comm.set_option("planes_padded", 0)
         w, nl = rm.matrix("AvI"), 3
-        wide = torch.full((world * nl, w.nrow_d + 200), float(rank + 7), dtype=torch.float64, device="cuda")
-        state["out"], state["calls"], state["counts"], state["pin_off"] = wide.view(-1), 0, [], 0
-        x_all = syn.fields(world * nl, w.ncol_d, seed=41)
-        x_loc = torch.from_numpy(x_all[rank * nl:(rank + 1) * nl].copy()).cuda()
-        out = apply_sharded(w, comm, x_loc, out_all=wide[:, 100: 100 + w.nrow_d], fill=-2.0)
-        comm.wait()
-        torch.cuda.synchronize()
-        ok = ok and state["calls"] == nl and set(state["counts"]) == {w.nrow_d}
-        hw = wide.cpu().numpy()
-        ok = ok and bool(np.all(hw[:, :100] == rank + 7) and np.all(hw[:, 100 + w.nrow_d:] == rank + 7))
-        for p in range(world):
-            xp = torch.from_numpy(x_all[p * nl:(p + 1) * nl].copy()).cuda()
-            ref = w.apply_device(xp, fill=-2.0, force_conservation=False).cpu().numpy()
-            ok = ok and bool(np.array_equal(np.ascontiguousarray(hw[p * nl:(p + 1) * nl, 100: 100 + w.nrow_d]).view(np.uint64), ref.view(np.uint64)))
+        for left, right in ((100, 100), (4, 6)):
+            wide = torch.full((world * nl, w.nrow_d + left + right), float(rank + 7), dtype=torch.float64, device="cuda")
+            state["out"], state["calls"], state["counts"], state["pin_off"] = wide.view(-1), 0, [], 0
+            x_all = syn.fields(world * nl, w.ncol_d, seed=41)
+            x_loc = torch.from_numpy(x_all[rank * nl:(rank + 1) * nl].copy()).cuda()
+            out = apply_sharded(w, comm, x_loc, out_all=wide[:, left: left + w.nrow_d], fill=-2.0)
+            comm.wait()
+            torch.cuda.synchronize()
+            ok = ok and state["calls"] == nl and set(state["counts"]) == {w.nrow_d}
+            hw = wide.cpu().numpy()
+            ok = ok and bool(np.all(hw[:, :left] == rank + 7) and np.all(hw[:, left + w.nrow_d:] == rank + 7))
+            for p in range(world):
+                xp = torch.from_numpy(x_all[p * nl:(p + 1) * nl].copy()).cuda()
+                ref = w.apply_device(xp, fill=-2.0, force_conservation=False).cpu().numpy()
+                ok = ok and bool(np.array_equal(np.ascontiguousarray(hw[p * nl:(p + 1) * nl, left: left + w.nrow_d]).view(np.uint64), ref.view(np.uint64)))
+        comm.set_option("planes_padded", 1)
         # several field batches: one SpMM launch, one grouped exchange (the transport is called once per result here)
         from icebin_amd.distributed import apply_many_sharded
         w, nl, nb = rm.matrix("AvI"), 4, 3
@@ -332,14 +342,12 @@ def _worker_sharded(rank, world, port, q):
                 ref = w.apply_device(xp, fill=-2.0, force_conservation=False).cpu().numpy()
                 ok = ok and bool(np.array_equal(outs[k][p * nl:(p + 1) * nl].cpu().numpy().view(np.uint64), ref.view(np.uint64)))
         q.put((rank, ok, ncalls))
-        # tear down in dependency order: the pinned staging buffer was used on the communicator's exchange stream (torch's host
-        # allocator remembers that stream) -- it goes first, while the stream still exists; the communicator last
+        # the communicator goes FIRST, with the transport's pinned buffer still alive and recorded on the exchange stream: the
+        # stream is this process's (ibh_comm_set_stream), so nothing the allocator remembers dies with the communicator
+        comm.close()
         torch.cuda.synchronize()
         state.clear()
         import gc
-        gc.collect()
-        torch._C._host_emptyCache() if hasattr(torch._C, "_host_emptyCache") else None
-        del comm
         gc.collect()
     finally:
         dist.destroy_process_group()
