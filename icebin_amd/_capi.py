@@ -98,6 +98,8 @@ _SIGS = {
     "ibh_weighted_reserve": (C.c_int, [C.c_void_p, C.c_int32]),
     "ibh_weighted_prepare": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "ibh_weighted_pair_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "ibh_weighted_apply_chain_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
+                                               C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_double, C.c_void_p]),
     "ibh_weighted_apply_pair_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64,
                                                C.c_void_p, C.c_int64, C.c_double, C.c_void_p]),
     "ibh_comm_unique_id": (C.c_int, [C.c_char_p]),

@@ -566,6 +566,18 @@ int ibh_weighted_apply_pair_device(const ibh_weighted *first, const ibh_weighted
         spmm_launch_pair(first, second, dA, nvar, lda, dB1, ldb1, dB2, ldb2, fill, static_cast<hipStream_t>(stream));
     });
 }
+int ibh_weighted_apply_chain_device(const ibh_weighted *first, const ibh_weighted *second, const ibh_weighted *third, const double *dA, int32_t nvar,
+                                    int64_t lda, double *dB1, int64_t ldb1, double *dB2, int64_t ldb2, double *dB3, int64_t ldb3, double fill,
+                                    void *stream) {
+    return guarded([&] {
+        check_weighted_device(first);
+        check_weighted_device(second);
+        check_weighted_device(third);
+        IBH_CHECK(nvar >= 0 && (nvar == 0 || (dA && dB1 && dB2 && dB3)), "bad arguments");
+        IBH_CHECK(nvar == 0 || ldb3 >= third->nrow, "chain apply: leading dimension %ld smaller than %d rows", (long)ldb3, third->nrow);
+        spmm_launch_chain(first, second, third, dA, nvar, lda, dB1, ldb1, dB2, ldb2, dB3, ldb3, fill, static_cast<hipStream_t>(stream));
+    });
+}
 int ibh_weighted_apply_host(const ibh_weighted *w, const double *A_b, int32_t nvar, int64_t lda, double *B_b,
                             int64_t ldb, double fill, int force_conservation) {
     return guarded([&] {

@@ -289,6 +289,7 @@ struct ibh_weighted {
     mutable ibh::DevBuf<double> pair_w;
     mutable ibh::DevBuf<uint32_t> pair_mask;
     mutable ibh::DevBuf<int32_t> pair_row;
+    mutable ibh::DevBuf<uint32_t> chain_cnt;             // chain (ibh_weighted_apply_chain_device): {workgroups of the pair kernel done, of the last kernel through}
     mutable int32_t grp_n = 0, grp_nslot = 0, grp_nitems = 0;          // groups (0: not built), most rows in a group, items
     mutable ibh::DevBuf<int32_t> grp_ptr, grp_ns, grp_slotrow, grp_col; // [grp_n+1] items of a group; [grp_n] rows of a group; [grp_n*IBH_GSLOTS]; [nitems]
     mutable ibh::DevBuf<uint32_t> grp_meta;
@@ -330,7 +331,9 @@ void weighted_reserve(const ibh_weighted *w, int nvar);
 void weighted_prepare(const ibh_weighted *w, int nvar, int nbatch);
 void weighted_pair_prepare(const ibh_weighted *first, const ibh_weighted *second, int nvar);
 void spmm_launch_pair(const ibh_weighted *first, const ibh_weighted *second, const double *dA, int nvar, int64_t lda, double *dB1,
-                      int64_t ldb1, double *dB2, int64_t ldb2, double fill, hipStream_t stream);
+                      int64_t ldb1, double *dB2, int64_t ldb2, double fill, hipStream_t stream, unsigned *done = nullptr);
+void spmm_launch_chain(const ibh_weighted *first, const ibh_weighted *second, const ibh_weighted *third, const double *dA, int nvar, int64_t lda,
+                       double *dB1, int64_t ldb1, double *dB2, int64_t ldb2, double *dB3, int64_t ldb3, double fill, hipStream_t stream);
 // assemble.hip: the band structure of an E-row matrix from its CSR (same result as building it with the matrix)
 void build_bands_from_csr(const ibh_weighted *w, hipStream_t st);
 // assemble.hip: the column-sweep structure of an E-row matrix from its CSR (sweep_kernel.inl); false: not representable

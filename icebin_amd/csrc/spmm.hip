@@ -72,6 +72,9 @@ void set_tuning(const char *key, int value) {
 // next rowblock launch of this thread attaches them to its own dispatch (hipExtLaunchKernel: start =
 // kernel begins, stop = kernel ends -- the interval rocprofv3's kernel trace reports).  One-shot.
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+// chain (ibh_weighted_apply_chain_device): the next I-row launch of this thread waits on a device counter instead of the queue
+static thread_local unsigned *g_chain_cnt = nullptr;
+static thread_local unsigned g_chain_n = 0;
 void set_launch_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
 
 // ---- helpers -------------------------------------------------------------------------------
@@ -493,7 +496,48 @@ struct PairView {
     const double *wM2;
     double *Y2;
     long ldy2;
+    unsigned *done;     // chain (ibh_weighted_apply_chain_device): every workgroup counts itself here when its results are visible
 };
+// a workgroup of the first kernel of a chain is finished: its stores are released to the device, then it counts itself
+// Chain counters {c, flag}: every workgroup of the first kernel clears `flag` when it starts (the kernel before it in the queue --
+// the previous chain's last kernel -- has completed: a barrier packet) and counts itself at `c` when its results are out; the
+// one that counts last re-arms c and raises the flag.  The last kernel's workgroups only READ the flag: same-address
+// read-modify-writes go through one L2 channel one after the other (1 200 waiting workgroups counting themselves cost 20 us).
+// (the results the next kernel reads were stored with chain_store -- written through to the device-coherent level -- so no
+// release fence is needed, which at agent scope writes back the whole L2 of the XCD: every wave waits for its own stores, the
+// barrier collects the waves)
+__device__ __forceinline__ void chain_begin(unsigned *cnt) {
+    if (threadIdx.x == 0) __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_signal(unsigned *cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__device__ __forceinline__ void chain_store(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a value the kernel before this one wrote (and released at agent scope): a load that is coherent across the XCDs' L2s
+__device__ __forceinline__ double chain_load(const double *p) {
+    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+#ifndef CHAIN_SLEEP
+#define CHAIN_SLEEP 32
+#endif
+// the first thing a workgroup of the chain's last kernel does: wait until the kernel before it has raised the flag (that kernel
+// was dispatched first, so its workgroups are placed first and always finish)
+__device__ __forceinline__ void chain_wait(unsigned *cnt, unsigned) {
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(CHAIN_SLEEP);
+    }
+    __syncthreads();
+}
 template <int NW, int U, int TW, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView gv, const BatchPtrs bp, long ldx, int ncol, long ldy, int nf,
                                                                int nfc, int xcd_mode, const double *__restrict__ wM, double fill,
@@ -507,7 +551,11 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView 
     unsigned *s_meta = reinterpret_cast<unsigned *>(s_col + SEG);
     double *s_tab = rg_lds + 3 * SEG;                       // [NW][nslot][64]
     int g, fc;
-    if (!block_to_task(blockIdx.x, gv.ngrp, nfc, xcd_mode, g, fc)) return;
+    if (PAIR && pv.done) chain_begin(pv.done);
+    if (!block_to_task(blockIdx.x, gv.ngrp, nfc, xcd_mode, g, fc)) {
+        if (PAIR && pv.done) chain_signal(pv.done);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fw = fc * NW + wave;
@@ -623,8 +671,12 @@ __global__ __launch_bounds__(NW * 64) void spmm_rowgroup_kernel(const GroupView 
             double v = 0.0;
             if (half == 0 && sl < ns && ((pv.mask[g] >> sl) & 1u)) v = pv.w[g * IBH_GSLOTS + sl] * y1;
             const double s2 = wave_sum(v);
-            if (lane == 0 && fw < nf) pv.Y2[(long)fw * pv.ldy2 + a2] = pv.wM2[a2] == 0.0 ? fill : s2;
+            if (lane == 0 && fw < nf) {
+                const double o2 = pv.wM2[a2] == 0.0 ? fill : s2;
+                if (pv.done) chain_store(&pv.Y2[(long)fw * pv.ldy2 + a2], o2); else pv.Y2[(long)fw * pv.ldy2 + a2] = o2;
+            }
         }
+        if (pv.done) chain_signal(pv.done);
     }
 }
 
@@ -716,7 +768,11 @@ __global__ __launch_bounds__(NW * 64, GT_WPS) void spmm_grouptile_kernel(const T
     unsigned short *s_ek = reinterpret_cast<unsigned short *>(s_ev + ECAP);      // [ECAP]
     double *s_tab = gt_lds;                                              // epilogue: [R][32 units][GT_TABP], over s_x
     int g, fc;
-    if (!block_to_task(blockIdx.x, tv.ngrp, nfc, xcd_mode, g, fc)) return;
+    if (PAIR && pv.done) chain_begin(pv.done);
+    if (!block_to_task(blockIdx.x, tv.ngrp, nfc, xcd_mode, g, fc)) {
+        if (PAIR && pv.done) chain_signal(pv.done);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     GT_STAMP(0);
@@ -887,11 +943,15 @@ __global__ __launch_bounds__(NW * 64, GT_WPS) void spmm_grouptile_kernel(const T
                 double s_lo, s_hi;
                 wave_half_sums(v2, s_lo, s_hi);
                 const double s2 = half ? s_hi : s_lo;
-                if (sl == 0 && fw < nf) pv.Y2[(long)fw * pv.ldy2 + a2] = pv.wM2[a2] == 0.0 ? fill : s2;
+                if (sl == 0 && fw < nf) {
+                    const double o2 = pv.wM2[a2] == 0.0 ? fill : s2;
+                    if (pv.done) chain_store(&pv.Y2[(long)fw * pv.ldy2 + a2], o2); else pv.Y2[(long)fw * pv.ldy2 + a2] = o2;
+                }
             }
         }
     }
     GT_STAMP(12);
+    if (PAIR && pv.done) chain_signal(pv.done);
 }
 
 constexpr int SR_THREADS = 256;
@@ -936,9 +996,10 @@ template <bool NT, int G, bool REALIGN, bool XT>
 __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     const int *__restrict__ rowptr, const int *__restrict__ colind, const double *__restrict__ vals,
     const BatchPtrs bp, const double *__restrict__ XT0, long xt_stride, long ldx, long ldy, int nrow, int nf, int fper,
-    const double *__restrict__ wM, double fill)
+    const double *__restrict__ wM, double fill, unsigned *chain_cnt = nullptr, unsigned chain_n = 0, int chain_ncol = 0)
 {
     __shared__ double s_y[REALIGN ? G : 1][SR_THREADS];
+    extern __shared__ double sr_chain[];                 // chain: this workgroup's fields of X, [fper][chain_ncol]
     // blockIdx.y = field batch of a batched launch (ibh_weighted_apply_many_device): the workgroups of batch q+1 start while
     // those of batch q still store, so launch ramp and drain are paid once per launch
     const double *__restrict__ X = XT ? XT0 + (long)blockIdx.y * xt_stride : bp.x[blockIdx.y];
@@ -952,9 +1013,21 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     const int rbase = rb * (REALIGN ? SR_STEP : SR_THREADS);
     const int r = rbase + threadIdx.x;
     const bool live = r < nrow;
-    if (!REALIGN && !live) return;
     const int fbeg = fy * fper;
     const int fend = min(nf, fbeg + fper);
+    if (chain_cnt) {
+        // last kernel of a chain: dispatched without a barrier behind the kernel that makes X.  Wait for that kernel's workgroups,
+        // then take this workgroup's fields of the (small: an A-space result) X into LDS through device-coherent loads -- once
+        // per workgroup; the gathers below read LDS (plain loads could hit stale lines, coherent ones bypass the L1 they live on)
+        chain_wait(chain_cnt, chain_n);
+        const int nel = (fend - fbeg) * chain_ncol;
+        for (int k = threadIdx.x; k < nel; k += SR_THREADS) {
+            const int ff = k / chain_ncol, c = k - ff * chain_ncol;
+            sr_chain[k] = chain_load(X + (long)(fbeg + ff) * ldx + c);
+        }
+        __syncthreads();
+    }
+    if (!REALIGN && !live) return;
     int beg = 0, end = 0;
     bool dead = false;
     if (live) { beg = rowptr[r]; end = rowptr[r + 1]; dead = wM[r] == 0.0; }
@@ -1072,11 +1145,20 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
             const double *xf = X + (long)f * ldx;
             // predicated, never multiplied by a padded zero: 0*NaN must not leak into a row
             double a = 0.0;
-            if (n > 0) a = v0 * xf[c0];
-            if (n > 1) a = fma(v1, xf[c1], a);
-            if (n > 2) a = fma(v2, xf[c2], a);
-            if (n > 3) a = fma(v3, xf[c3], a);
-            for (int k = beg + 4; k < end; ++k) a = fma(vals[k], xf[colind[k]], a);
+            if (chain_cnt) {                            // (X comes from the kernel this one was dispatched behind without a barrier: staged)
+                const double *xs = sr_chain + (f - fbeg) * chain_ncol;
+                if (n > 0) a = v0 * xs[c0];
+                if (n > 1) a = fma(v1, xs[c1], a);
+                if (n > 2) a = fma(v2, xs[c2], a);
+                if (n > 3) a = fma(v3, xs[c3], a);
+                for (int k = beg + 4; k < end; ++k) a = fma(vals[k], xs[colind[k]], a);
+            } else {
+                if (n > 0) a = v0 * xf[c0];
+                if (n > 1) a = fma(v1, xf[c1], a);
+                if (n > 2) a = fma(v2, xf[c2], a);
+                if (n > 3) a = fma(v3, xf[c3], a);
+                for (int k = beg + 4; k < end; ++k) a = fma(vals[k], xf[colind[k]], a);
+            }
             acc[g] = dead ? fill : a;
         }
         }
@@ -1774,8 +1856,9 @@ void weighted_pair_prepare(const ibh_weighted *first, const ibh_weighted *second
     first->pair_uid = second->uid;
 }
 
+static unsigned pair_grid_blocks(const ibh_weighted *first, int nvar);
 void spmm_launch_pair(const ibh_weighted *first, const ibh_weighted *second, const double *dA, int nvar, int64_t lda, double *dB1,
-                      int64_t ldb1, double *dB2, int64_t ldb2, double fill, hipStream_t stream)
+                      int64_t ldb1, double *dB2, int64_t ldb2, double fill, hipStream_t stream, unsigned *done)
 {
     HandleScope hs_(first);
     IBH_CHECK(first->pair_second == second && first->pair_uid == second->uid && first->grp_n > 0,
@@ -1786,7 +1869,7 @@ void spmm_launch_pair(const ibh_weighted *first, const ibh_weighted *second, con
     IBH_CHECK(first->conservative && second->conservative, "pair apply: smoothed (non-conservative) matrices take separate applies");
     BatchPtrs bp{};
     bp.x[0] = dA; bp.y[0] = dB1;
-    const PairView pv{first->pair_w.p, first->pair_mask.p, first->pair_row.p, second->wM.p, dB2, (long)ldb2};
+    const PairView pv{first->pair_w.p, first->pair_mask.p, first->pair_row.p, second->wM.p, dB2, (long)ldb2, done};
     const int nw = get_tuning("rowgroup_waves", nvar >= 32 ? 8 : 4), tw = get_tuning("rowgroup_tw", first->nnz < (1 << 20) ? 32 : 64);
 #define IBH_RGP(N, TT) launch_rowgroup<N, 8, TT>(first, bp, 1, nvar, (long)lda, (long)ldb1, fill, stream, &pv)
     if (use_grouptile(first, nvar)) {
@@ -1797,6 +1880,48 @@ void spmm_launch_pair(const ibh_weighted *first, const ibh_weighted *second, con
     first->last_kernel = 5;
     second->last_kernel = 5;
     ++first->napply; ++second->napply;
+}
+// workgroups of the pair launch of (first, nvar): what the chain's last kernel waits for
+static unsigned pair_grid_blocks(const ibh_weighted *first, int nvar) {
+    int xcd_mode;
+    if (use_grouptile(first, nvar)) return (unsigned)rowblock_grid(first->grp_n, ceil_div(nvar, 16), xcd_mode);
+    const int nw = get_tuning("rowgroup_waves", nvar >= 32 ? 8 : 4);
+    return (unsigned)rowblock_grid(first->grp_n, ceil_div(nvar, nw == 8 ? 8 : 4), xcd_mode);
+}
+// B1 = first * A, B2 = second * B1 (the fused pair), B3 = third * B2: the chain ice -> elevation classes -> atmosphere -> ice of
+// BASELINE config 3 (EvI, AvE, IvA): the pair launch and the third matrix's apply, stream-ordered.
+// ibh_set_tuning("chain_overlap", 1): the second launch is dispatched WITHOUT a barrier behind the first (hipExtAnyOrderLaunch) --
+// its launch latency runs while the first kernel computes -- and its workgroups wait on a device flag the first kernel's last
+// workgroup raises once all results are out (chain_begin / chain_signal / chain_wait; the first kernel's packet precedes it in
+// the queue, so its workgroups are placed first: the waiting ones cannot starve them).  Bitwise the ordered launches, and MEASURED
+// SLOWER on MI355X / ROCm 7.2 (5 km, 16 fields, back-to-back chains: 33 us per chain against 15.9 ordered; 68 us with agent-scope
+// acquire fences in the waiting workgroups -- every one of them invalidates its XCD's L2 --, 43 with device-coherent loads of X,
+// 33 with X staged in LDS and the flag only read; the length of the sleep in the wait loop changes nothing; under rocprofv3 the
+// pair kernel lasts 28 us instead of 9 with the waiting kernel resident): off by default, kept for a runtime where an unordered
+// dispatch is cheap.
+void spmm_launch_chain(const ibh_weighted *first, const ibh_weighted *second, const ibh_weighted *third, const double *dA, int nvar, int64_t lda,
+                       double *dB1, int64_t ldb1, double *dB2, int64_t ldb2, double *dB3, int64_t ldb3, double fill, hipStream_t stream)
+{
+    IBH_CHECK(third->ncol == second->nrow, "chain: the third matrix reads %d columns, the second makes %d rows", third->ncol, second->nrow);
+    if (nvar <= 0 || first->nrow == 0) return;
+    bool overlap = get_tuning("chain_overlap", 0) != 0 && third->conservative && third->nrow > 0;
+    if (overlap) {
+        HandleScope hs_(third);
+        const ShortrowPlan sp = shortrow_plan(third, nvar, 1);
+        overlap = pick_kernel(third, nvar, 1) == 2 && !sp.use_xt && (size_t)sp.fper * (size_t)third->ncol * sizeof(double) <= 32 * 1024;
+    }
+    if (!overlap) {
+        spmm_launch_pair(first, second, dA, nvar, lda, dB1, ldb1, dB2, ldb2, fill, stream, nullptr);
+        spmm_launch(third, dB2, nvar, ldb2, dB3, ldb3, fill, 0, stream);
+        return;
+    }
+    if (!first->chain_cnt.p) { first->chain_cnt.alloc(2); first->chain_cnt.zero(stream); }
+    unsigned nblk;
+    { HandleScope hs_(first); nblk = pair_grid_blocks(first, nvar); }
+    spmm_launch_pair(first, second, dA, nvar, lda, dB1, ldb1, dB2, ldb2, fill, stream, first->chain_cnt.p);
+    g_chain_cnt = first->chain_cnt.p; g_chain_n = nblk;
+    spmm_launch(third, dB2, nvar, ldb2, dB3, ldb3, fill, 0, stream);
+    IBH_CHECK(g_chain_cnt == nullptr, "internal: the chain's last apply did not take the counter");
 }
 
 static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &bp, int nbatch, int nvar, int64_t lda,
@@ -1922,10 +2047,16 @@ static void launch_one_impl(const ibh_weighted *w, int kernel, const BatchPtrs &
                 e_first = nullptr;
                 xld = p.ldt;
             }
+            unsigned *ccnt = g_chain_cnt;
+            const unsigned cn = g_chain_n;
+            g_chain_cnt = nullptr; g_chain_n = 0;
+            IBH_CHECK(!ccnt || (!p.use_xt && nbatch == 1), "internal: a chain's last apply must read its input in place");
+            const size_t clds = ccnt ? (size_t)fper * (size_t)w->ncol * sizeof(double) : 0;
 #define IBH_SR4(NT, GG, RA, XTT)                                                                                \
-    hipExtLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, RA, XTT>), grid, dim3(SR_THREADS), 0, stream, e_first, e_last, 0,    \
+    hipExtLaunchKernelGGL((spmm_shortrow_kernel<NT, GG, RA, XTT>), grid, dim3(SR_THREADS), clds, stream, e_first, e_last,   \
+                          ccnt ? hipExtAnyOrderLaunch : 0,                                                                  \
                           w->rowptr.p, w->colind.p, w->val.p, bq, (const double *)w->xt.p, xt_stride, xld, (long)ldb,       \
-                          w->nrow, nvar, fper, w->wM.p, fill)
+                          w->nrow, nvar, fper, w->wM.p, fill, ccnt, cn, w->ncol)
 #define IBH_SR(NT, GG)                                                                                          \
     do {                                                                                                        \
         if (realign) { if (p.use_xt) IBH_SR4(NT, GG, true, true); else IBH_SR4(NT, GG, true, false); }          \

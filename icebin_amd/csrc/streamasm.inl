@@ -1478,8 +1478,8 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     // SIMD (66 KB of LDS per workgroup), and R = 4 beats 16: more waves matter more than full lanes.  1 km Greenland (1 143 long
     // ranges) loses by 2 x.  So: column sums of grids with many ranges only.
     const int forced_rl = get_tuning("assemble_stream_rowsl", -1);
-    const bool rowsl = forced_rl >= 0 ? forced_rl != 0 : (!g_is_row && nr >= 16384);
-    const int avg_cls = g.NC == 1 ? 1 : std::max(1, (int)((hme[3] + (uint32_t)std::max(nr, 1) - 1) / (uint32_t)std::max(nr, 1)));
+    const bool rowsl = forced_rl >= 0 ? forced_rl != 0 : (!g_is_row && nAr >= 16384);       // (by the whole grid's ranges: every rank of a shared build takes the same kernel)
+    const int avg_cls = g.NC == 1 ? 1 : std::max(1, (int)((G0[world] + (uint64_t)std::max(nAr, 1) - 1) / (uint64_t)std::max(nAr, 1)));     // (the whole grid's, as rowsl)
     const int rows_R = std::max(1, std::min(16, get_tuning("assemble_stream_rowsl_r", std::min(4, 16 / avg_cls))));
     const dim3 grl(ceil_div(nr, 4 * rows_R));
     double *sval = nullptr;

@@ -347,6 +347,12 @@ public:
                            long ldb2, double fill, void *stream) const {
         check(ibh_weighted_apply_pair_device(h_, second.h_, dA_b, nvar, lda, dB1_b, ldb1, dB2_b, ldb2, fill, stream));
     }
+    /** the chain of BASELINE config 3 (EvI, AvE, IvA): the fused pair, then `third` on its result, the third product's launch
+        overlapped with the pair kernel (ibh_weighted_apply_chain_device); bitwise the pair apply followed by third.apply_device */
+    void apply_chain_device(Weighted const &second, Weighted const &third, const double *dA_b, int nvar, long lda, double *dB1_b, long ldb1,
+                            double *dB2_b, long ldb2, double *dB3_b, long ldb3, double fill = std::nan(""), void *stream = nullptr) const {
+        check(ibh_weighted_apply_chain_device(h_, second.h_, third.h_, dA_b, nvar, lda, dB1_b, ldb1, dB2_b, ldb2, dB3_b, ldb3, fill, stream));
+    }
     /** apply() of world x nvar_local fields sharded by field over the ranks of `comm`: this rank's dA_local (nvar_local x lda)
         -> dB_all (world*nvar_local x ldb, the same on every rank once comm.wait(stream) has been honoured).  The SpMM runs on
         `stream`, the peer-to-peer exchange on the communicator's own stream, block_fields fields at a time (0: by size). */

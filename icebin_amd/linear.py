@@ -298,6 +298,27 @@ class linear_Weighted:
                                                   ld(out2, second.nrow_d), float(fill), C.c_void_p(s)))
         return out1, out2
 
+    def apply_chain_device(self, second, third, dA, out1=None, out2=None, out3=None, fill=float("nan"), stream=None):
+        """B1 = self * A, B2 = second * B1 (the fused pair: pair_prepare(second) first), B3 = third * B2 with the third product's
+        launch overlapped with the pair kernel (ibh_weighted_apply_chain_device); returns (B1, B2, B3), bitwise the pair apply
+        followed by third.apply_device."""
+        import torch
+        assert dA.is_cuda and dA.dtype == torch.float64 and dA.dim() == 2 and dA.stride(1) == 1 and dA.shape[1] == self.ncol_d
+        nvar = dA.shape[0]
+        outs = []
+        for o, n in ((out1, self.nrow_d), (out2, second.nrow_d), (out3, third.nrow_d)):
+            if o is None:
+                o = _aligned_planes(torch, nvar, n, dA.device)
+            assert o.is_cuda and o.dtype == torch.float64 and o.shape == (nvar, n) and o.stride(1) == 1
+            outs.append(o)
+        s = torch.cuda.current_stream(dA.device).cuda_stream if stream is None else stream
+        ld = lambda t, n: t.stride(0) if nvar > 1 else max(t.stride(0), n)
+        check(lib().ibh_weighted_apply_chain_device(self._h, second._h, third._h, C.c_void_p(dA.data_ptr()), nvar, ld(dA, self.ncol_d),
+                                                   C.c_void_p(outs[0].data_ptr()), ld(outs[0], self.nrow_d), C.c_void_p(outs[1].data_ptr()),
+                                                   ld(outs[1], second.nrow_d), C.c_void_p(outs[2].data_ptr()), ld(outs[2], third.nrow_d),
+                                                   float(fill), C.c_void_p(s)))
+        return tuple(outs)
+
     def apply_transformed_device(self, dV, T, b, out=None, fill=float("nan"), stream=None):
         """The coupler's fused product  M * (V*T + b)  on HBM-resident fields (IceCoupler.cpp:203-252,
         :445): dV torch.float64 CUDA [nvar_in, ncol_d]; T [nvar_in, nvar_out] (the sparse variable

@@ -265,6 +265,15 @@ int ibh_weighted_prepare(const ibh_weighted *w, int32_t nvar, int32_t nbatch);
 int ibh_weighted_pair_prepare(const ibh_weighted *first, const ibh_weighted *second, int32_t nvar);
 int ibh_weighted_apply_pair_device(const ibh_weighted *first, const ibh_weighted *second, const double *dA_b, int32_t nvar, int64_t lda,
                                    double *dB1_b, int64_t ldb1, double *dB2_b, int64_t ldb2, double fill, void *stream);
+/* The chain of BASELINE config 3, ice -> elevation classes -> atmosphere -> ice, in one call: B1 = first * A and B2 = second * B1
+ * as the fused pair above (ibh_weighted_pair_prepare(first, second) first), B3 = third * B2 (IvA; the reference: three
+ * Weighted_Eigen::apply calls, IceCoupler.cpp:203-252 builds its inputs the same way).  Two stream-ordered launches; B1, B2, B3 are
+ * bitwise what the pair apply followed by ibh_weighted_apply_device(third) writes; a pure enqueue (graph-capturable).
+ * ibh_set_tuning("chain_overlap", 1) dispatches the second launch without a queue barrier behind the pair kernel and lets its
+ * workgroups wait on a device flag instead (same bits; measured slower on MI355X / ROCm 7.2: DESIGN.md K1f). */
+int ibh_weighted_apply_chain_device(const ibh_weighted *first, const ibh_weighted *second, const ibh_weighted *third, const double *dA_b,
+                                    int32_t nvar, int64_t lda, double *dB1_b, int64_t ldb1, double *dB2_b, int64_t ldb2, double *dB3_b,
+                                    int64_t ldb3, double fill, void *stream);
 int ibh_weighted_reserve(const ibh_weighted *w, int32_t nvar);
 /* The coupler's fused product B = M * (A*T + b) (IceCoupler.cpp:203-252 construct_ice_ivalsI and
  * :445 gcm_ivalsX = M * (ice_ovalsI*T + b)): dA_b [nvar_in x ncol_d] field-major device pointer,

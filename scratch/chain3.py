@@ -94,6 +94,34 @@ e1.record(); torch.cuda.synchronize()
 fused_graph_us = e0.elapsed_time(e1) * 1e3 / N
 fused_same = bool(torch.equal(yI.view(torch.int64), ref.view(torch.int64)))
 fused_close = float(((yI - ref).abs().max() / ref.abs().max()).item())
+# (c2) the chain call: the fused pair, then IvA dispatched without a queue barrier and waiting on a device counter
+def chain_overlapped(x):
+    W["EvI"].apply_chain_device(W["AvE"], W["IvA"], x, out1=yE, out2=yA, out3=yI)
+
+
+yI.zero_()
+icebin_amd.set_tuning("chain_overlap", 1)
+for x in X[:4]:
+    chain_overlapped(x)
+torch.cuda.synchronize()
+e0.record()
+for i in range(N):
+    chain_overlapped(X[i % len(X)])
+e1.record(); torch.cuda.synchronize()
+over_eager_us = e0.elapsed_time(e1) * 1e3 / N
+over_same = bool(torch.equal(yI.view(torch.int64), ref.view(torch.int64)))
+yI.zero_()
+ograph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(ograph):
+    chain_overlapped(X[(N - 1) % len(X)])
+ograph.replay(); ograph.replay(); torch.cuda.synchronize()
+over_graph_same = bool(torch.equal(yI.view(torch.int64), ref.view(torch.int64)))
+e0.record()
+for i in range(N):
+    ograph.replay()
+e1.record(); torch.cuda.synchronize()
+over_graph_us = e0.elapsed_time(e1) * 1e3 / N
+icebin_amd.set_tuning("chain_overlap", -2 ** 31)
 # (d) 16 consecutive fused chains (16 time steps' worth, rotating inputs) captured as ONE graph: one submission per 16 chains
 big = torch.cuda.CUDAGraph()
 with torch.cuda.graph(big):
@@ -133,5 +161,7 @@ print("%s chain EvI->AvE->IvA, %d fields: kernels %s; %.1f MB algorithmic per ch
 print("   EvI+AvE fused into one launch (apply_pair_device) + IvA: eager %.2f us per chain, hipGraph replay %.2f us (%.1f %% of 8 TB/s); final field bitwise "
       "the three-launch chain's: %s (max rel diff %.1e); 16 fused chains in one graph: %.2f us per chain" %
       (fused_eager_us, fused_graph_us, B / fused_graph_us / 1e3 / 8000 * 100, fused_same, fused_close, big_us), flush=True)
+print("   the chain call (apply_chain_device: IvA dispatched without a barrier behind the pair kernel, waits on a device counter): eager %.2f us per chain, "
+      "final field bitwise the three-launch chain's: %s; as a replayed hipGraph %.2f us, bitwise: %s" % (over_eager_us, over_same, over_graph_us, over_graph_same), flush=True)
 print("   %d independent %d-field batches through the chain, three batched launches (apply_many_device): %.2f us per chain (%.1f %% of 8 TB/s)"
       % (nb, nf, batched_us, B / batched_us / 1e3 / 8000 * 100), flush=True)

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-root=$(pwd); out=$root/gpurun_out/r03/asm_g5; mkdir -p $out
+root=$(pwd); out=$root/gpurun_out/r05/asm_g5; mkdir -p $out
 for m in AvI EvI IvE; do
   (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $out/$m -- python3 $root/scratch/time_assembly.py g5 $m > $out/$m.log 2>&1)
   python3 - <<PY

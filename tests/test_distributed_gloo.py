@@ -384,7 +384,7 @@ def _hip_runtime():
     return rt
 
 
-def _worker_asm_sharded(rank, world, port, q):
+def _worker_asm_sharded(rank, world, port, q, configs=("g5", "g20"), stage_mb=64):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -395,7 +395,7 @@ def _worker_asm_sharded(rank, world, port, q):
         from icebin_amd.distributed import Communicator
         torch.cuda.set_device(0)                        # the ranks share the box's one card: the transport is host-staged
         hip = _hip_runtime()
-        stage = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+        stage = torch.empty(stage_mb << 20, dtype=torch.uint8).pin_memory()
         calls = {"blocks": 0, "gatherv": 0, "bytes": 0}
 
         def move(d_base, pieces, r_, stream):
@@ -440,7 +440,7 @@ def _worker_asm_sharded(rank, world, port, q):
                 notes.append(what)
             ok = ok and good
 
-        for config in ("g5", "g20"):
+        for config in configs:
             g = syn.make_grids(config)
             em = syn.dome_elevmask(g)
             mm = icebin_amd.from_synthetic(g)
@@ -463,6 +463,20 @@ def _worker_asm_sharded(rank, world, port, q):
             ws, w1 = rm.matrix_d_sharded(comm, "AvI", (None, ident[0])), rm.matrix_d("AvI", (None, ident[1]))
             ok = ok and not ws.built_sharded()
             same(ws, w1, config + " AvI identity dimI")
+            # the coupler's step (IceCoupler.cpp:361-377, 462-467): EvI {dimE1, identity dimI}, AvI {dimA1, identity dimI},
+            # IvE {identity dimI, dimE1 as EvI left it}, XvE {identity dimX, dimE1} -- identity and pre-populated sets index their
+            # arrays by sparse position, a rank's pieces are not one range per array: every rank builds these redundantly (the
+            # collective call returns the same, complete matrix everywhere; built_sharded() says which way it was made)
+            nE = g["nA"] * len(g["hcdefs"])
+            sets = []
+            for sharded in (True, False):
+                dimI, dimX, dimE, dimA = icebin_amd.SparseSet.identity(g["nI"]), icebin_amd.SparseSet.identity(len(g["ex_area"])), icebin_amd.SparseSet(nE), icebin_amd.SparseSet(g["nA"])
+                build = (lambda name, dims, **kw: rm.matrix_d_sharded(comm, name, dims, **kw)) if sharded else (lambda name, dims, **kw: rm.matrix_d(name, dims, **kw))
+                sets.append([build("EvI", (dimE, dimI), scale=False, correctA=False), build("AvI", (dimA, dimI), scale=False, correctA=True),
+                             build("IvE", (dimI, dimE), scale=True, correctA=True), build("XvE", (dimX, dimE), scale=False, correctA=True)])
+            for a, b, name in zip(sets[0], sets[1], ("EvI", "AvI", "IvE", "XvE")):
+                ok = ok and not a.built_sharded()
+                same(a, b, "%s coupler %s" % (config, name))
         # an elevation above the last class: every rank raises the reference's error, whichever rank's block holds the cell
         g = syn.make_grids("g20")
         em = syn.dome_elevmask(g)
@@ -479,6 +493,25 @@ def _worker_asm_sharded(rank, world, port, q):
         del comm
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_assembly_at_1km_takes_the_streamed_builds_size_branches():
+    """The shared build with two ranks on the 1 km grid (4.4 M exchange cells): a rank's block starts in the middle of the grid
+    (sx0 != 0), the emit pass walks tiles, the byte passes run several waves, the kernel choices that depend on the number of
+    ranges are taken from the WHOLE grid -- all eight matrices, both branches, bitwise the single-rank build; and the coupler's
+    four calls on identity / pre-populated sets come out equal (redundantly built)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_asm_sharded, args=(r, 2, port, q, ("g1",), 512)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert all(ok for _, ok, _, _ in got), got
 
 
 @pytest.mark.gpu

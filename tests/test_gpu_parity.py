@@ -152,6 +152,28 @@ def test_fused_pair_evi_then_ave_is_the_two_applies(config, kw, rowgroup_form):
             ref_a = oA.apply(ref_e[:, operm], fill=-1.0, force_conservation=False)
             order_a = np.argsort(AvE.dim(0))[np.searchsorted(np.sort(AvE.dim(0)), oA.dims[0])]
             assert rel_linf(b2.cpu().numpy()[:, order_a], ref_a) <= FIELD_RTOL, (config, shared, nvar)
+        # the chain of BASELINE config 3 in one call: the pair, then IvA on its result (its launch overlapped with the pair kernel,
+        # its workgroups waiting on a device counter) -- bitwise the pair apply followed by the IvA apply, again and again (the
+        # counters re-arm themselves), and with a last matrix the overlapped path does not serve (ordered launches)
+        if not shared:
+            IvA = rm.matrix("IvA")
+            permA = np.argsort(AvE.dim(0))[np.searchsorted(np.sort(AvE.dim(0)), IvA.dim(1))]
+            assert np.array_equal(permA, np.arange(len(permA)))      # (both numbered by first sight of the GCM cells: the same order)
+            for nvar in (16, 3, 40):
+                x = torch.from_numpy(syn.fields(nvar, EvI.ncol_d, seed=70 + nvar)).cuda()
+                x[nvar // 2, ::9] = float("nan")
+                b1, b2 = EvI.apply_pair_device(AvE, x, fill=-1.0)
+                b3 = IvA.apply_device(b2, fill=-1.0, force_conservation=False).clone()
+                for overlap in (0, 1):          # ordered launches (the default), and the unordered dispatch with the device flag
+                    icebin_amd.set_tuning("chain_overlap", overlap)
+                    try:
+                        for rep in range(3):
+                            c1, c2, c3 = EvI.apply_chain_device(AvE, IvA, x, fill=-1.0)
+                            torch.cuda.synchronize()
+                            for a, b in ((c1, b1), (c2, b2), (c3, b3)):
+                                assert torch.equal(a.view(torch.int64), b.view(torch.int64)), (config, nvar, overlap, rep)
+                    finally:
+                        icebin_amd.set_tuning("chain_overlap", -2 ** 31)
         # inside a hipGraph
         x = torch.from_numpy(syn.fields(16, EvI.ncol_d, seed=5)).cuda()
         o1, o2 = EvI.apply_pair_device(AvE, x, fill=-1.0)
