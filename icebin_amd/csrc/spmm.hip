@@ -1193,6 +1193,14 @@ __global__ __launch_bounds__(SR_THREADS) void spmm_shortrow_kernel(
     }
 }
 
+// (Round 5, tried and removed -- "fieldlane": I-row matrices on >= 64 fields with lane = FIELD, a wave owning 16 rows, the row
+// structure wave-uniform (columns and weights through v_readlane into the scalar offset of one coalesced 512-byte load of the
+// transposed input per entry, one FMA, no masks), row sums through an LDS tile that leaves transposed.  Bitwise the row kernel on
+// every matrix tried, smoothed ones included, and slower everywhere on the Antarctic sheet, 128 fields, IvE / IvA against 4.1 /
+// 2.8 ms: a tile per wave stored as 16 or 8 rows per plane (128- / 64-byte pieces) 6.8 / 5.8 and 8.6-9.0 / 7.5-8.0 ms -- with 22
+// scalar instructions per entry or with 4, the same; HBM traffic exact (16.9 GB written, 1.6 fetched) -- and a tile per workgroup
+// with the row kernel's own 512-byte stores 7.1 / 6.1 ms: four workgroups of 33 KB per CU and six to eight dependent round trips
+// per 64 rows.  The thread-per-row kernel keeps many more loads in flight per wave; it stays.)
 // ---- conservation correction (non-conservative matrices only) ------------------------------
 // out[k] = sum_j w[j] * A[k*lda + j] over j with w[j] != 0, in a fixed order: the vector is cut into <= WD_MAXCHUNK chunks
 // (one workgroup each per variable: a single workgroup per variable reads 10^5..10^7 elements at one CU's bandwidth --
