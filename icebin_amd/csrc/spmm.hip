@@ -1629,7 +1629,10 @@ static int pick_kernel(const ibh_weighted *w, int nvar, int nbatch = 1) {
         const bool sweep_ok = w->sweep_ntask > 0 && sweep_lanes(nvar, nbatch) >= get_tuning("sweep_min_nvar", 32) && get_tuning("sweep_auto", 1) &&
                               (w->band_eligible || nbatch >= get_tuning("sweep_min_batch", 4) || (huge && nvar >= 128));
         const bool grp_ok = w->grp_n > 0 && nvar >= 4 && get_tuning("rowgroup_auto", 1);
-        if (grp_ok && (nvar >= 32 || !sweep_ok)) kernel = 5;
+        // (round 5: on matrices of 2^24 entries and more the tiled row groups beat the sweep in batched launches of few fields too --
+        // the Antarctic EvI, 16 fields, batches of 4: bench.py 0.487 of peak through the sweep, measured again below)
+        const bool tiles_win = w->gt_ntile > 0 && w->nnz >= (1l << 24) && get_tuning("rowgroup_form", -1) != 0;
+        if (grp_ok && (nvar >= 32 || !sweep_ok || tiles_win)) kernel = 5;
         else if (sweep_ok) kernel = 4;
     }
     if (kernel == 5 && w->grp_n == 0) kernel = 1;             // no row groups were built for this matrix
