@@ -1252,6 +1252,22 @@ __global__ void k_sa_shift(uint32_t *__restrict__ Pw, uint32_t *__restrict__ Lw,
     if (i <= nr) { gbase[r0 + i] += dG; ebase[r0 + i] += dE; }
 }
 __global__ void k_sa_set_u32(uint32_t *p, uint32_t v) { *p = v; }
+// Shared build of an A/E-row matrix on an IDENTITY P set: Mw is indexed by sparse position, a rank's sums are scattered over it --
+// but they are exactly the P keys first seen in its slice, which the flag pass counted and the scans numbered.  Every such cell
+// puts {sparse position, its sum} at its first-seen rank; the pairs of all ranks are gathered and scattered on every rank.
+__global__ void k_sa_pack_mw(SaBuf sb, const int32_t *__restrict__ exI, int pkey_x, const double *__restrict__ Mw, int32_t *__restrict__ cidx,
+                             double *__restrict__ cval) {
+    const long x = sb.sx0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= sb.sx1 || !(sb.code[x] & SA_P)) return;
+    const uint32_t k = sa_prank_at(sb.Pw, sb.pbits, x);
+    const int32_t pos = pkey_x ? (int32_t)x : exI[x];
+    cidx[k] = pos; cval[k] = Mw[pos];
+}
+__global__ void k_sa_unpack_mw(const int32_t *__restrict__ cidx, const double *__restrict__ cval, long k0, long k1, long n, double *__restrict__ Mw) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || (k >= k0 && k < k1)) return;                   // (this rank's own sums are in place)
+    Mw[cidx[k]] = cval[k];
+}
 
 // false: not served here (nothing has been touched: fast_build's own kernels run next).
 // comm != nullptr: the SHARDED build of ibh_regrid_matrices_matrix_d_sharded -- every rank of the communicator calls this with the
@@ -1288,9 +1304,13 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     // an I-row matrix on an identity ice set (the coupler's IvE, IceCoupler.cpp:462): its rows lie in ice-cell order, not in
     // first-seen order -- row lengths are scattered by ice cell and scanned over the ice cells
     const bool by_ice = !g_is_row && pkey == KEY_I && pmode == 0;
-    // sharded: the pieces of a rank must be contiguous in every result array -- sets numbered by this build (an identity or a
-    // pre-populated set indexes Mw by sparse position); at most 8 ranks (one 256-byte read-back carries all counters)
-    if (world > 1 && (pmode != 1 || !g_fresh || world > 8 || P.nAr < world)) return false;
+    // sharded: the pieces of a rank must be contiguous in every result array -- sets numbered by this build; at most 8 ranks (one
+    // 256-byte read-back carries all counters).  An A/E-row matrix on an IDENTITY P set (the coupler's EvI / AvI over the identity
+    // dimI, IceCoupler.cpp:366-377) is served too: its CSR pieces are contiguous as they are (an entry's column is its sparse
+    // index), only Mw is scattered -- the sums travel as {position, value} pairs at their first-seen ranks (k_sa_pack_mw).
+    const bool ident_p = world > 1 && pmode == 0 && g_is_row;
+    if (world > 1 && ((pmode != 1 && !ident_p) || !g_fresh || world > 8 || P.nAr < world)) return false;
+    const bool pscan = pmode == 1 || ident_p;                    // the P keys are numbered (first-seen ranks)
     const int merge = (sp->row_key != KEY_X && sp->col_key != KEY_X) ? 1 : 0;
     const int S = uses_ep ? 2 : 1;
     if (gr->nhc > 64) return false;
@@ -1391,7 +1411,7 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     // (world > 1: one more wave than the slice has -- the zero count behind the last one makes the scan yield the totals in place)
     {
         const long nws = world == 1 ? nW : nwl + 1;
-        const MsCh chP{p.fresh ? (const void *)(sb.cntP + gW0) : nullptr, sb.Pw + gW0, world == 1 ? d_cnt + 2 : nullptr, p.fresh ? nws : 0, 1, 0};
+        const MsCh chP{pscan ? (const void *)(sb.cntP + gW0) : nullptr, sb.Pw + gW0, world == 1 ? d_cnt + 2 : nullptr, pscan ? nws : 0, 1, 0};
         const bool lch = !g_is_row && !by_ice;
         const MsCh chL{lch ? (const void *)(sb.cntL + gW0) : nullptr, lch ? sb.Lw + gW0 : nullptr, world == 1 ? d_cnt + 5 : nullptr, lch ? nws : 0, 0, 0};
         const MsCh chG{g.r_ncls + sb.sr0, g.gbase + sb.sr0, d_cnt + 3, nr, 0, 1};
@@ -1409,7 +1429,7 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
             sa_scan_channels(chs2, 2, st);
         }
     }
-    if (world > 1) hipLaunchKernelGGL(k_sa_slice_counts, dim3(1), dim3(64), 0, st, sb, p.fresh, g_is_row ? 0 : 1, d_cnt);
+    if (world > 1) hipLaunchKernelGGL(k_sa_slice_counts, dim3(1), dim3(64), 0, st, sb, pscan ? 1 : 0, g_is_row ? 0 : 1, d_cnt);
     IBH_HIP(hipGetLastError());
     if (world > 1) comm_exchange_blocks(comm, reinterpret_cast<double *>(d_tot), 4, 4, st);          // exchange 1
     uint32_t hh[64];
@@ -1435,7 +1455,7 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     const int np_d = p.fresh ? (int)P0[world] : (int)extent_of(pkey);
     const int ng_d = g_fresh ? (int)G0[world] : gset->n;
     // local -> global numbering of this rank's slice
-    if (world > 1) hipLaunchKernelGGL(k_sa_shift, dim3(ceil_div(std::max<long>(nwl + 1, nr + 1), 256l)), dim3(256), 0, st, p.fresh ? sb.Pw : nullptr, g_is_row ? nullptr : sb.Lw,
+    if (world > 1) hipLaunchKernelGGL(k_sa_shift, dim3(ceil_div(std::max<long>(nwl + 1, nr + 1), 256l)), dim3(256), 0, st, pscan ? sb.Pw : nullptr, g_is_row ? nullptr : sb.Lw,
                        gW0, nwl + 1, (uint32_t)(P0[rank] - hme[6]), (uint32_t)(L0[rank] - hme[7]), g.gbase, g.ebase, sb.sr0, nr, (uint32_t)G0[rank], (uint32_t)E0[rank]);
     if (world > 1) {                                             // exchange 2: what the ranks look up in each other's slices
         // (the code bytes stay at home: every pass reads them inside its own slice only)
@@ -1565,10 +1585,25 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         for (int k = 0; k <= world; ++k) {
             o4e[k] = (int64_t)En[k] * 4; o8e[k] = (int64_t)En[k] * 8; o4r[k] = (int64_t)Rw[k] * 4; o8r[k] = (int64_t)Rw[k] * 8; o8c[k] = (int64_t)Cl[k] * 8;
         }
+        if (ident_p) {
+            // identity P set: no P table; Mw as {position, value} pairs in first-seen order, scattered on every rank
+            const long npk = (long)P0[world];
+            int32_t *cidx = A.get<int32_t>((size_t)std::max<long>(npk, 1));
+            double *cval = A.get<double>((size_t)std::max<long>(npk, 1));
+            if (sb.sx1 > sb.sx0)
+                hipLaunchKernelGGL(k_sa_pack_mw, dim3((unsigned)ceil_div(sb.sx1 - sb.sx0, 256l)), dim3(256), 0, st, sb, pl.exI, pkey == KEY_X ? 1 : 0, w->Mw.p, cidx, cval);
+            std::vector<int64_t> o4p(world + 1), o8p(world + 1);
+            for (int k = 0; k <= world; ++k) { o4p[k] = (int64_t)P0[k] * 4; o8p[k] = (int64_t)P0[k] * 8; }
+            void *bases[7] = {w->colind.p, w->val.p, w->rowptr.p, w->wM.p, gtable.p, cidx, cval};
+            const int64_t *offs[7] = {o4e.data(), o8e.data(), o4r.data(), o8r.data(), o8r.data(), o4p.data(), o8p.data()};
+            comm_gatherv(comm, 7, bases, offs, st);
+            if (npk) hipLaunchKernelGGL(k_sa_unpack_mw, dim3((unsigned)ceil_div(npk, 256l)), dim3(256), 0, st, cidx, cval, (long)P0[rank], (long)P0[rank + 1], npk, w->Mw.p);
+        } else {
         void *bases[7] = {w->colind.p, w->val.p, w->rowptr.p, w->wM.p, w->Mw.p, g_is_row ? (void *)gtable.p : (void *)ptable.p,
                           g_is_row ? (void *)ptable.p : (void *)gtable.p};
         const int64_t *offs[7] = {o4e.data(), o8e.data(), o4r.data(), o8r.data(), o8c.data(), o8r.data(), o8c.data()};
         comm_gatherv(comm, 7, bases, offs, st);
+        }
     }
     auto commit = [&](ibh_sparse_set *set, int64_t extent, DevBuf<int64_t> &table, int n) {
         set->sparse_extent = extent;

@@ -459,14 +459,19 @@ def _worker_asm_sharded(rank, world, port, q, configs=("g5", "g20"), stage_mb=64
             ws, w1 = rm.matrix_d_sharded(comm, "EvA"), rm.matrix_d("EvA")
             ok = ok and not ws.built_sharded()
             same(ws, w1, config + " EvA")
-            ident = [icebin_amd.SparseSet.identity(g["nI"]) for _ in range(2)]
-            ws, w1 = rm.matrix_d_sharded(comm, "AvI", (None, ident[0])), rm.matrix_d("AvI", (None, ident[1]))
-            ok = ok and not ws.built_sharded()
-            same(ws, w1, config + " AvI identity dimI")
-            # the coupler's step (IceCoupler.cpp:361-377, 462-467): EvI {dimE1, identity dimI}, AvI {dimA1, identity dimI},
-            # IvE {identity dimI, dimE1 as EvI left it}, XvE {identity dimX, dimE1} -- identity and pre-populated sets index their
-            # arrays by sparse position, a rank's pieces are not one range per array: every rank builds these redundantly (the
-            # collective call returns the same, complete matrix everywhere; built_sharded() says which way it was made)
+            # an A/E-row matrix on an identity P set IS shared (round 5): Mw travels as {position, value} pairs
+            for name, n_id in (("AvI", g["nI"]), ("EvI", g["nI"]), ("AvX", len(g["ex_area"])), ("EvX", len(g["ex_area"]))):
+                ident = [icebin_amd.SparseSet.identity(n_id) for _ in range(2)]
+                ws, w1 = rm.matrix_d_sharded(comm, name, (None, ident[0])), rm.matrix_d(name, (None, ident[1]))
+                if not ws.built_sharded():
+                    ok = False
+                    notes.append("%s %s on an identity set not shared" % (config, name))
+                same(ws, w1, "%s %s identity P set" % (config, name))
+            # the coupler's step (IceCoupler.cpp:361-377, 462-467): EvI {dimE1, identity dimI}, AvI {dimA1, identity dimI} -- shared:
+            # the CSR pieces of an A/E-row matrix are contiguous whatever the column numbering, Mw travels as pairs -- and
+            # IvE {identity dimI, dimE1 as EvI left it}, XvE {identity dimX, dimE1}: rows indexed by sparse position / columns of a
+            # pre-populated set, built redundantly by every rank (the collective call returns the same, complete matrix everywhere;
+            # built_sharded() says which way it was made)
             nE = g["nA"] * len(g["hcdefs"])
             sets = []
             for sharded in (True, False):
@@ -475,7 +480,9 @@ def _worker_asm_sharded(rank, world, port, q, configs=("g5", "g20"), stage_mb=64
                 sets.append([build("EvI", (dimE, dimI), scale=False, correctA=False), build("AvI", (dimA, dimI), scale=False, correctA=True),
                              build("IvE", (dimI, dimE), scale=True, correctA=True), build("XvE", (dimX, dimE), scale=False, correctA=True)])
             for a, b, name in zip(sets[0], sets[1], ("EvI", "AvI", "IvE", "XvE")):
-                ok = ok and not a.built_sharded()
+                if a.built_sharded() != (name in ("EvI", "AvI")):
+                    ok = False
+                    notes.append("%s coupler %s: built_sharded() %s" % (config, name, a.built_sharded()))
                 same(a, b, "%s coupler %s" % (config, name))
         # an elevation above the last class: every rank raises the reference's error, whichever rank's block holds the cell
         g = syn.make_grids("g20")
