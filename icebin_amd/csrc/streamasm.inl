@@ -1263,6 +1263,21 @@ __global__ void k_sa_pack_mw(SaBuf sb, const int32_t *__restrict__ exI, int pkey
     const int32_t pos = pkey_x ? (int32_t)x : exI[x];
     cidx[k] = pos; cval[k] = Mw[pos];
 }
+// The same for the column sums of an I/X-row matrix on a PRE-POPULATED G set (the coupler's dimE1 in XvE): a class of a range has
+// the compact index gbase[r] + erank[r][cls] (the numbering a fresh set would get) and sits at tab[key] of the caller's set.
+__global__ void k_sa_pack_mw_g(RgView rg, PlanView pl, FaG g, int sr0, int sr1, const double *__restrict__ Mw, int32_t *__restrict__ cidx,
+                               double *__restrict__ cval) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = sr0 + (int)(i / g.NC), cls = (int)(i % g.NC);
+    if (r >= sr1) return;
+    const int er = g.erank[(size_t)r * g.NC + cls];
+    if (er < 0) return;
+    const long iA = pl.riA[r];
+    const long gkey = g.key == KEY_E ? iA * rg.sA + (long)cls * rg.sHC : iA;
+    const uint32_t k = g.gbase[r] + (uint32_t)er;
+    const int32_t pos = g.tab[gkey];
+    cidx[k] = pos; cval[k] = Mw[pos];
+}
 __global__ void k_sa_unpack_mw(const int32_t *__restrict__ cidx, const double *__restrict__ cval, long k0, long k1, long n, double *__restrict__ Mw) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n || (k >= k0 && k < k1)) return;                   // (this rank's own sums are in place)
@@ -1308,8 +1323,14 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     // 256-byte read-back carries all counters).  An A/E-row matrix on an IDENTITY P set (the coupler's EvI / AvI over the identity
     // dimI, IceCoupler.cpp:366-377) is served too: its CSR pieces are contiguous as they are (an entry's column is its sparse
     // index), only Mw is scattered -- the sums travel as {position, value} pairs at their first-seen ranks (k_sa_pack_mw).
+    // An X-row matrix on the identity dimX (the coupler's XvE, :467) has its rows in exchange-cell order: a block of cells is a block
+    // of rows.  A pre-populated G set (its dimE1, numbered by EvI) is looked up in the table every rank has; the column sums sit
+    // at the caller's dense ids and travel as pairs too, at the ranks a fresh numbering would give the classes (k_sa_pack_mw_g).
+    // Not served: I rows on an identity dimI (by_ice: rows in ice-cell order, a rank's rows are scattered over the matrix).
     const bool ident_p = world > 1 && pmode == 0 && g_is_row;
-    if (world > 1 && ((pmode != 1 && !ident_p) || !g_fresh || world > 8 || P.nAr < world)) return false;
+    const bool ident_x_rows = world > 1 && pmode == 0 && !g_is_row && pkey == KEY_X;
+    const bool prepop_g = world > 1 && !g_fresh;                 // (an E column set: checked above)
+    if (world > 1 && ((pmode != 1 && !ident_p && !ident_x_rows) || world > 8 || P.nAr < world)) return false;
     const bool pscan = pmode == 1 || ident_p;                    // the P keys are numbered (first-seen ranks)
     const int merge = (sp->row_key != KEY_X && sp->col_key != KEY_X) ? 1 : 0;
     const int S = uses_ep ? 2 : 1;
@@ -1579,31 +1600,39 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
 #undef SA_LAUNCH_EMIT
     IBH_HIP(hipGetLastError());
     if (world > 1) {                                             // exchange 3: the pieces of the result
-        // A/E-row matrix: CSR by entries of the ranges, rows by classes; I/X-row matrix: CSR by row entries, rows by P keys
-        const std::vector<uint64_t> &En = g_is_row ? E0 : L0, &Rw = g_is_row ? G0 : P0, &Cl = g_is_row ? P0 : G0;
-        std::vector<int64_t> o4e(world + 1), o8e(world + 1), o4r(world + 1), o8r(world + 1), o8c(world + 1);
+        // A/E-row matrix: CSR by entries of the ranges, rows by classes; I/X-row matrix: CSR by row entries, rows by P keys (an
+        // identity dimX: by exchange cells).  The column-side sums are one range per rank when the column set was numbered by this
+        // build; on an identity / pre-populated set they travel as {position, value} pairs and are scattered on every rank.
+        std::vector<uint64_t> Xc(world + 1);
+        for (int k = 0; k <= world; ++k) Xc[k] = (uint64_t)X[k];
+        const std::vector<uint64_t> &En = g_is_row ? E0 : L0, &Rw = g_is_row ? G0 : (ident_x_rows ? Xc : P0), &Cl = g_is_row ? P0 : G0;
+        std::vector<int64_t> o4e(world + 1), o8e(world + 1), o4r(world + 1), o8r(world + 1), o4c(world + 1), o8c(world + 1);
         for (int k = 0; k <= world; ++k) {
-            o4e[k] = (int64_t)En[k] * 4; o8e[k] = (int64_t)En[k] * 8; o4r[k] = (int64_t)Rw[k] * 4; o8r[k] = (int64_t)Rw[k] * 8; o8c[k] = (int64_t)Cl[k] * 8;
+            o4e[k] = (int64_t)En[k] * 4; o8e[k] = (int64_t)En[k] * 8; o4r[k] = (int64_t)Rw[k] * 4; o8r[k] = (int64_t)Rw[k] * 8;
+            o4c[k] = (int64_t)Cl[k] * 4; o8c[k] = (int64_t)Cl[k] * 8;
         }
-        if (ident_p) {
-            // identity P set: no P table; Mw as {position, value} pairs in first-seen order, scattered on every rank
-            const long npk = (long)P0[world];
-            int32_t *cidx = A.get<int32_t>((size_t)std::max<long>(npk, 1));
-            double *cval = A.get<double>((size_t)std::max<long>(npk, 1));
-            if (sb.sx1 > sb.sx0)
-                hipLaunchKernelGGL(k_sa_pack_mw, dim3((unsigned)ceil_div(sb.sx1 - sb.sx0, 256l)), dim3(256), 0, st, sb, pl.exI, pkey == KEY_X ? 1 : 0, w->Mw.p, cidx, cval);
-            std::vector<int64_t> o4p(world + 1), o8p(world + 1);
-            for (int k = 0; k <= world; ++k) { o4p[k] = (int64_t)P0[k] * 4; o8p[k] = (int64_t)P0[k] * 8; }
-            void *bases[7] = {w->colind.p, w->val.p, w->rowptr.p, w->wM.p, gtable.p, cidx, cval};
-            const int64_t *offs[7] = {o4e.data(), o8e.data(), o4r.data(), o8r.data(), o8r.data(), o4p.data(), o8p.data()};
-            comm_gatherv(comm, 7, bases, offs, st);
-            if (npk) hipLaunchKernelGGL(k_sa_unpack_mw, dim3((unsigned)ceil_div(npk, 256l)), dim3(256), 0, st, cidx, cval, (long)P0[rank], (long)P0[rank + 1], npk, w->Mw.p);
-        } else {
-        void *bases[7] = {w->colind.p, w->val.p, w->rowptr.p, w->wM.p, w->Mw.p, g_is_row ? (void *)gtable.p : (void *)ptable.p,
-                          g_is_row ? (void *)ptable.p : (void *)gtable.p};
-        const int64_t *offs[7] = {o4e.data(), o8e.data(), o4r.data(), o8r.data(), o8c.data(), o8r.data(), o8c.data()};
-        comm_gatherv(comm, 7, bases, offs, st);
+        const bool pairs = g_is_row ? ident_p : prepop_g;        // the column-side sums as pairs
+        const long npk = (long)Cl[world];
+        int32_t *cidx = nullptr;
+        double *cval = nullptr;
+        if (pairs) {
+            cidx = A.get<int32_t>((size_t)std::max<long>(npk, 1));
+            cval = A.get<double>((size_t)std::max<long>(npk, 1));
+            if (g_is_row) {
+                if (sb.sx1 > sb.sx0)
+                    hipLaunchKernelGGL(k_sa_pack_mw, dim3((unsigned)ceil_div(sb.sx1 - sb.sx0, 256l)), dim3(256), 0, st, sb, pl.exI, pkey == KEY_X ? 1 : 0, w->Mw.p, cidx, cval);
+            } else if (nr > 0)
+                hipLaunchKernelGGL(k_sa_pack_mw_g, dim3((unsigned)ceil_div((long)nr * g.NC, 256l)), dim3(256), 0, st, rg, pl, g, sb.sr0, sb.sr1, w->Mw.p, cidx, cval);
         }
+        std::vector<void *> bases = {w->colind.p, w->val.p, w->rowptr.p, w->wM.p};
+        std::vector<const int64_t *> offs = {o4e.data(), o8e.data(), o4r.data(), o8r.data()};
+        if (pairs) { bases.push_back(cidx); offs.push_back(o4c.data()); bases.push_back(cval); offs.push_back(o8c.data()); }
+        else { bases.push_back(w->Mw.p); offs.push_back(o8c.data()); }
+        DevBuf<int64_t> &rtable = g_is_row ? gtable : ptable, &ctable = g_is_row ? ptable : gtable;
+        if (rtable.p) { bases.push_back(rtable.p); offs.push_back(o8r.data()); }
+        if (ctable.p) { bases.push_back(ctable.p); offs.push_back(o8c.data()); }
+        comm_gatherv(comm, (int)bases.size(), bases.data(), offs.data(), st);
+        if (pairs && npk) hipLaunchKernelGGL(k_sa_unpack_mw, dim3((unsigned)ceil_div(npk, 256l)), dim3(256), 0, st, cidx, cval, (long)Cl[rank], (long)Cl[rank + 1], npk, w->Mw.p);
     }
     auto commit = [&](ibh_sparse_set *set, int64_t extent, DevBuf<int64_t> &table, int n) {
         set->sparse_extent = extent;
