@@ -218,7 +218,8 @@ __global__ __launch_bounds__(SA_T) void k_sa_flags(RgView rg, PlanView pl, SaBuf
             if (in) sb.rl[x] = (uint8_t)len;
             if (sb.rli) {                                        // identity ice set: rows by ice cell (zeroed beforehand: masked cells have empty rows)
                 if (P && len) sb.rli[iIv[u]] = (uint8_t)len;
-            } else {
+            }
+            if (sb.cntL) {                                       // (rows in first-seen order; a SHARED build on an identity ice set: the order its rows travel in)
                 const uint32_t tot = sa_wave_sum_u32(len);
                 if (lane == 0 && xw < sb.gx1) sb.cntL[xw >> 6] = tot;
             }
@@ -1263,6 +1264,41 @@ __global__ void k_sa_pack_mw(SaBuf sb, const int32_t *__restrict__ exI, int pkey
     const int32_t pos = pkey_x ? (int32_t)x : exI[x];
     cidx[k] = pos; cval[k] = Mw[pos];
 }
+// Shared build of an I-row matrix on the IDENTITY ice set (the coupler's IvE, IceCoupler.cpp:462): its rows lie in ice-cell order, so
+// a rank's rows are scattered over the matrix.  (a) Before the row pointer can be scanned every rank needs every ice cell's row
+// length: the owners' {ice cell, length} pairs travel at the cells' first-seen ranks.  (b) After the passes a rank's rows -- written
+// at their final places -- are copied into first-seen order, gathered, and copied out to their places on every other rank.
+__global__ void k_sa_pack_keys(SaBuf sb, const int32_t *__restrict__ exI, int32_t *__restrict__ kidx, uint8_t *__restrict__ klen) {
+    const long x = sb.sx0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= sb.sx1 || !(sb.code[x] & SA_P)) return;
+    const uint32_t k = sa_prank_at(sb.Pw, sb.pbits, x);
+    kidx[k] = exI[x]; klen[k] = sb.rl[x];
+}
+__global__ void k_sa_unpack_rli(const int32_t *__restrict__ kidx, const uint8_t *__restrict__ klen, long k0, long k1, long n, uint8_t *__restrict__ rli) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || (k >= k0 && k < k1) || !klen[k]) return;
+    rli[kidx[k]] = klen[k];
+}
+__global__ void k_sa_pack_rows(SaBuf sb, const int32_t *__restrict__ exI, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                               const double *__restrict__ val, const double *__restrict__ wM, int32_t *__restrict__ ccol, double *__restrict__ cvl,
+                               double *__restrict__ kwM, uint32_t *__restrict__ klo) {
+    const long x = sb.sx0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= sb.sx1 || !(sb.code[x] & SA_P)) return;
+    const uint32_t k = sa_prank_at(sb.Pw, sb.pbits, x), lo = sa_lrank_at(sb.Lw, sb.rl, x);
+    const int iI = exI[x], len = sb.rl[x], b = rowptr[iI];
+    kwM[k] = wM[iI]; klo[k] = lo;
+    for (int j = 0; j < len; ++j) { ccol[lo + j] = colind[b + j]; cvl[lo + j] = val[b + j]; }
+}
+__global__ void k_sa_unpack_rows(const int32_t *__restrict__ kidx, const uint8_t *__restrict__ klen, const uint32_t *__restrict__ klo,
+                                 const double *__restrict__ kwM, const int32_t *__restrict__ ccol, const double *__restrict__ cvl, long k0, long k1, long n,
+                                 const int32_t *__restrict__ rowptr, int32_t *__restrict__ colind, double *__restrict__ val, double *__restrict__ wM) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || (k >= k0 && k < k1)) return;
+    const int iI = kidx[k], len = klen[k], b = rowptr[iI];
+    const uint32_t lo = klo[k];
+    wM[iI] = kwM[k];
+    for (int j = 0; j < len; ++j) { colind[b + j] = ccol[lo + j]; val[b + j] = cvl[lo + j]; }
+}
 // The same for the column sums of an I/X-row matrix on a PRE-POPULATED G set (the coupler's dimE1 in XvE): a class of a range has
 // the compact index gbase[r] + erank[r][cls] (the numbering a fresh set would get) and sits at tab[key] of the caller's set.
 __global__ void k_sa_pack_mw_g(RgView rg, PlanView pl, FaG g, int sr0, int sr1, const double *__restrict__ Mw, int32_t *__restrict__ cidx,
@@ -1326,12 +1362,14 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     // An X-row matrix on the identity dimX (the coupler's XvE, :467) has its rows in exchange-cell order: a block of cells is a block
     // of rows.  A pre-populated G set (its dimE1, numbered by EvI) is looked up in the table every rank has; the column sums sit
     // at the caller's dense ids and travel as pairs too, at the ranks a fresh numbering would give the classes (k_sa_pack_mw_g).
-    // Not served: I rows on an identity dimI (by_ice: rows in ice-cell order, a rank's rows are scattered over the matrix).
+    // I rows on the identity dimI (its IvE, :462; by_ice): rows in ice-cell order -- the row lengths are merged before the row pointer
+    // is scanned, the rows travel in first-seen order and are copied to their places (k_sa_pack_keys / k_sa_pack_rows).
     const bool ident_p = world > 1 && pmode == 0 && g_is_row;
     const bool ident_x_rows = world > 1 && pmode == 0 && !g_is_row && pkey == KEY_X;
+    const bool ident_i_rows = world > 1 && by_ice;
     const bool prepop_g = world > 1 && !g_fresh;                 // (an E column set: checked above)
-    if (world > 1 && ((pmode != 1 && !ident_p && !ident_x_rows) || world > 8 || P.nAr < world)) return false;
-    const bool pscan = pmode == 1 || ident_p;                    // the P keys are numbered (first-seen ranks)
+    if (world > 1 && ((pmode != 1 && !ident_p && !ident_x_rows && !ident_i_rows) || world > 8 || P.nAr < world)) return false;
+    const bool pscan = pmode == 1 || ident_p || ident_i_rows;    // the P keys are numbered (first-seen ranks)
     const int merge = (sp->row_key != KEY_X && sp->col_key != KEY_X) ? 1 : 0;
     const int S = uses_ep ? 2 : 1;
     if (gr->nhc > 64) return false;
@@ -1383,7 +1421,8 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         if (by_ice) {
             sb.rli = A.get<uint8_t>((size_t)gr->nI);
             IBH_HIP(hipMemsetAsync(sb.rli, 0, (size_t)gr->nI, st));
-        } else { sb.cntL = A.get<uint32_t>((size_t)nW + 1); sb.Lw = A.get<uint32_t>((size_t)nW + 1); }
+        }
+        if (!by_ice || world > 1) { sb.cntL = A.get<uint32_t>((size_t)nW + 1); sb.Lw = A.get<uint32_t>((size_t)nW + 1); }
     }
     if (uses_ep) sb.rel = A.get_bytes((size_t)nX * S * (rel32 ? 4 : 2));
     else {
@@ -1402,7 +1441,7 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     if (world > 1) {     // (one more wave than the slice has: a zero count behind the last one, so that the scans also yield totals)
         IBH_HIP(hipMemsetAsync(sb.cntP + gW1, 0, 1, st));
         IBH_HIP(hipMemsetAsync(sb.pbits + gW1, 0, 8, st));
-        if (!g_is_row && !by_ice) IBH_HIP(hipMemsetAsync(sb.cntL + gW1, 0, sizeof(uint32_t), st));
+        if (!g_is_row) IBH_HIP(hipMemsetAsync(sb.cntL + gW1, 0, sizeof(uint32_t), st));
     }
     if (!uses_ep) {      // (the scans of the entry counts are read AT the end of the last range too)
         IBH_HIP(hipMemsetAsync(sb.cntE + gW1, 0, 1, st));
@@ -1433,7 +1472,7 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
     {
         const long nws = world == 1 ? nW : nwl + 1;
         const MsCh chP{pscan ? (const void *)(sb.cntP + gW0) : nullptr, sb.Pw + gW0, world == 1 ? d_cnt + 2 : nullptr, pscan ? nws : 0, 1, 0};
-        const bool lch = !g_is_row && !by_ice;
+        const bool lch = !g_is_row && (!by_ice || world > 1);
         const MsCh chL{lch ? (const void *)(sb.cntL + gW0) : nullptr, lch ? sb.Lw + gW0 : nullptr, world == 1 ? d_cnt + 5 : nullptr, lch ? nws : 0, 0, 0};
         const MsCh chG{g.r_ncls + sb.sr0, g.gbase + sb.sr0, d_cnt + 3, nr, 0, 1};
         const MsCh chN{g.r_nent + sb.sr0, g.ebase + sb.sr0, d_cnt + 4, nr, 0, 1};
@@ -1543,6 +1582,20 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         else hipLaunchKernelGGL((k_sa_emit<EP, GR, uint16_t, 4>), egrid(4), dim3(SA_T), 0, st, rg, pl, *sp, g, p, sb, merge, o, sval, sdid);       \
     } while (0)
     sb.end_row = nrow; sb.end_nnz = nnz;
+    int32_t *kidx = nullptr;                                     // shared build, identity ice rows: the ice cell / row length of every P key, in first-seen order
+    uint8_t *klen = nullptr;
+    const long nkeys = ident_i_rows ? (long)P0[world] : 0;
+    if (ident_i_rows) {                                          // exchange 2b: every rank learns every ice cell's row length
+        kidx = A.get<int32_t>((size_t)std::max<long>(nkeys, 1));
+        klen = A.get<uint8_t>((size_t)std::max<long>(nkeys, 1));
+        if (sb.sx1 > sb.sx0) hipLaunchKernelGGL(k_sa_pack_keys, dim3((unsigned)ceil_div(sb.sx1 - sb.sx0, 256l)), dim3(256), 0, st, sb, pl.exI, kidx, klen);
+        std::vector<int64_t> o4p(world + 1), o1p(world + 1);
+        for (int k = 0; k <= world; ++k) { o4p[k] = (int64_t)P0[k] * 4; o1p[k] = (int64_t)P0[k]; }
+        void *bases[2] = {kidx, klen};
+        const int64_t *offs[2] = {o4p.data(), o1p.data()};
+        comm_gatherv(comm, 2, bases, offs, st);
+        if (nkeys) hipLaunchKernelGGL(k_sa_unpack_rli, dim3((unsigned)ceil_div(nkeys, 256l)), dim3(256), 0, st, kidx, klen, (long)P0[rank], (long)P0[rank + 1], nkeys, sb.rli);
+    }
     if (by_ice) {                                                // the row pointer over the ice cells (closes itself: rowptr[nI] = nnz); wM of non-members
         const MsCh chI{sb.rli, reinterpret_cast<uint32_t *>(w->rowptr.p), nullptr, (long)gr->nI, 1, 1};
         sa_scan_channels(&chI, 1, st);
@@ -1626,12 +1679,32 @@ static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
         }
         std::vector<void *> bases = {w->colind.p, w->val.p, w->rowptr.p, w->wM.p};
         std::vector<const int64_t *> offs = {o4e.data(), o8e.data(), o4r.data(), o8r.data()};
+        int32_t *ccol = nullptr;
+        double *cvl = nullptr, *kwM = nullptr;
+        uint32_t *klo = nullptr;
+        std::vector<int64_t> o4p(world + 1), o8p(world + 1);
+        if (ident_i_rows) {
+            // the rows in first-seen order (every rank scanned the same row pointer: it does not travel), wM and the place of every
+            // key's row in that order at the key's rank
+            const long nl = (long)L0[world];
+            ccol = A.get<int32_t>((size_t)std::max<long>(nl, 1)); cvl = A.get<double>((size_t)std::max<long>(nl, 1));
+            kwM = A.get<double>((size_t)std::max<long>(nkeys, 1)); klo = A.get<uint32_t>((size_t)std::max<long>(nkeys, 1));
+            if (sb.sx1 > sb.sx0)
+                hipLaunchKernelGGL(k_sa_pack_rows, dim3((unsigned)ceil_div(sb.sx1 - sb.sx0, 256l)), dim3(256), 0, st, sb, pl.exI, w->rowptr.p, w->colind.p, w->val.p,
+                                   w->wM.p, ccol, cvl, kwM, klo);
+            for (int k = 0; k <= world; ++k) { o4p[k] = (int64_t)P0[k] * 4; o8p[k] = (int64_t)P0[k] * 8; }
+            bases = {ccol, cvl, kwM, klo};
+            offs = {o4e.data(), o8e.data(), o8p.data(), o4p.data()};
+        }
         if (pairs) { bases.push_back(cidx); offs.push_back(o4c.data()); bases.push_back(cval); offs.push_back(o8c.data()); }
         else { bases.push_back(w->Mw.p); offs.push_back(o8c.data()); }
         DevBuf<int64_t> &rtable = g_is_row ? gtable : ptable, &ctable = g_is_row ? ptable : gtable;
         if (rtable.p) { bases.push_back(rtable.p); offs.push_back(o8r.data()); }
         if (ctable.p) { bases.push_back(ctable.p); offs.push_back(o8c.data()); }
         comm_gatherv(comm, (int)bases.size(), bases.data(), offs.data(), st);
+        if (ident_i_rows && nkeys)
+            hipLaunchKernelGGL(k_sa_unpack_rows, dim3((unsigned)ceil_div(nkeys, 256l)), dim3(256), 0, st, kidx, klen, klo, kwM, ccol, cvl, (long)P0[rank],
+                               (long)P0[rank + 1], nkeys, w->rowptr.p, w->colind.p, w->val.p, w->wM.p);
         if (pairs && npk) hipLaunchKernelGGL(k_sa_unpack_mw, dim3((unsigned)ceil_div(npk, 256l)), dim3(256), 0, st, cidx, cval, (long)Cl[rank], (long)Cl[rank + 1], npk, w->Mw.p);
     }
     auto commit = [&](ibh_sparse_set *set, int64_t extent, DevBuf<int64_t> &table, int n) {

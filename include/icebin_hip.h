@@ -378,8 +378,12 @@ int ibh_comm_wait(ibh_comm *c, void *stream);
  * (AbbrGrid.cpp:10-21), so rank k runs the streamed passes over a contiguous block of ranges holding ~1/world of the exchange
  * cells; three exchanges on the caller's thread stream (counters; the first-seen flags and class ranks the ranks look up in each
  * other's blocks, ~1 byte per exchange cell; the pieces of the CSR / weights / dims tables) complete it.  Served this way: the
- * eight A/E/I/X matrices on sets numbered by the build (dims NULL or empty), sorted grids, at most 8 ranks; anything else is
- * built redundantly on every rank (same result).  ibh_weighted_built_fast reports 3 for a shared build.  A custom transport needs
+ * eight A/E/I/X matrices on sets numbered by the build (dims NULL or empty) AND on the sets the reference's coupler passes
+ * (IceCoupler.cpp:366-377, 462-467) -- an identity dimI / dimX on the ice / exchange side (A/E-row matrices: Mw travels as
+ * {position, value} pairs; X rows: a block of cells is a block of rows; I rows: the row lengths are merged before the row pointer
+ * is scanned, the rows travel in first-seen order and are copied to their places), a pre-populated dimE as the column set (looked
+ * up in the table every rank has; the column sums travel as pairs) --, sorted grids, at most 8 ranks; anything else (EvA / AvE, a
+ * pre-populated row set, unsorted grids) is built redundantly on every rank (same result).  ibh_weighted_built_fast reports 3 for a shared build.  A custom transport needs
  * ibh_comm_set_custom_gatherv. */
 int ibh_regrid_matrices_matrix_d_sharded(const ibh_regrid_matrices *rm, ibh_comm *c, const char *spec, ibh_sparse_set *dim0,
                                          ibh_sparse_set *dim1, int scale, int correctA, ibh_weighted **out);

@@ -482,11 +482,19 @@ def _worker_asm_sharded(rank, world, port, q, configs=("g5", "g20"), stage_mb=64
                 ok = False
                 notes.append("%s IvE over a pre-populated dimE not shared" % config)
             same(ws, w1, "%s IvE pre-populated dimE" % config)
-            # the coupler's step (IceCoupler.cpp:361-377, 462-467): EvI {dimE1, identity dimI}, AvI {dimA1, identity dimI} -- shared:
-            # the CSR pieces of an A/E-row matrix are contiguous whatever the column numbering, Mw travels as pairs; XvE {identity
-            # dimX, dimE1 as EvI left it} -- shared: a block of cells is a block of rows, the column sums travel as pairs; IvE
-            # {identity dimI, dimE1}: rows in ice-cell order, a rank's rows are scattered over the matrix -- built redundantly by every
-            # rank (the collective call returns the same, complete matrix everywhere; built_sharded() says which way it was made)
+            # I rows on the identity dimI (rows in ice-cell order: the row lengths are merged before the row pointer is scanned, the
+            # rows travel in first-seen order), with a column set of their own
+            for name in ("IvA", "IvE"):
+                ident = [icebin_amd.SparseSet.identity(g["nI"]) for _ in range(2)]
+                ws, w1 = rm.matrix_d_sharded(comm, name, (ident[0], None)), rm.matrix_d(name, (ident[1], None))
+                if not ws.built_sharded():
+                    ok = False
+                    notes.append("%s %s on the identity dimI not shared" % (config, name))
+                same(ws, w1, "%s %s identity dimI" % (config, name))
+            # the coupler's step (IceCoupler.cpp:361-377, 462-467), all four calls shared: EvI {dimE1, identity dimI}, AvI {dimA1,
+            # identity dimI} -- the CSR pieces of an A/E-row matrix are contiguous whatever the column numbering, Mw travels as pairs;
+            # XvE {identity dimX, dimE1 as EvI left it} -- a block of cells is a block of rows, the column sums travel as pairs;
+            # IvE {identity dimI, dimE1} -- rows in ice-cell order, copied to their places on every rank
             nE = g["nA"] * len(g["hcdefs"])
             sets = []
             for sharded in (True, False):
@@ -495,7 +503,7 @@ def _worker_asm_sharded(rank, world, port, q, configs=("g5", "g20"), stage_mb=64
                 sets.append([build("EvI", (dimE, dimI), scale=False, correctA=False), build("AvI", (dimA, dimI), scale=False, correctA=True),
                              build("IvE", (dimI, dimE), scale=True, correctA=True), build("XvE", (dimX, dimE), scale=False, correctA=True)])
             for a, b, name in zip(sets[0], sets[1], ("EvI", "AvI", "IvE", "XvE")):
-                if a.built_sharded() != (name in ("EvI", "AvI", "XvE")):
+                if not a.built_sharded():
                     ok = False
                     notes.append("%s coupler %s: built_sharded() %s" % (config, name, a.built_sharded()))
                 same(a, b, "%s coupler %s" % (config, name))

@@ -843,11 +843,20 @@ def test_config5_antarctica_colsweep_agrees_with_rowblock_at_64_fields():
         torch.cuda.synchronize()
         assert rel_linf(y.cpu().numpy(), ref) <= FIELD_RTOL, kernel
     w.set_kernel("auto")
-    ys = w.apply_many_device([x16] * 4, fill=-1.0, force_conservation=False)          # (batch, field) lanes of the sweep
+    ys = w.apply_many_device([x16] * 4, fill=-1.0, force_conservation=False)          # batched launch of few fields: the tiled row groups (round 5)
     torch.cuda.synchronize()
-    assert w.last_kernel() == "colsweep"
+    assert w.last_kernel() == "rowgroup" and "grouptile" in w.last_launch()
     for q in (0, 3):
         assert rel_linf(ys[q].cpu().numpy(), ref) <= FIELD_RTOL
+    icebin_amd.set_tuning("rowgroup_form", 0)                                         # ... and the (batch, field) lanes of the sweep
+    try:
+        ys = w.apply_many_device([x16] * 4, fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert w.last_kernel() == "colsweep"
+        for q in (0, 3):
+            assert rel_linf(ys[q].cpu().numpy(), ref) <= FIELD_RTOL
+    finally:
+        icebin_amd.set_tuning("rowgroup_form", -2 ** 31)
     assert rel_linf(y_col[:16], ref) <= FIELD_RTOL
 
 
