@@ -1767,7 +1767,7 @@ def rowgroup_form(request):
     icebin_amd.set_tuning("grouptile_seg", -2 ** 31)
 
 
-@pytest.mark.parametrize("variant", ["sorted", "shuffled", "elev_class", "x_fastest", "g20"])
+@pytest.mark.parametrize("variant", ["sorted", "shuffled", "elev_class", "x_fastest", "g20", "fine_classes"])
 def test_rowgroup_on_grid_variants(variant, rowgroup_form):
     """The row-group apply of the E-row matrices (spmm.hip rowgroup / grouptile: the elevation classes of one GCM cell form a
     group whose columns are gathered once) against the oracle: 1..130 fields, NaN-carrying fields, fill, both interpolation
@@ -1775,16 +1775,21 @@ def test_rowgroup_on_grid_variants(variant, rowgroup_form):
     launches bitwise equal to separate applies, inside a hipGraph, and a shared dimE in a scrambled order (the rows of a group
     are not consecutive)."""
     import torch
-    kw = dict(sorted={}, shuffled=dict(order="shuffled"), elev_class={}, x_fastest=dict(x_fastest=True), g20={})[variant]
+    kw = dict(sorted={}, shuffled=dict(order="shuffled"), elev_class={}, x_fastest=dict(x_fastest=True), g20={}, fine_classes=dict(nhc=64))[variant]
     g = syn.make_grids("g20" if variant == "g20" else "g5", **kw)
     if variant == "elev_class":
         g["interp_style"] = 1
+    if variant == "fine_classes":           # 64 classes 60 m apart: GCM cells with 17..32 classes (the kernels' second instantiation)
+        g["hcdefs"] = np.arange(64, dtype=np.float64) * 60.0 - 30.0
     em = syn.dome_elevmask(g)
     mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
     rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
     for name in ("EvI", "EvX"):
         w, o = rm.matrix(name), rg.matrix_d(name, em, scale=True, correctA=True)
         w.set_kernel("rowgroup")
+        if variant == "fine_classes" and rowgroup_form != "atomics":
+            w.apply(syn.fields(4, w.ncol_d), fill=-1.0, force_conservation=False)
+            assert "grouptile_kernel<16, 32," in w.last_launch(), w.last_launch()      # groups of 17..32 rows
         for nvar in (64, 40, 130, 7, 1):
             x = syn.fields(nvar, w.ncol_d, seed=7 + nvar)
             x[nvar // 2, ::7] = np.nan              # NaN in a field must stay in the rows that use those cells
