@@ -177,6 +177,90 @@ __global__ __launch_bounds__(SC_T) void scan_tile_apply(const IN *in, uint32_t *
     }
 }
 
+// ---- the same in ONE launch: chained scan (decoupled look-back) ---------------------------------------------------------------
+// Every tile's workgroup publishes its sum, wave 0 looks back over its predecessors 64 at a time -- a predecessor's word says
+// {sum of that tile alone} or {sum of everything up to and including it}; the first of the second kind ends the walk -- and
+// publishes the tile's own inclusive prefix.  Workgroups are dispatched in index order, so a tile only ever waits for tiles that are
+// already running or done.  A status word is one 64-bit value {sum, epoch << 2 | kind}, stored and loaded whole at device scope
+// (coherent across the XCDs' L2s); the epoch of the call makes every older word invalid, so the buffer is never cleared.  A 5 km
+// build makes three to eight scans of <= 182 k elements: two launches fewer each (~5 us apiece at that size, round 5).
+namespace {
+struct ScanState {
+    unsigned long long *status = nullptr;
+    size_t cap = 0;
+    unsigned epoch = 0;
+    int device = -1;
+};
+ScanState &scan_state() { static thread_local ScanState s; return s; }
+}  // namespace
+template <class IN>
+__global__ __launch_bounds__(SC_T) void scan_chained(const IN *__restrict__ in, uint32_t *__restrict__ out, size_t n, unsigned long long *status,
+                                                     unsigned epoch, uint32_t *__restrict__ total) {
+    __shared__ uint32_t tile[SC_TILE + SC_T];   // +1 pad per 8: thread t owns tile[9t .. 9t+7]
+    __shared__ uint32_t s_wave[SC_T / 64];
+    __shared__ uint32_t s_prefix;
+    const size_t t = blockIdx.x, base = t * SC_TILE;
+#pragma unroll
+    for (int i = 0; i < SC_I; ++i) {
+        const int e = i * SC_T + threadIdx.x;
+        const size_t idx = base + e;
+        tile[e + (e >> 3)] = idx < n ? (uint32_t)in[idx] : 0u;
+    }
+    __syncthreads();
+    uint32_t v[SC_I], sum = 0;
+#pragma unroll
+    for (int i = 0; i < SC_I; ++i) { v[i] = tile[threadIdx.x * 9 + i]; sum += v[i]; }
+    uint32_t tot;
+    uint32_t run = block_excl_scan<SC_T>(sum, s_wave, tot);
+    constexpr unsigned long long AGG = 1, PRE = 2;
+    const unsigned long long tag = (unsigned long long)epoch << 2;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        uint32_t prefix = 0;
+        if (t == 0) {
+            if (lane == 0) __hip_atomic_store(status, ((unsigned long long)tot << 32) | tag | PRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(status + t, ((unsigned long long)tot << 32) | tag | AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long j = (long)t - 1;
+            while (true) {
+                const long idx = j - lane;
+                unsigned long long w = ((unsigned long long)0 << 32) | tag | PRE;      // before the first tile: an empty prefix
+                if (idx >= 0) {
+                    do { w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    while ((w & 0xfffffffcull) != (tag & 0xfffffffcull) || (w & 3ull) == 0);
+                }
+                const unsigned long long pre = __ballot((w & 3ull) == PRE);
+                uint32_t val = (uint32_t)(w >> 32);
+                if (pre) {
+                    const int first = __builtin_ctzll(pre);      // the nearest predecessor that knows everything before it
+                    if (lane > first) val = 0;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) val += __shfl_xor(val, off, 64);
+                prefix += val;
+                if (pre) break;
+                j -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(status + t, ((unsigned long long)(prefix + tot) << 32) | tag | PRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_prefix = prefix;
+            if (total && t == gridDim.x - 1) *total = prefix + tot;
+        }
+    }
+    __syncthreads();
+    run += s_prefix;
+#pragma unroll
+    for (int i = 0; i < SC_I; ++i) { tile[threadIdx.x * 9 + i] = run; run += v[i]; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SC_I; ++i) {
+        const int e = i * SC_T + threadIdx.x;
+        const size_t idx = base + e;
+        if (idx < n) out[idx] = tile[e + (e >> 3)];
+    }
+}
+
 template <class IN>
 static void exclusive_scan_any(const IN *in, uint32_t *out, size_t n, uint32_t *total, hipStream_t stream) {
     if (n == 0) {
@@ -185,6 +269,28 @@ static void exclusive_scan_any(const IN *in, uint32_t *out, size_t n, uint32_t *
     }
     const size_t nb = (n + SC_TILE - 1) / SC_TILE;
     IBH_CHECK(nb < (1ul << 31), "scan too large");
+    if (get_tuning("scan_chained", 1)) {
+        ScanState &ss = scan_state();
+        int dev = 0;
+        IBH_HIP(hipGetDevice(&dev));
+        if (ss.device != dev || ss.cap < nb) {                  // (the words of an older, smaller buffer die with it: a fresh one starts at zero)
+            if (ss.status) (void)hipFree(ss.status);
+            ss.cap = std::max<size_t>(nb, 4096) * 2;
+            IBH_HIP(hipMalloc(&ss.status, ss.cap * sizeof(unsigned long long)));
+            IBH_HIP(hipMemsetAsync(ss.status, 0, ss.cap * sizeof(unsigned long long), stream));
+            IBH_HIP(hipStreamSynchronize(stream));              // (other streams of this thread may scan next)
+            ss.device = dev; ss.epoch = 0;
+        }
+        if (++ss.epoch >= (1u << 30)) {                         // (the epoch field is 30 bits: start over on a cleared buffer)
+            IBH_HIP(hipDeviceSynchronize());
+            IBH_HIP(hipMemsetAsync(ss.status, 0, ss.cap * sizeof(unsigned long long), stream));
+            IBH_HIP(hipStreamSynchronize(stream));
+            ss.epoch = 1;
+        }
+        hipLaunchKernelGGL(scan_chained<IN>, dim3((unsigned)nb), dim3(SC_T), 0, stream, in, out, n, ss.status, ss.epoch, total);
+        IBH_HIP(hipGetLastError());
+        return;
+    }
     uint32_t *sums = arena().get<uint32_t>(nb);
     hipLaunchKernelGGL(scan_tile_sums<IN>, dim3((unsigned)nb), dim3(SC_T), 0, stream, in, n, sums);
     hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(1024), 0, stream, sums, (int)nb, total);
