@@ -860,6 +860,43 @@ def test_config5_antarctica_colsweep_agrees_with_rowblock_at_64_fields():
     assert rel_linf(y_col[:16], ref) <= FIELD_RTOL
 
 
+def test_config5_antarctica_128_fields_in_one_launch_against_the_oracle():
+    """Config 5 at the shape bench.py times it (128 fields in ONE launch, the Antarctic sheet), every family of the hot path:
+    the first and the last 16 fields against the ORACLE's apply fed the GPU-built matrix (whose bits are the oracle's: the hash
+    test above), the 96 between them against 16-field applies -- the per-GPU share, oracle-checked here and in the test
+    above.  NaN inputs, fill and the constant field ride along."""
+    import torch
+    g = _big_grids("a1h")
+    em = syn.dome_elevmask(g)
+    rm = icebin_amd.from_synthetic(g).regrid_matrices("greenland", em, scale=True, correctA=False)
+    for name, expect in (("AvI", "colsweep"), ("IvA", "shortrow"), ("EvI", "grouptile"), ("IvE", "shortrow")):
+        w = rm.matrix(name)
+        w.prepare(128)                                      # (as bench.py does: the apply structures built before the first apply)
+        gen = torch.Generator(device="cuda").manual_seed(17)
+        x = torch.randn((128, w.ncol_d), dtype=torch.float64, device="cuda", generator=gen)
+        x[2, ::999983] = float("nan")
+        x[127, 5::1000003] = float("nan")
+        x[120].fill_(1.0)
+        y = w.apply_device(x, fill=-1.0, force_conservation=False)
+        torch.cuda.synchronize()
+        assert expect in w.last_kernel() + " " + w.last_launch(), (name, w.last_kernel(), w.last_launch())
+        row, col, val = w.coo_dense()
+        o = orc.Weighted.from_coo(w.nrow_d, w.ncol_d, row, col, val, w.wM, w.Mw)
+        del row, col, val
+        for b in (0, 7):
+            ref = o.apply(x[16 * b:16 * b + 16].cpu().numpy(), fill=-1.0, force_conservation=False)
+            assert rel_linf(y[16 * b:16 * b + 16].cpu().numpy(), ref) <= FIELD_RTOL, (name, b)
+            del ref
+        del o
+        for b in range(1, 7):
+            y16 = w.apply_device(x[16 * b:16 * b + 16].contiguous(), fill=-1.0, force_conservation=False)
+            torch.cuda.synchronize()
+            assert rel_linf(y[16 * b:16 * b + 16].cpu().numpy(), y16.cpu().numpy()) <= FIELD_RTOL, (name, b)
+        live = torch.from_numpy(w.wM != 0).cuda()
+        assert bool(torch.all(torch.abs(y[120][:w.nrow_d][live] - 1.0) < 1e-11)), name          # scaled rows sum to 1
+        del x, y, w
+
+
 def test_config5_greenland_1km_half_degree_sheet():
     # the other sheet of config 5: Greenland 1 km <-> 1/2 deg
     W = _sheet_properties("g1h", ("AvI", "IvA"), 4204301)
