@@ -14,6 +14,8 @@ for k, v in [kv.split("=") for kv in os.environ.get("TUNE", "").split(",") if kv
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 bad = n = 0
+import collections
+seen = collections.Counter()
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     g, em = T._random_grid(seed, force_sorted=bool(seed % 2))
@@ -35,6 +37,7 @@ for seed in range(first, first + count):
                 w.set_kernel(k)
                 y = w.apply(x, fill=-7.0, force_conservation=False)
                 n += 1
+                seen[w.last_kernel() + " " + w.last_launch().split("<")[0]] += 1
                 if T.rel_linf(y, ref) > T.FIELD_RTOL:
                     bad += 1; print("MISMATCH", seed, name, k, nvar, T.rel_linf(y, ref), flush=True)
                 dx = torch.from_numpy(x).cuda()
@@ -65,5 +68,6 @@ for seed in range(first, first + count):
         except icebin_amd.IcebinHipError as ex:
             print("pair refused", seed, str(ex)[:90], flush=True)
     print("seed %d done (%d applies so far)" % (seed, n), flush=True)
+print("kernels:", dict(seen))
 print("applies checked:", n, "of them fused pairs:", globals().get("npair", 0), "mismatches:", bad)
 sys.exit(1 if bad else 0)
