@@ -440,9 +440,25 @@ def _worker_asm_sharded(rank, world, port, q, configs=("g5", "g20"), stage_mb=64
                 notes.append(what)
             ok = ok and good
 
+        strict = [True]
+
+        def unshared(what):
+            """the shared build declined (every rank then builds redundantly, which is allowed -- and expected of none of the fixed
+            grids; on the random grids of scratch/fuzz_sharded.py it is only noted)"""
+            nonlocal ok
+            notes.append(what)
+            ok = ok and not strict[0]
+
         for config in configs:
-            g = syn.make_grids(config)
-            em = syn.dome_elevmask(g)
+            random_case = isinstance(config, str) and config.startswith("rand:")
+            strict[0] = not random_case
+            if random_case:                             # scratch/fuzz_sharded.py: the random sorted grids of the assembly tests
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import test_gpu_parity
+                g, em = test_gpu_parity._random_grid(int(config[5:]), force_sorted=True)
+            else:
+                g = syn.make_grids(config)
+                em = syn.dome_elevmask(g)
             mm = icebin_amd.from_synthetic(g)
             for scale, correctA in ((True, True), (False, False)):
                 rm = mm.regrid_matrices("greenland", em, scale=scale, correctA=correctA)
@@ -450,9 +466,8 @@ def _worker_asm_sharded(rank, world, port, q, configs=("g5", "g20"), stage_mb=64
                     n0 = calls["gatherv"]
                     ws = rm.matrix_d_sharded(comm, name, scale=scale, correctA=correctA)
                     w1 = rm.matrix_d(name, scale=scale, correctA=correctA)
-                    if not ws.built_sharded() or calls["gatherv"] - n0 != 4 + 7:     # (exchange 2: four arrays, exchange 3: seven)
-                        ok = False
-                        notes.append("%s %s not shared (%d gathers)" % (config, name, calls["gatherv"] - n0))
+                    if not ws.built_sharded() or (calls["gatherv"] - n0 != 4 + 7 and not random_case):     # (exchange 2: four arrays, exchange 3: seven)
+                        unshared("%s %s not shared (%d gathers)" % (config, name, calls["gatherv"] - n0))
                     same(ws, w1, "%s %s scale=%d correctA=%d" % (config, name, scale, correctA))
             rm = mm.regrid_matrices("greenland", em, scale=True, correctA=True)
             # not served by the shared build: built redundantly by every rank, same result (EvA: another pipeline; an identity set)
@@ -464,23 +479,20 @@ def _worker_asm_sharded(rank, world, port, q, configs=("g5", "g20"), stage_mb=64
                 ident = [icebin_amd.SparseSet.identity(n_id) for _ in range(2)]
                 ws, w1 = rm.matrix_d_sharded(comm, name, (None, ident[0])), rm.matrix_d(name, (None, ident[1]))
                 if not ws.built_sharded():
-                    ok = False
-                    notes.append("%s %s on an identity set not shared" % (config, name))
+                    unshared("%s %s on an identity set not shared" % (config, name))
                 same(ws, w1, "%s %s identity P set" % (config, name))
             # X rows on the identity dimX with a column set of their own; I rows numbered by the build over a pre-populated dimE
             for name in ("XvA", "XvE"):
                 ident = [icebin_amd.SparseSet.identity(len(g["ex_area"])) for _ in range(2)]
                 ws, w1 = rm.matrix_d_sharded(comm, name, (ident[0], None)), rm.matrix_d(name, (ident[1], None))
                 if not ws.built_sharded():
-                    ok = False
-                    notes.append("%s %s on the identity dimX not shared" % (config, name))
+                    unshared("%s %s on the identity dimX not shared" % (config, name))
                 same(ws, w1, "%s %s identity dimX" % (config, name))
             keysE = rm.matrix_d("EvI").dim(0)
             dE = [icebin_amd.SparseSet(g["nA"] * len(g["hcdefs"]), keysE[::-1].copy()) for _ in range(2)]      # (any order: here reversed)
             ws, w1 = rm.matrix_d_sharded(comm, "IvE", (None, dE[0])), rm.matrix_d("IvE", (None, dE[1]))
             if not ws.built_sharded():
-                ok = False
-                notes.append("%s IvE over a pre-populated dimE not shared" % config)
+                unshared("%s IvE over a pre-populated dimE not shared" % config)
             same(ws, w1, "%s IvE pre-populated dimE" % config)
             # I rows on the identity dimI (rows in ice-cell order: the row lengths are merged before the row pointer is scanned, the
             # rows travel in first-seen order), with a column set of their own
@@ -488,8 +500,7 @@ def _worker_asm_sharded(rank, world, port, q, configs=("g5", "g20"), stage_mb=64
                 ident = [icebin_amd.SparseSet.identity(g["nI"]) for _ in range(2)]
                 ws, w1 = rm.matrix_d_sharded(comm, name, (ident[0], None)), rm.matrix_d(name, (ident[1], None))
                 if not ws.built_sharded():
-                    ok = False
-                    notes.append("%s %s on the identity dimI not shared" % (config, name))
+                    unshared("%s %s on the identity dimI not shared" % (config, name))
                 same(ws, w1, "%s %s identity dimI" % (config, name))
             # the coupler's step (IceCoupler.cpp:361-377, 462-467), all four calls shared: EvI {dimE1, identity dimI}, AvI {dimA1,
             # identity dimI} -- the CSR pieces of an A/E-row matrix are contiguous whatever the column numbering, Mw travels as pairs;
@@ -504,8 +515,7 @@ def _worker_asm_sharded(rank, world, port, q, configs=("g5", "g20"), stage_mb=64
                              build("IvE", (dimI, dimE), scale=True, correctA=True), build("XvE", (dimX, dimE), scale=False, correctA=True)])
             for a, b, name in zip(sets[0], sets[1], ("EvI", "AvI", "IvE", "XvE")):
                 if not a.built_sharded():
-                    ok = False
-                    notes.append("%s coupler %s: built_sharded() %s" % (config, name, a.built_sharded()))
+                    unshared("%s coupler %s: built_sharded() %s" % (config, name, a.built_sharded()))
                 same(a, b, "%s coupler %s" % (config, name))
         # an elevation above the last class: every rank raises the reference's error, whichever rank's block holds the cell
         g = syn.make_grids("g20")
