@@ -338,24 +338,81 @@ __device__ __forceinline__ uint32_t fa_pflag_of(const RgView &rg, const PlanView
 }
 
 // ---- G-side numbering and entry counts: one workgroup per range -----------------------------------
+// Small grids (round 5): the three scans that used to follow this kernel -- the first-occurrence flags of the P keys over the
+// cells, the classes and the entries over the ranges: two launches -- are CHAINED through it.  A range's workgroup publishes its
+// three totals in one 64-bit status word {flag 2 | epoch 4 | new P keys 21 | entries 22 | classes 15 bits} and looks back over its
+// predecessors' words (decoupled look-back, as prims.hip scan_chained: workgroups are dispatched in index order and publish
+// their own totals before they wait, so the wait always ends); the ranks of the new keys inside the range come from ballots.
+// status == nullptr: off (large grids scan with kernels of their own; EvA / AvE count other things).
+struct FaChain {
+    unsigned long long *status;     // [nAr]
+    unsigned epoch;                 // 1..15: words of another epoch are "not yet written"
+    uint32_t *tot;                  // [3]: new P keys, classes, entries of the whole grid (the counters read back by the host)
+};
+constexpr int FA_CH_NP = 21, FA_CH_NE = 22, FA_CH_NC = 15;
+// Exclusive prefix of `mine` (<= 58 bits, fields that cannot overflow) over the workgroups before r; every thread of the workgroup
+// calls it and gets the same value.  One round looks at T predecessors at once -- at 5 km every range sees all the others in one.
+template <int T>
+__device__ __forceinline__ unsigned long long fa_chain_prefix(unsigned long long *status, int r, unsigned epoch, unsigned long long mine,
+                                                              unsigned long long *s_part, int *s_flag) {
+    constexpr unsigned long long AGG = 1, PRE = 2;
+    const unsigned long long tag = (unsigned long long)(epoch & 15u) << 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) __hip_atomic_store(status + r, (mine << 6) | tag | (r == 0 ? PRE : AGG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (r == 0) return 0ull;
+    unsigned long long prefix = 0;
+    long j = (long)r - 1;
+    while (true) {
+        const long idx = j - (long)threadIdx.x;
+        unsigned long long w = tag | PRE;                       // before the first workgroup: an empty prefix
+        if (idx >= 0) {
+            do { w = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            while ((w & 0x3cull) != tag || (w & 3ull) == 0);
+        }
+        const unsigned long long pre = __ballot((w & 3ull) == PRE);
+        unsigned long long val = w >> 6;
+        if (pre && lane > __builtin_ctzll(pre)) val = 0;        // beyond the nearest predecessor that knows everything before it
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) val += __shfl_xor(val, off, 64);
+        if (lane == 0) { s_part[wave] = val; s_flag[wave] = pre != 0; }
+        __syncthreads();
+        bool done = false;
+        for (int q = 0; q < T / 64 && !done; ++q) { prefix += s_part[q]; done = s_flag[q] != 0; }
+        __syncthreads();
+        if (done) break;
+        j -= T;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(status + r, ((prefix + mine) << 6) | tag | PRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return prefix;
+}
 template <bool WITH_EP, int T, int CPT>
 __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int g_is_row, int merge,
-                                                    uint32_t *__restrict__ err_x, uint32_t *__restrict__ flags, int eva_check) {
+                                                    uint32_t *__restrict__ err_x, uint32_t *__restrict__ flags, int eva_check, FaChain ch) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     __shared__ uint32_t s_first[FA_NC], s_cn[FA_NC], s_co[FA_NC];
+    __shared__ uint32_t s_pw[CPT][T / 64], s_runp, s_nc, s_ne;
+    __shared__ unsigned long long s_part[T / 64];
+    __shared__ int s_flag[T / 64];
     stage_hc<WITH_EP>(rg, s_hc);
     const int r = blockIdx.x;
     const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
     const int iA_r = rg.exi[2 * x0];                          // the atmosphere cell of the whole range
     if (threadIdx.x < FA_NC) { s_first[threadIdx.x] = 0xffffffffu; s_cn[threadIdx.x] = 0; s_co[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) s_runp = 0;
+    const bool chained = ch.status != nullptr, prank = chained && p.fresh;
+    const bool one_pass = x1 - x0 <= (long)T * CPT;         // then the ranks wait in registers for the keys before the range
+    uint32_t pv[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) pv[u] = 0;
     __syncthreads();
     // CPT cells per thread and pass with their loads staged (exchange cell, then mask / first-seen position of the ice
     // cell) before anything is consumed: a range of ~10^3 cells is one pass, i.e. two dependent round trips in all
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (long cb = x0; cb < x1; cb += (long)T * CPT) {
         int iAv[CPT], iIv[CPT], ifv[CPT];
         double av[CPT], ev[CPT];
-        unsigned fl[CPT];
+        unsigned fl[CPT], prk[CPT];
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
             const long x = cb + (long)u * T + threadIdx.x;
@@ -376,9 +433,13 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
             const long x = cb + (long)u * T + threadIdx.x;
             const bool in = x < x1;
             uint32_t cn0 = 0, co0 = 0;                        // one-class ranges: this lane's new / old entries
+            uint32_t pf = 0;
             if (in) {
                 const XCell c = make_cell<WITH_EP>(rg, iAv[u], iIv[u], av[u], ev[u]);
-                if (p.fresh) p.pflag[x] = (uint8_t)(p.key == KEY_I ? ((ifv[u] == (int32_t)x && c.unmasked) ? 1u : 0u) : fa_pflag_of<WITH_EP>(rg, pl, p, c, x));
+                if (p.fresh) {
+                    pf = p.key == KEY_I ? ((ifv[u] == (int32_t)x && c.unmasked) ? 1u : 0u) : fa_pflag_of<WITH_EP>(rg, pl, p, c, x);
+                    p.pflag[x] = (uint8_t)pf;
+                }
                 if (WITH_EP && c.range_error) atomicMin(err_x, (uint32_t)x);
                 else {
                     // EvA / AvE number the A side by "the range has entries": a cell of GvAp without an elevation-class entry
@@ -407,6 +468,25 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
                 const unsigned long long bn = __ballot(cn0 != 0), bo = __ballot(co0 != 0);
                 if (lane == 0) { if (bn) atomicAdd(&s_cn[0], (uint32_t)__popcll(bn)); if (bo) atomicAdd(&s_co[0], (uint32_t)__popcll(bo)); }
             }
+            if (prank) {                                      // rank of a new P key among the new keys of its range, in x order
+                const unsigned long long bp = __ballot(pf != 0);
+                prk[u] = (uint32_t)__popcll(bp & lt);
+                if (lane == 0) s_pw[u][wave] = (uint32_t)__popcll(bp);
+            }
+        }
+        if (prank) {
+            __syncthreads();
+            uint32_t before = s_runp, all = 0;
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                uint32_t mine = before;
+                for (int w = 0; w < T / 64; ++w) { const uint32_t c = s_pw[u][w]; if (w < wave) mine += c; before += c; all += c; }
+                const long x = cb + (long)u * T + threadIdx.x;
+                if (one_pass) pv[u] = mine + prk[u];
+                else if (x < x1) p.poff[x] = mine + prk[u];   // (inside the range: the keys before the range are added below)
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_runp += all;
         }
     }
     __syncthreads();
@@ -432,6 +512,34 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
         for (int k = 0; k < g.NC; ++k) { nc += s_first[k] != 0xffffffffu ? 1u : 0u; ne += s_cn[k] + s_co[k]; no += s_co[k]; }
         g.r_ncls[r] = nc; g.r_nent[r] = ne;
         if (no > (uint32_t)FA_OLDMAX) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
+        s_nc = nc; s_ne = ne;
+    }
+    if (!chained) return;
+    __syncthreads();
+    const unsigned long long mine = (unsigned long long)s_runp | ((unsigned long long)s_ne << FA_CH_NP) | ((unsigned long long)s_nc << (FA_CH_NP + FA_CH_NE));
+    const unsigned long long prefix = fa_chain_prefix<T>(ch.status, r, ch.epoch, mine, s_part, s_flag);
+    const unsigned long long m21 = (1ull << FA_CH_NP) - 1, m22 = (1ull << FA_CH_NE) - 1;
+    if (threadIdx.x == 0) {
+        g.gbase[r] = (uint32_t)(prefix >> (FA_CH_NP + FA_CH_NE));
+        g.ebase[r] = (uint32_t)((prefix >> FA_CH_NP) & m22);
+        if (r == (int)gridDim.x - 1) {
+            const unsigned long long t = prefix + mine;
+            const uint32_t tc = (uint32_t)(t >> (FA_CH_NP + FA_CH_NE)), te = (uint32_t)((t >> FA_CH_NP) & m22);
+            g.gbase[r + 1] = tc; g.ebase[r + 1] = te;
+            ch.tot[0] = (uint32_t)(t & m21); ch.tot[1] = tc; ch.tot[2] = te;
+        }
+    }
+    const uint32_t pbase = (uint32_t)(prefix & m21);
+    if (prank) {
+        if (one_pass) {
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                const long x = x0 + (long)u * T + threadIdx.x;
+                if (x < x1) p.poff[x] = pv[u] + pbase;
+            }
+        } else if (pbase) {
+            for (long x = x0 + threadIdx.x; x < x1; x += T) p.poff[x] += pbase;
+        }
     }
 }
 // ---- the same counts for ONE-class matrices (AvI, AvX, IvA, XvA: the G side is the atmosphere grid, no elevation classes),
@@ -1159,7 +1267,7 @@ static bool fast_build_eva(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh
     uint32_t *d_cnt = A.get<uint32_t>(8);
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     const int fa_shape = fa_range_shape(nX, nAr);
-    FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, e_is_row ? 1 : 0, 0, d_cnt, d_cnt + 1, 1);
+    FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, e_is_row ? 1 : 0, 0, d_cnt, d_cnt + 1, 1, FaChain{});
     if (nAr > 4096 && fa_rscan_many(g, nAr, abase, d_cnt + 3, d_cnt + 5, st)) {
         // (three short launches for the three channels)
     } else if (nAr > 4096) {
@@ -1250,6 +1358,53 @@ static void fast_prewarm(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_s
 static bool stream_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_sparse_set *dims[2], int scale, int correctA,
                          const RgView &rg, ibh_weighted *w, hipStream_t st, ibh_comm *comm);          // streamasm.inl
 // the first exchange cell of every range on the host (the sharded build deals ranges to ranks), copied once per plan
+// Per host thread (a thread's builds run one after the other on its stream): the status words of the chained scans and a ring of
+// counter slots {0xffffffff, 0, ...}.  The words carry a 4-bit epoch, so they are cleared every 15 builds; the ring is
+// initialised again when it has gone round (both stream-ordered, both amortised to nothing).
+__global__ void k_fa_init_ring(uint32_t *cnt, int nslot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nslot * 8) cnt[i] = (i & 7) == 0 ? 0xffffffffu : 0u;
+}
+struct FaChainState {
+    static constexpr int NSLOT = 256;
+    unsigned long long *status = nullptr;
+    size_t cap = 0;
+    unsigned epoch = 0;
+    uint32_t *ring = nullptr;
+    int next = NSLOT, device = -1;
+    void bind() {
+        int dev = 0;
+        IBH_HIP(hipGetDevice(&dev));
+        if (dev == device) return;
+        // (buffers of another device are left to that device's context: a thread that switches devices is rare and they are small)
+        status = nullptr; cap = 0; epoch = 0; ring = nullptr; next = NSLOT; device = dev;
+    }
+    uint32_t *counters(hipStream_t st) {
+        bind();
+        if (!ring) IBH_HIP(hipMalloc(&ring, sizeof(uint32_t) * 8 * NSLOT));
+        if (next >= NSLOT) {
+            hipLaunchKernelGGL(k_fa_init_ring, dim3(ceil_div(8 * NSLOT, 256)), dim3(256), 0, st, ring, (int)NSLOT);
+            next = 0;
+        }
+        return ring + 8 * (size_t)(next++);
+    }
+    unsigned long long *words(size_t n, hipStream_t st) {
+        bind();
+        bool clear = false;
+        if (cap < n) {
+            if (status) (void)hipFree(status);
+            cap = std::max<size_t>(n, 4096) * 2;
+            IBH_HIP(hipMalloc(&status, cap * sizeof(unsigned long long)));
+            clear = true;
+            epoch = 0;
+        }
+        if (++epoch > 15) { epoch = 1; clear = true; }
+        if (clear) IBH_HIP(hipMemsetAsync(status, 0, cap * sizeof(unsigned long long), st));
+        return status;
+    }
+};
+static FaChainState &fa_chain_state() { static thread_local FaChainState s; return s; }
+
 static const std::vector<int32_t> &plan_arng_host(const ibh_regridder *g) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
@@ -1303,20 +1458,34 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     FaP p{};
     p.key = pkey; p.list = plist; p.fresh = pmode;
     // counters read back with one sync: [0] first out-of-range cell, [1] fallback flags, [2] new P keys, [3] G classes, [4] entries
-    uint32_t *d_cnt = A.get<uint32_t>(8);
-    hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
+    const bool stream_count = !uses_ep && g.NC == 1 && !g.tab && get_tuning("assemble_stream_count", nX >= (1l << 20) ? 1 : 0);
+    // small grids: the scans ride in the counting kernel (FaChain) and the counters come initialised from a ring of slots --
+    // three launches fewer in a chain of seven to nine that is all a 5 km build costs
+    const bool chained = !stream_count && nX <= (1l << 20) && nrc < (1ul << FA_CH_NC) && get_tuning("assemble_chain", 1);
+    FaChain chain{};
+    uint32_t *d_cnt;
+    if (chained) {
+        FaChainState &cs = fa_chain_state();
+        d_cnt = cs.counters(st);
+        chain = FaChain{cs.words((size_t)nAr, st), cs.epoch, d_cnt + 2};
+    } else {
+        d_cnt = A.get<uint32_t>(8);
+        hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
+    }
     if (p.fresh) { p.pflag = A.get<uint8_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
     const int fa_shape = fa_range_shape(nX, nAr);
-    const bool stream_count = !uses_ep && g.NC == 1 && !g.tab && get_tuning("assemble_stream_count", nX >= (1l << 20) ? 1 : 0);
     if (stream_count) {
         // one-class matrices of large grids: cells streamed, counts by integer atomics (three launches, all short)
         hipLaunchKernelGGL(k_fa_zero_counts, dim3(ceil_div(nAr, 256)), dim3(256), 0, st, g.r_ncls, g.ecntn, g.ecnto, nAr);
         hipLaunchKernelGGL(k_fa_count_stream<4>, dim3(ceil_div(nX, 1024)), dim3(256), 0, st, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge);
         hipLaunchKernelGGL(k_fa_count_fin, dim3(ceil_div(nAr, 256)), dim3(256), 0, st, g, nAr, d_cnt + 1);
-    } else if (uses_ep) FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
-    else FA_LAUNCH_COUNT(false, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0);
-    if (p.fresh) exclusive_scan_u8(p.pflag, p.poff, (size_t)nX, d_cnt + 2, st);
-    if (nAr > 4096 && fa_rscan_many(g, nAr, nullptr, d_cnt + 3, nullptr, st)) {
+    } else if (uses_ep) FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0, chain);
+    else FA_LAUNCH_COUNT(false, rg, pl, *sp, g, p, g_is_row ? 1 : 0, merge, d_cnt, d_cnt + 1, 0, chain);
+    if (chained) {
+        // (poff, gbase / ebase and the three totals were written by k_fa_count)
+    } else if (p.fresh) exclusive_scan_u8(p.pflag, p.poff, (size_t)nX, d_cnt + 2, st);
+    if (chained) {
+    } else if (nAr > 4096 && fa_rscan_many(g, nAr, nullptr, d_cnt + 3, nullptr, st)) {
         // (many ranges: three short launches for both channels)
     } else if (nAr > 4096) {                                    // very many: the device-wide scan; few: one workgroup, one launch
         exclusive_scan_u32(g.r_ncls, g.gbase, (size_t)nAr, g.gbase + nAr, st);
