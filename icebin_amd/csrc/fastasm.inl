@@ -348,6 +348,8 @@ struct FaChain {
     unsigned long long *status;     // [nAr]
     unsigned epoch;                 // 1..15: words of another epoch are "not yet written"
     uint32_t *tot;                  // [3]: new P keys, classes, entries of the whole grid (the counters read back by the host)
+    uint32_t *zero;                 // words a later kernel of the build wants cleared (a hipMemsetAsync of an odd size is TWO launches)
+    unsigned nzero;
 };
 constexpr int FA_CH_NP = 21, FA_CH_NE = 22, FA_CH_NC = 15;
 // Exclusive prefix of `mine` (<= 58 bits, fields that cannot overflow) over the workgroups before r; every thread of the workgroup
@@ -400,6 +402,8 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
     if (threadIdx.x < FA_NC) { s_first[threadIdx.x] = 0xffffffffu; s_cn[threadIdx.x] = 0; s_co[threadIdx.x] = 0; }
     if (threadIdx.x == 0) s_runp = 0;
     const bool chained = ch.status != nullptr, prank = chained && p.fresh;
+    if (chained && ch.zero)
+        for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nzero; i += gridDim.x * T) ch.zero[i] = 0u;
     const bool one_pass = x1 - x0 <= (long)T * CPT;         // then the ranks wait in registers for the keys before the range
     uint32_t pv[CPT];
 #pragma unroll
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
                     }
                     if (!(merge && (fl[u] & 1))) {
                         GEnt ge;
-                        fa_group<WITH_EP>(rg, pl, s, g_is_row != 0, merge != 0, c, x, ge);
+                        fa_group<WITH_EP>(rg, pl, s, g_is_row != 0, merge != 0 && (fl[u] & 128), c, x, ge);      // (plan bit 7: a duplicate follows)
                         const bool isnew = p.key != KEY_I || !p.fresh || ifv[u] >= x0;
                         if (g.NC == 1) { cn0 = (ge.n > 0 && isnew) ? 1u : 0u; co0 = (ge.n > 0 && !isnew) ? 1u : 0u; }
                         else {
@@ -734,7 +738,15 @@ struct FaOut {
     double *wM, *Mw;                // EMIT writes wM (rows = G side), SUMS writes Mw (cols = G side)
     int family, scale, correctA;
     int g_rows;                     // SUMS only: the G side is the ROW side of the spec (EvA through the column-sum machinery)
+#ifdef FA_TIMELINE
+    long long *dbg;                 // scratch/r05/range_timeline.py: 8 stamps per range from thread 0
+#endif
 };
+#ifdef FA_TIMELINE
+#define FA_STAMP(i) do { if (tid == 0) { tl[i] = (long long)__builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define FA_STAMP(i) do { } while (0)
+#endif
 template <bool WITH_EP, bool EMIT, int T, int CPT>
 __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, FaOut o,
                                                     uint32_t *__restrict__ flags) {
@@ -742,11 +754,16 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
     __shared__ int s_rank[FA_NC];
     __shared__ uint32_t s_start[FA_NC + 1], s_seg[FA_NC], s_nold[FA_NC], s_run[FA_NC], s_wcnt[T / 64][FA_NC];
     __shared__ double s_mul[FA_NC];
+    __shared__ double s_chain[T / 64][64];
     __shared__ uint32_t s_no, s_w1[2][T / 64];
     __shared__ int o_cls[FA_OLDMAX], o_did[FA_OLDMAX];
     __shared__ double o_t[FA_OLDMAX];
     stage_hc<WITH_EP>(rg, s_hc);
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef FA_TIMELINE
+    long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    FA_STAMP(0);
     const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
     const int iA_r = rg.exi[2 * x0];                          // the atmosphere cell of the whole range
     const uint32_t eb = g.ebase[r];
@@ -771,6 +788,7 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
     __syncthreads();
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const bool g_is_row = EMIT || o.g_rows != 0;
+    FA_STAMP(1);
     // CPT cells per thread and pass: their loads are issued in three staged rounds (exchange cell -> mask and
     // first-seen position of its ice cell -> dense id) before anything is consumed, so a pass pays the dependent
     // round trips once instead of once per 256 cells; the ranking then walks the CPT sub-chunks in x order.
@@ -809,6 +827,9 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
                 } else didv[u] = iIv[u];
             } else didv[u] = p.fresh ? (int)pov[u] : (int)(x < x1 ? x : x1 - 1);
         }
+#ifdef FA_TIMELINE
+        if (cb == x0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[2] = (long long)__builtin_amdgcn_s_memtime(); }
+#endif
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
             const long x = cb + (long)u * T + tid;
@@ -818,7 +839,7 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
             bool member = false;                              // EMIT: the P key of this head cell is in the set numbered by this build
             if (head) {
                 const XCell c = make_cell<WITH_EP>(rg, iAv[u], iIv[u], av[u], ev[u]);
-                if (!(WITH_EP && c.range_error)) fa_group<WITH_EP>(rg, pl, s, g_is_row, merge != 0, c, x, ge);
+                if (!(WITH_EP && c.range_error)) fa_group<WITH_EP>(rg, pl, s, g_is_row, merge != 0 && (fl[u] & 128), c, x, ge);
                 member = p.fresh && (p.key == KEY_I ? (c.unmasked && ifv[u] >= 0) : pfv[u] != 0);
             }
             newv[u] = head && (p.key != KEY_I || !p.fresh || ifv[u] >= x0);
@@ -838,6 +859,7 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
                 }
             }
         }
+        if (cb == x0) FA_STAMP(3);
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
             if (cb + (long)u * T >= x1) break;          // uniform: this sub-chunk lies past the range
@@ -911,6 +933,7 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
             __syncthreads();
         }
     }
+    FA_STAMP(4);
     const uint32_t no = s_no < (uint32_t)FA_OLDMAX ? s_no : (uint32_t)FA_OLDMAX;
     if (s_no > (uint32_t)FA_OLDMAX && tid == 0) atomicOr(flags, (uint32_t)FA_ERR_OLDOVER);
     for (uint32_t e = tid; e < no; e += T) {            // inside a class the old ids are distinct: rank by counting
@@ -923,25 +946,34 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
     }
     __threadfence_block();
     __syncthreads();
+    FA_STAMP(5);
     // Sequential sums (the order of spsparse sum()), one WAVE per segment: 64 values are loaded coalesced and the
     // chain is replayed from registers with v_readlane (every lane computes the identical sum), as k_seg_sums_wave
     // does; then the weights (k_weights) and, for the rows, the scaling.
     for (int q = wave; q < ncls; q += T / 64) {
         const uint32_t b = eb + s_start[q], e = eb + s_start[q + 1];
         double sum = 0.0;
+        // The chain is replayed from LDS: the wave parks 64 values in its own 512 bytes and every lane reads them back one address
+        // at a time (a broadcast read) -- one read and one dependent add per value where v_readlane took two scalar moves and an
+        // add (25 cycles per value measured; the longest row of a 5 km range, ~1 100 values, was half of this kernel's time).
+        // The next chunk's load is in flight while this one is summed.
+        double *buf = s_chain[wave];
+        double vnext = b + lane < e ? o.val[b + lane] : 0.0;
         for (uint32_t base = b; base < e; base += 64) {
-            const uint32_t k = base + lane;
-            const double v = k < e ? o.val[k] : 0.0;
+            const double v = vnext;
+            const uint32_t kn = base + 64 + lane;
+            vnext = kn < e ? o.val[kn] : 0.0;
+            buf[lane] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             const int cnt = (int)min(64u, e - base);
-            const int lo = __double2loint(v), hi = __double2hiint(v);
             if (cnt == 64) {
 #pragma unroll
-                for (int j = 0; j < 64; ++j)
-                    sum = sum + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+                for (int j = 0; j < 64; ++j) sum = sum + buf[j];
             } else {
-                for (int j = 0; j < cnt; ++j)
-                    sum = sum + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+                for (int j = 0; j < cnt; ++j) sum = sum + buf[j];
             }
+            __builtin_amdgcn_wave_barrier();
         }
         if (lane == 0) {
             int cls = 0;
@@ -971,6 +1003,7 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
             }
         }
     }
+    FA_STAMP(6);
     if (EMIT && r == pl.nAr - 1 && tid == 0) o.rowptr[g.gbase[pl.nAr]] = (int32_t)g.ebase[pl.nAr];      // rowptr[nrow] = nnz
     if (EMIT && o.scale) {
         __syncthreads();
@@ -979,6 +1012,13 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
             for (uint32_t k = eb + s_start[q] + tid; k < eb + s_start[q + 1]; k += T) o.val[k] = mul * o.val[k];
         }
     }
+#ifdef FA_TIMELINE
+    if (tid == 0 && o.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tl[7] = (long long)__builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 8; ++i) o.dbg[(size_t)r * 8 + i] = tl[i];
+    }
+#endif
 }
 
 // ---- one thread per P element (ice cell or exchange cell): its <= 8 entries --------------------------
@@ -1052,7 +1092,7 @@ __global__ __launch_bounds__(FA_T, (WITH_EP && MODE == 2) ? (ANYORDER ? 1 : 6) :
                                 : load_cell<WITH_EP>(rg, x);
             if (WITH_EP && c.range_error) continue;
             GEnt ge;
-            fa_group<WITH_EP>(rg, pl, s, g_is_row, merge != 0, c, x, ge);
+            fa_group<WITH_EP>(rg, pl, s, g_is_row, merge != 0 && (fx & 128), c, x, ge);      // (plan bit 7: a duplicate follows)
             if (ge.n == 0) continue;
             const int r = pl.aidx[x];
             const int id0 = MODE == FA_PCOUNT ? 0 : fa_gdense(g, r, ge.cls0, ge.gkey0);
@@ -1159,11 +1199,16 @@ __global__ void k_fa_init(uint32_t *cnt) {
 //                                                            128 x 4 1.33 / 1.87, 64 x 4 1.32 / 2.12, 64 x 2 1.38 / 2.22
 //   1 km (553 ranges of ~7 900 cells):                       128 x 2 0.30 / 0.44, 256 x 4 0.24 / 0.32, 1024 x 4 0.34 / 0.37
 //   5 km (122 ranges of ~1 500: fewer workgroups than CUs):  128 x 2 0.096 / 0.142, 256 x 4 0.082 / 0.109, 1024 x 4 0.076 / 0.089
-// shape 0: 128 threads x 2 cells, 1: 256 x 4, 2: 1024 x 4 (tuning "assemble_range_shape" overrides; scratch/asm_shapes.py)
+// Round 5, the synthetic 5 km grid of the tests (252 ranges of ~720 cells; us per build AvI / EvI / IvE / XvE): 256 x 4 64.8 / 94.3 /
+// 115.0 / 89.8, 1024 x 4 58.6 / 75.8 / 97.9 / 74.2, 1024 x 1 54.6 / 68.8 / 92.6 / 69.5; 20 km (60 ranges of ~240): 256 x 4 46.0 / 68.2 /
+// 84.1 / 63.4, 1024 x 4 54.5 / 69.5 / 88.0 / 68.0, 1024 x 1 46.2 / 62.5 / 80.3 / 60.1 -- with fewer workgroups than the chip holds, one
+// cell per thread: the per-thread loops over the cells of a pass are what a range's workgroup spends its time in.
+// shape 0: 128 threads x 2 cells, 1: 256 x 4, 2: 1024 x 4, 3: 1024 x 1 (tuning "assemble_range_shape" overrides; scratch/asm_shapes.py)
 static int fa_range_shape(long nX, int nAr) {
     const int forced = get_tuning("assemble_range_shape", -1);
-    if (forced >= 0 && forced <= 2) return forced;
+    if (forced >= 0 && forced <= 3) return forced;
     const long mean = nX / (nAr > 0 ? nAr : 1);
+    if (mean <= 1024 && nAr <= 512) return 3;           // every workgroup resident at once (two of 1024 threads per CU): a cell per thread
     if (mean <= 1024 && nAr >= 2048) return 0;
     if (mean > 1024 && nAr <= 256) return 2;            // at most one workgroup per CU: make it a big one
     return 1;
@@ -1172,12 +1217,14 @@ static int fa_range_shape(long nX, int nAr) {
     do {                                                                                                                \
         if (fa_shape == 0) hipLaunchKernelGGL((k_fa_count<EP, 128, 2>), dim3(nAr), dim3(128), 0, st, __VA_ARGS__);      \
         else if (fa_shape == 2) hipLaunchKernelGGL((k_fa_count<EP, 1024, 4>), dim3(nAr), dim3(1024), 0, st, __VA_ARGS__); \
+        else if (fa_shape == 3) hipLaunchKernelGGL((k_fa_count<EP, 1024, 1>), dim3(nAr), dim3(1024), 0, st, __VA_ARGS__); \
         else hipLaunchKernelGGL((k_fa_count<EP, 256, 4>), dim3(nAr), dim3(256), 0, st, __VA_ARGS__);                    \
     } while (0)
 #define FA_LAUNCH_RANGE(EP, EM, ...)                                                                                    \
     do {                                                                                                                \
         if (fa_shape == 0) hipLaunchKernelGGL((k_fa_range<EP, EM, 128, 2>), dim3(nAr), dim3(128), 0, st, __VA_ARGS__);  \
         else if (fa_shape == 2) hipLaunchKernelGGL((k_fa_range<EP, EM, 1024, 4>), dim3(nAr), dim3(1024), 0, st, __VA_ARGS__); \
+        else if (fa_shape == 3) hipLaunchKernelGGL((k_fa_range<EP, EM, 1024, 1>), dim3(nAr), dim3(1024), 0, st, __VA_ARGS__); \
         else hipLaunchKernelGGL((k_fa_range<EP, EM, 256, 4>), dim3(nAr), dim3(256), 0, st, __VA_ARGS__);                \
     } while (0)
 
@@ -1461,13 +1508,24 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     const bool stream_count = !uses_ep && g.NC == 1 && !g.tab && get_tuning("assemble_stream_count", nX >= (1l << 20) ? 1 : 0);
     // small grids: the scans ride in the counting kernel (FaChain) and the counters come initialised from a ring of slots --
     // three launches fewer in a chain of seven to nine that is all a 5 km build costs
-    const bool chained = !stream_count && nX <= (1l << 20) && nrc < (1ul << FA_CH_NC) && get_tuning("assemble_chain", 1);
+    const bool optimistic = nX <= (1l << 20) && get_tuning("assemble_optimistic", 1);
+    const bool chained = optimistic && !stream_count && nrc < (1ul << FA_CH_NC) && get_tuning("assemble_chain", 1);
     FaChain chain{};
     uint32_t *d_cnt;
+    uint32_t *rowlen_early = nullptr;
     if (chained) {
         FaChainState &cs = fa_chain_state();
         d_cnt = cs.counters(st);
-        chain = FaChain{cs.words((size_t)nAr, st), cs.epoch, d_cnt + 2};
+        chain = FaChain{cs.words((size_t)nAr, st), cs.epoch, d_cnt + 2, nullptr, 0u};
+        // what the later kernels want cleared, by the upper bounds the outputs are allocated with below
+        const size_t np_ub = p.fresh ? (size_t)std::min<int64_t>(extent_of(pkey), nX) : (size_t)extent_of(pkey);
+        if (g_is_row && !p.fresh && np_ub) {                    // Mw of an identity P set: members without entries stay 0
+            w->Mw.alloc(np_ub);
+            chain.zero = reinterpret_cast<uint32_t *>(w->Mw.p); chain.nzero = (unsigned)(2 * np_ub);
+        } else if (!g_is_row && p.fresh) {                      // row lengths beyond the real number of rows
+            rowlen_early = A.get<uint32_t>(np_ub + 1);
+            chain.zero = rowlen_early; chain.nzero = (unsigned)(np_ub + 1);
+        }
     } else {
         d_cnt = A.get<uint32_t>(8);
         hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
@@ -1513,7 +1571,6 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     // Small grids are bound by launches and synchronisations, not by bytes: their outputs are allocated by upper bounds
     // (<= 2 entries per exchange cell, <= NC rows per range) so that the counters are read back ONCE, with the final
     // synchronisation; large grids read them here and allocate exactly.
-    const bool optimistic = nX <= (1l << 20) && get_tuning("assemble_optimistic", 1);
     if (!optimistic && !check_counters()) return false;
     const uint32_t n_pnew = optimistic ? (uint32_t)std::min<int64_t>(extent_of(pkey), nX) : h[2];
     const uint32_t n_g = optimistic ? (uint32_t)nrc : h[3];
@@ -1529,6 +1586,9 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     w->rowptr.alloc((size_t)nrow + 1); w->colind.alloc(nnz); w->val.alloc(nnz);
     w->wM.alloc((size_t)nrow); w->Mw.alloc((size_t)ncol);
     FaOut o{w->rowptr.p, w->colind.p, w->val.p, w->wM.p, w->Mw.p, sp->family, scale, correctA, 0};
+#ifdef FA_TIMELINE
+    o.dbg = reinterpret_cast<long long *>(((unsigned long long)(unsigned)get_tuning("gt_dbg_hi", 0) << 32) | (unsigned)get_tuning("gt_dbg_lo", 0));
+#endif
     uint32_t *flags = d_cnt + 1;
     const long np_s = p.key == KEY_I ? gr->nI : nX;             // P elements by sparse index
     const dim3 gp(ceil_div(np_s, T));
@@ -1536,7 +1596,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         // rows = G: CSR + wM + (most of) Mw from the ranges; members of the P set without entries keep Mw = 0
         // (a set numbered by this build: every member's Mw is written by k_fa_range / k_fa_pelem<SUMS>; an identity set has
         // non-members -- masked cells -- whose Mw stays 0)
-        if (ncol && !p.fresh) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
+        if (ncol && !p.fresh && !chain.zero) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
         if (uses_ep) FA_LAUNCH_RANGE(true, true, rg, pl, *sp, g, p, merge, o, flags);
         else FA_LAUNCH_RANGE(false, true, rg, pl, *sp, g, p, merge, o, flags);
         if (p.key == KEY_I && P.nmulti) {                     // Mw of the ice cells that straddle ranges (a few %)
@@ -1546,8 +1606,8 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         }
     } else {
         // rows = P: count -> scan -> emit per element; Mw (G columns) from the ranges through a scratch copy of the terms
-        uint32_t *rowlen = A.get<uint32_t>((size_t)nrow + 1);
-        if (optimistic && p.fresh) IBH_HIP(hipMemsetAsync(rowlen, 0, sizeof(uint32_t) * ((size_t)nrow + 1), st));   // rows beyond the real count
+        uint32_t *rowlen = rowlen_early ? rowlen_early : A.get<uint32_t>((size_t)nrow + 1);
+        if (optimistic && p.fresh && !rowlen_early) IBH_HIP(hipMemsetAsync(rowlen, 0, sizeof(uint32_t) * ((size_t)nrow + 1), st));   // rows beyond the real count
         if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
         else hipLaunchKernelGGL((k_fa_pelem<false, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
         exclusive_scan_u32(rowlen, reinterpret_cast<uint32_t *>(w->rowptr.p), (size_t)nrow, reinterpret_cast<uint32_t *>(w->rowptr.p) + nrow, st);

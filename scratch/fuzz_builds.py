@@ -18,7 +18,7 @@ for seed in range(first, first + count):
         mm, rg = icebin_amd.from_synthetic(g), orc.Regridder(g)
         rm = mm.regrid_matrices("greenland", em)
         icebin_amd.set_tuning("assemble_stream_count", seed % 2)
-        icebin_amd.set_tuning("assemble_range_shape", seed % 3)
+        icebin_amd.set_tuning("assemble_range_shape", seed % 4)
         icebin_amd.set_tuning("assemble_static_count", (seed // 2) % 2)
         # the streamed build (what grids of 2^20 cells and more take) on every third seed, its row kernels and tile walk varied
         icebin_amd.set_tuning("assemble_stream", 1 if seed % 3 == 0 else -2 ** 31)

@@ -195,11 +195,11 @@ def test_fused_pair_evi_then_ave_is_the_two_applies(config, kw, rowgroup_form):
         a.apply_pair_device(b, torch.zeros((2, a.ncol_d), dtype=torch.float64, device="cuda"))
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3])
 def test_assembly_range_kernel_shapes_are_bit_identical(shape):
-    # the per-range kernels of the plan-based build exist in three workgroup shapes (128 x 2, 256 x 4, 1024 x 4 cells per pass,
-    # chosen by the size of the ranges: fastasm.inl fa_range_shape); every shape must give the oracle's bits -- ranges shorter
-    # and longer than one pass (g50: ~20 cells, g5: ~1 500), duplicates, zero areas, both interpolation styles
+    # the per-range kernels of the plan-based build exist in four workgroup shapes (128 x 2, 256 x 4, 1024 x 4, 1024 x 1 cells per
+    # pass, chosen by the size and number of the ranges: fastasm.inl fa_range_shape); every shape must give the oracle's bits --
+    # ranges shorter and longer than one pass (g50: ~20 cells, g5: ~720, up to ~1 500), duplicates, zero areas, both interpolation styles
     try:
         icebin_amd.set_tuning("assemble_range_shape", shape)
         # (shape 1 also with the row counts of the I-row builds taken by VISITING the exchange cells instead of from the plan's
@@ -2176,7 +2176,7 @@ def test_random_sorted_grids_on_every_variant_of_the_plan_based_build(seed):
     rm = mm.regrid_matrices("greenland", em)
     try:
         icebin_amd.set_tuning("assemble_stream_count", 1)
-        icebin_amd.set_tuning("assemble_range_shape", seed % 3)
+        icebin_amd.set_tuning("assemble_range_shape", seed % 4)
         icebin_amd.set_tuning("assemble_static_count", seed % 2)
         icebin_amd.set_tuning("assemble_stream_rowsl", (seed // 2) % 2)        # (the lane-parallel row kernel of the streamed build ...
         icebin_amd.set_tuning("assemble_stream_rowsl_r", (1, 3, 16, 5, 2)[seed % 5])      # ... and its ranges per wave)
