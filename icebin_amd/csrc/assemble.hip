@@ -19,6 +19,8 @@
 #include "assemble.h"
 #include "prims.h"
 #include "sweep_kernel.inl"
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
@@ -2285,31 +2287,39 @@ bool assemble_matrix(const ibh_regrid_matrices *rm, const char *spec_name, ibh_s
 // pipeline -- which may append -- is redone sequentially afterwards, together with the later jobs that share its sets.
 namespace {
 class WorkerPool {
+    // A coupling step at 5 km is ~0.2 ms in two waves of two builds: a worker that went to sleep on the condition variable between
+    // the waves costs a futex wake-up (tens of us) each time.  Workers therefore poll for the next job for a short while after
+    // finishing one, and wait() polls before it blocks; idle pools sleep as before.
+    static constexpr long SPIN_NS = 400 * 1000;
     std::vector<std::thread> threads;
     std::mutex mu;
     std::condition_variable cv, done_cv;
     std::deque<std::function<void()>> queue;
-    int pending = 0;
+    std::atomic<int> queued{0}, pending{0};
     bool stop = false;
+    static long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 public:
     explicit WorkerPool(int n) {
         for (int i = 0; i < n; ++i)
             threads.emplace_back([this] {
+                long spin_until = 0;
                 for (;;) {
                     std::function<void()> job;
+                    while (queued.load(std::memory_order_acquire) == 0 && now_ns() < spin_until) __builtin_ia32_pause();
                     {
                         std::unique_lock<std::mutex> lk(mu);
                         cv.wait(lk, [this] { return stop || !queue.empty(); });
                         if (stop && queue.empty()) return;
                         job = std::move(queue.front());
                         queue.pop_front();
+                        queued.fetch_sub(1, std::memory_order_relaxed);
                     }
                     job();
-                    {
-                        std::lock_guard<std::mutex> lk(mu);
-                        --pending;
+                    if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                        std::lock_guard<std::mutex> lk(mu);      // (pairs with wait(): no wake-up is lost)
+                        done_cv.notify_all();
                     }
-                    done_cv.notify_all();
+                    spin_until = now_ns() + SPIN_NS;
                 }
             });
     }
@@ -2319,12 +2329,14 @@ public:
         for (auto &t : threads) t.detach();      // process exit: the HIP runtime may already be gone, do not join into it
     }
     void submit(std::function<void()> f) {
-        { std::lock_guard<std::mutex> lk(mu); queue.push_back(std::move(f)); ++pending; }
+        { std::lock_guard<std::mutex> lk(mu); queue.push_back(std::move(f)); pending.fetch_add(1, std::memory_order_relaxed); queued.fetch_add(1, std::memory_order_release); }
         cv.notify_one();
     }
     void wait() {
+        const long until = now_ns() + 4 * SPIN_NS;
+        while (pending.load(std::memory_order_acquire) != 0 && now_ns() < until) __builtin_ia32_pause();
         std::unique_lock<std::mutex> lk(mu);
-        done_cv.wait(lk, [this] { return pending == 0; });
+        done_cv.wait(lk, [this] { return pending.load(std::memory_order_acquire) == 0; });
     }
 };
 WorkerPool &pool() { static WorkerPool *p = new WorkerPool(3); return *p; }
