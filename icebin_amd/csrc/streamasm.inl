@@ -832,6 +832,7 @@ template <bool EMIT, int OLDSEG>
 __global__ __launch_bounds__(256) void k_sa_rows1(RgView rg, PlanView pl, FaG g, FaOut o, int32_t *__restrict__ sdid, int sr0, int sr1) {
     __shared__ int s_did[4][OLDSEG], s_did2[4][OLDSEG];
     __shared__ double s_t[4][OLDSEG], s_t2[4][OLDSEG];
+    __shared__ double s_ch[4][64];
     constexpr int NV = 8;                                        // chunks of 64 values of a segment loaded up front and kept in registers
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (walking the ranges from the END of the slice first -- the segments the emit pass wrote last, the likeliest to be still in
@@ -885,17 +886,20 @@ __global__ __launch_bounds__(256) void k_sa_rows1(RgView rg, PlanView pl, FaG g,
         // with v_readlane (every lane computes the identical sum)
         double sum = 0.0;
         for (uint32_t k = 0; k < no; ++k) sum = sum + s_t2[wv][k];
-        auto chain = [&](double val, uint32_t cb) {
-            const int cnt = (int)min(64u, e - cb);
-            const int lo = __double2loint(val), hi = __double2hiint(val);
-            if (cnt == 64) {
+        // The chain (round 5): a chunk's 64 values are parked in the wave's LDS row and ONE lane adds them (ds_read_b128 + two
+        // adds per pair of terms where the v_readlane replay took six vector instructions; measured on a dependent chain: 9.3
+        // against 20.7 cycles per term; this pass is bound by instruction issue).  Values past the segment's end were loaded as +0.0: a chain that
+        // starts from +0.0 never holds -0.0, so adding them changes no bit.
+        double *chb = s_ch[wv];
+        auto chain = [&](double val, uint32_t) {
+            chb[lane] = val;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
 #pragma unroll
-                for (int j = 0; j < 64; ++j)
-                    sum = sum + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
-            } else {
-                for (int j = 0; j < cnt; ++j)
-                    sum = sum + __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+                for (int j = 0; j < 64; ++j) sum = sum + chb[j];
             }
+            __builtin_amdgcn_wave_barrier();
         };
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
@@ -917,6 +921,7 @@ __global__ __launch_bounds__(256) void k_sa_rows1(RgView rg, PlanView pl, FaG g,
                 chain(u4[c], cb);
             }
         }
+        sum = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sum)), __builtin_amdgcn_readfirstlane(__double2loint(sum)));
         const long gkey = g.key == KEY_E ? iA * rg.sA + (long)cls * rg.sHC : iA;
         const int gd = fa_gdense(g, r, cls, gkey);
         if (gd < 0) continue;                                   // a key the pre-populated set lacks: the build is discarded (FA_ERR_MISSING)
