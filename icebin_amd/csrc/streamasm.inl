@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) void k_sa_rows1(RgView rg, PlanView pl, FaG g,
             chb[lane] = val;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
+            if (lane == 0) {                  // (all 64 lanes adding: the same time, 64 x the LDS traffic)
 #pragma unroll
                 for (int j = 0; j < 64; ++j) sum = sum + chb[j];
             }
