@@ -755,6 +755,10 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
     __shared__ uint32_t s_start[FA_NC + 1], s_seg[FA_NC], s_nold[FA_NC], s_run[FA_NC], s_wcnt[T / 64][FA_NC];
     __shared__ double s_mul[FA_NC];
     __shared__ double s_chain[T / 64][64];
+    // the values of a range that fits (its entries <= LCAP: every range of a small grid) stay in LDS from their placement to the
+    // scaling: the sums and the scaling never read them back from memory
+    constexpr int LCAP = T == 1024 ? 4096 : T == 256 ? 2048 : 1024;
+    __shared__ __attribute__((aligned(16))) double s_vals[LCAP];
     __shared__ uint32_t s_no, s_w1[2][T / 64];
     __shared__ int o_cls[FA_OLDMAX], o_did[FA_OLDMAX];
     __shared__ double o_t[FA_OLDMAX];
@@ -788,6 +792,10 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
     __syncthreads();
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const bool g_is_row = EMIT || o.g_rows != 0;
+    const bool fits = s_start[ncls] <= (uint32_t)LCAP;          // (uniform)
+    // values go to memory from here only when nothing later writes them: rows that are scaled are written once, scaled; the
+    // terms of the column sums (SUMS: o.val is scratch) are not needed in memory at all when the range is in LDS
+    const bool wglobal = !fits || (EMIT && !o.scale);
     FA_STAMP(1);
     // CPT cells per thread and pass: their loads are issued in three staged rounds (exchange cell -> mask and
     // first-seen position of its ice cell -> dense id) before anything is consumed, so a pass pays the dependent
@@ -879,7 +887,8 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
                         for (int w = 0; w < wave; ++w) before += s_w1[par][w];
                         const uint32_t pos = eb + s_nold[0] + before + (uint32_t)__popcll(m & lt);
                         if (EMIT) o.colind[pos] = did;
-                        o.val[pos] = ge.t0;
+                        if (fits) s_vals[pos - eb] = ge.t0;
+                        if (wglobal) o.val[pos] = ge.t0;
                     } else {
                         const uint32_t q = atomicAdd(&s_no, 1u);
                         if (q < (uint32_t)FA_OLDMAX) { o_cls[q] = 0; o_did[q] = did; o_t[q] = ge.t0; }
@@ -918,7 +927,8 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
                     for (int w = 0; w < wave; ++w) before += s_wcnt[w][cls];
                     const uint32_t pos = eb + s_start[s_rank[cls]] + s_nold[cls] + before + (j ? in1 : in0);
                     if (EMIT) o.colind[pos] = did;
-                    o.val[pos] = ge.t(j);
+                    if (fits) s_vals[pos - eb] = ge.t(j);
+                    if (wglobal) o.val[pos] = ge.t(j);
                 } else {                                       // straddler: ranked after the stream
                     const uint32_t q = atomicAdd(&s_no, 1u);
                     if (q < (uint32_t)FA_OLDMAX) { o_cls[q] = cls; o_did[q] = did; o_t[q] = ge.t(j); }
@@ -942,7 +952,8 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
         for (uint32_t q = 0; q < no; ++q) cnt += (o_cls[q] == cls && o_did[q] < did) ? 1u : 0u;
         const uint32_t pos = eb + s_start[s_rank[cls]] + cnt;
         if (EMIT) o.colind[pos] = did;
-        o.val[pos] = o_t[e];
+        if (fits) s_vals[pos - eb] = o_t[e];
+        if (wglobal) o.val[pos] = o_t[e];
     }
     __threadfence_block();
     __syncthreads();
@@ -957,9 +968,23 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
         // at a time (a broadcast read) -- one read and one dependent add per value where v_readlane took two scalar moves and an
         // add (25 cycles per value measured; the longest row of a 5 km range, ~1 100 values, was half of this kernel's time).
         // The next chunk's load is in flight while this one is summed.
+        if (fits) {                                             // one lane walks the segment in LDS (5.5 cycles per term measured)
+            if (lane == 0) {
+                const uint32_t s0 = s_start[q], n = e - b;
+                uint32_t k = 0;
+                if ((s0 & 1u) && n) { sum = sum + s_vals[s0]; k = 1; }      // (then the rest is read 16 bytes at a time)
+                const double2 *sv2 = reinterpret_cast<const double2 *>(__builtin_assume_aligned(s_vals + s0 + k, 16));
+                for (; k + 64 <= n; k += 64, sv2 += 32) {
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) { const double2 t2 = sv2[j]; sum = sum + t2.x; sum = sum + t2.y; }
+                }
+                for (const double *sv = reinterpret_cast<const double *>(sv2); k < n; ++k, ++sv) sum = sum + *sv;
+            }
+            sum = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(sum)), __builtin_amdgcn_readfirstlane(__double2loint(sum)));
+        }
         double *buf = s_chain[wave];
-        double vnext = b + lane < e ? o.val[b + lane] : 0.0;
-        for (uint32_t base = b; base < e; base += 64) {
+        double vnext = (!fits && b + lane < e) ? o.val[b + lane] : 0.0;
+        for (uint32_t base = b; base < e && !fits; base += 64) {
             const double v = vnext;
             const uint32_t kn = base + 64 + lane;
             vnext = kn < e ? o.val[kn] : 0.0;
@@ -1009,7 +1034,8 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
         __syncthreads();
         for (int q = 0; q < ncls; ++q) {
             const double mul = s_mul[q];
-            for (uint32_t k = eb + s_start[q] + tid; k < eb + s_start[q + 1]; k += T) o.val[k] = mul * o.val[k];
+            if (fits) { for (uint32_t k = s_start[q] + tid; k < s_start[q + 1]; k += T) o.val[eb + k] = mul * s_vals[k]; }
+            else for (uint32_t k = eb + s_start[q] + tid; k < eb + s_start[q + 1]; k += T) o.val[k] = mul * o.val[k];
         }
     }
 #ifdef FA_TIMELINE
