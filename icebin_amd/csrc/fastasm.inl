@@ -250,6 +250,7 @@ struct FaG {
     uint32_t *r_ncls, *r_nent;  // [nAr]
     uint32_t *gbase, *ebase;    // [nAr+1] exclusive scans of r_ncls / r_nent
     int64_t *to_sparse;         // numbered by this build: dense -> sparse
+    int32_t *tab_out;           // ... and, small grids, sparse -> dense for the builds of the step that will find the set populated
 };
 struct FaP {
     int key, list;              // KEY_I / KEY_X, LIST_I / LIST_AP / LIST_EP
@@ -350,6 +351,8 @@ struct FaChain {
     uint32_t *tot;                  // [3]: new P keys, classes, entries of the whole grid (the counters read back by the host)
     uint32_t *zero;                 // words a later kernel of the build wants cleared (a hipMemsetAsync of an odd size is TWO launches)
     unsigned nzero;
+    int32_t *fill_m1;               // words to set to -1 (the sparse -> dense table of the G set, FaG::tab_out)
+    unsigned nfill;
 };
 constexpr int FA_CH_NP = 21, FA_CH_NE = 22, FA_CH_NC = 15;
 // Exclusive prefix of `mine` (<= 58 bits, fields that cannot overflow) over the workgroups before r; every thread of the workgroup
@@ -404,6 +407,8 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
     const bool chained = ch.status != nullptr, prank = chained && p.fresh;
     if (chained && ch.zero)
         for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nzero; i += gridDim.x * T) ch.zero[i] = 0u;
+    if (chained && ch.fill_m1)
+        for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nfill; i += gridDim.x * T) ch.fill_m1[i] = -1;
     const bool one_pass = x1 - x0 <= (long)T * CPT;         // then the ranks wait in registers for the keys before the range
     uint32_t pv[CPT];
 #pragma unroll
@@ -1028,6 +1033,7 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
             const int gd = fa_gdense(g, r, cls, gkey);
             if (gd < 0) continue;                               // a key the pre-populated set lacks: the build is discarded (FA_ERR_MISSING)
             if (g.to_sparse) g.to_sparse[gd] = gkey;            // a set numbered by this build: dense -> sparse
+            if (g.tab_out) g.tab_out[gkey] = gd;
             if (EMIT) {                                        // FAM_AEVI rows (RegridMatrices_Dynamic.cpp:100-146)
                 double wM, mul = 1.0;
                 if (o.correctA) {
@@ -1580,7 +1586,15 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     if (chained) {
         FaChainState &cs = fa_chain_state();
         d_cnt = cs.counters(st);
-        chain = FaChain{cs.words((size_t)nAr, st), cs.epoch, d_cnt + 2, nullptr, 0u};
+        chain = FaChain{cs.words((size_t)nAr, st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u};
+        // a fresh E set: the step's later builds (IvE, XvE on the dimE this EvI numbers: IceCoupler.cpp:361-377) look keys up in the
+        // sparse -> dense table -- written here as the set is numbered instead of by two launches and a synchronisation later
+        if (g_fresh && gkey == KEY_E && gext < (1l << 22) && get_tuning("assemble_tab_out", 1)) {
+            gset->tab_n = -1;
+            gset->tab.alloc((size_t)gext);
+            chain.fill_m1 = gset->tab.p; chain.nfill = (unsigned)gext;
+            g.tab_out = gset->tab.p;
+        }
         // what the later kernels want cleared, by the upper bounds the outputs are allocated with below
         const size_t np_ub = p.fresh ? (size_t)std::min<int64_t>(extent_of(pkey), nX) : (size_t)extent_of(pkey);
         if (g_is_row && !p.fresh && np_ub) {                    // Mw of an identity P set: members without entries stay 0
@@ -1720,6 +1734,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     // its extent is written only when it changes)
     if (p.fresh) commit(pset, extent_of(pkey), ptable, np_d); else if (pset->sparse_extent != extent_of(pkey)) pset->sparse_extent = extent_of(pkey);
     if (g_fresh) commit(gset, gext, gtable, ng_d); else if (gset->sparse_extent != gext) gset->sparse_extent = gext;
+    if (g.tab_out) { gset->tab_n = gset->n; gset->tab_extent = gext; }
     IBH_HIP(hipStreamSynchronize(st));
     return true;
 }
