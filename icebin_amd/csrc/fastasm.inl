@@ -27,6 +27,9 @@
 // the results are bit-identical; the general pipeline remains the fallback for unsorted grids,
 // partially pre-populated dims, EvA / AvE on pre-populated sets, and anything a limit below excludes.
 // EvA / AvE on fresh sets: fast_build_eva (count -> range sums -> one thread per range).
+// Small grids (<= 2^20 exchange cells, round 5): the scans after k_fa_count ride IN it (FaChain: decoupled look-back over the
+// ranges), the counters come from a ring of initialised slots and go back to the host from the build's last kernel
+// (fa_publish) -- a G-row build is k_fa_count -> k_fa_range -> k_fa_pelem<SUMS>, three launches.
 
 constexpr int FA_NC = 64;           // elevation classes per range (nhc <= 64)
 constexpr int FA_ILMAX = 8;         // exchange cells per ice cell
