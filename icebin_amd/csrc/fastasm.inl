@@ -1086,6 +1086,13 @@ template <bool WITH_EP, int MODE, bool ANYORDER>
 __device__ __forceinline__ void fa_pelem_body(RgView rg, const PlanView &pl, const MatSpec &s, const FaG &g, const FaP &p, int merge, long np, const FaOut &o,
                                               uint32_t *__restrict__ rowlen, uint32_t *__restrict__ flags, int only_multi) {
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+#ifdef FA_TIMELINE
+    const long wid_tl = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    auto PSTAMP = [&](int i) { if (MODE == FA_PEMIT && o.dbg) { const long long t = (long long)__builtin_amdgcn_s_memtime(); o.dbg[wid_tl * 8 + i] = t; } };
+#else
+    auto PSTAMP = [&](int) {};
+#endif
+    PSTAMP(0);
     stage_hc<WITH_EP>(rg, s_hc);
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= np) return;
@@ -1110,6 +1117,7 @@ __device__ __forceinline__ void fa_pelem_body(RgView rg, const PlanView &pl, con
     }
     if (d < 0) return;
     (void)flags;
+    PSTAMP(1);
     if (MODE == FA_PCOUNT && p.key == KEY_I && pl.icnt_pos) {
         // entries of an ice cell's row: one per group of duplicate exchange cells that contributes, times the elevation
         // classes its elevation lies between -- the groups are static (plan), the classes a function of the mask value
@@ -1145,6 +1153,8 @@ __device__ __forceinline__ void fa_pelem_body(RgView rg, const PlanView &pl, con
                                 ? make_cell<false>(rg, 0, q, (fx & 8) ? 1.0 : (fx & 16) ? -1.0 : 0.0, e)
                             : (!WITH_EP && MODE == FA_PSUMS && p.key == KEY_I && !g.tab)
                                 ? make_cell<false>(rg, 0, q, rg.area[x], e)
+                            : p.key == KEY_I                               // (the ice cell is this element, its mask value is in hand:
+                                ? make_cell<WITH_EP>(rg, rg.exi[2 * x], q, rg.area[x], e)      //  no gather behind the cell's indices)
                                 : load_cell<WITH_EP>(rg, x);
             if (WITH_EP && c.range_error) continue;
             GEnt ge;
@@ -1161,7 +1171,13 @@ __device__ __forceinline__ void fa_pelem_body(RgView rg, const PlanView &pl, con
     // EMIT with columns that ascend (known, or found so by the first visit): the first FA_KEEP entries of the row are parked in LDS (a private slot per thread, no
     // registers), so a row of that many entries -- an ice cell under one or two GCM cells: ~99 % of them -- is written after ONE
     // visit of its exchange cells instead of two (row sum first, scaled values second)
-    constexpr int FA_KEEP = 4;
+    const int b0 = MODE == FA_PEMIT ? o.rowptr[d] : 0;          // (asked for before the visit: the round trip overlaps it)
+    // (elevation classes: two entries per exchange cell -- an ice cell under three GCM cells has six; the waves that held one were
+    // the tail of this kernel at 5 km, 71 k cycles against a median of 21 k: they visited their cells twice)
+#ifndef FA_KEEP_EP
+#define FA_KEEP_EP 8
+#endif
+    constexpr int FA_KEEP = WITH_EP ? FA_KEEP_EP : 4;
     constexpr bool KEEP = MODE == FA_PEMIT;
     __shared__ double s_kt[KEEP ? FA_KEEP : 1][KEEP ? FA_T : 1];
     __shared__ int s_kid[KEEP ? FA_KEEP : 1][KEEP ? FA_T : 1], s_ka[KEEP ? FA_KEEP : 1][KEEP ? FA_T : 1];
@@ -1169,11 +1185,11 @@ __device__ __forceinline__ void fa_pelem_body(RgView rg, const PlanView &pl, con
         if (KEEP && ne < FA_KEEP) { s_kt[ne][threadIdx.x] = t; s_kid[ne][threadIdx.x] = id; s_ka[ne][threadIdx.x] = (int)iA; }
         ++ne; sum = sum + t; sorted = sorted && id >= prev; prev = id;
     });
+    PSTAMP(2);
     if (MODE == FA_PCOUNT) { rowlen[d] = (uint32_t)ne; return; }
     if (MODE == FA_PSUMS) { o.Mw[d] = sum; return; }          // FAM_AEVI: Mw = colsum (:100); G numbered by this build: in order
     // FAM_IVAE rows: wM = rowsum, M = [1/wM] * T [* sApvA]
     if (p.fresh) p.to_sparse[d] = pkey;
-    const int b0 = o.rowptr[d];
     auto finish = [&](double t, long iA) {
         double v = t;
         if (o.scale) v = (1.0 / sum) * v;
@@ -1211,6 +1227,7 @@ __device__ __forceinline__ void fa_pelem_body(RgView rg, const PlanView &pl, con
             last = best;
         }
     }
+    PSTAMP(3);
 }
 template <bool WITH_EP, int MODE, bool ANYORDER>
 __global__ __launch_bounds__(FA_T, (WITH_EP && MODE == 2) ? (ANYORDER ? 1 : 6) : 8) void k_fa_pelem(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, long np, FaOut o,
