@@ -159,6 +159,20 @@ __device__ __forceinline__ XCell make_cell(const RgView &rg, long iA, long iI, d
     }
     return c;
 }
+// the class search of make_cell for one elevation, to be handed back to it as `hint` by a caller that evaluates several exchange
+// cells of the same ice cell
+__device__ __forceinline__ int cell_hint(const RgView &rg, double e) {
+    if (e != e || rg.nhc < 1) return -1;
+    const double elevation = e < 0.0 ? 0.0 : e;
+    const int i1 = dev_lower_bound(rg.hc, rg.nhc, elevation);
+    if (rg.interp == 0) return i1;
+    const int n = rg.nhc;
+    if (i1 <= 0) return 0;
+    if (i1 >= n) return n - 1;
+    const int i0 = i1 - 1;
+    const double d0 = fabs(elevation - rg.hc[i0]), d1 = fabs(rg.hc[i1] - elevation);
+    return d0 <= d1 ? i0 : i1;
+}
 template <bool WITH_EP>
 __device__ __forceinline__ XCell load_cell(const RgView &rg, long x) {
     const long iA = rg.exi[2 * x], iI = rg.exi[2 * x + 1];

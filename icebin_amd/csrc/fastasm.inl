@@ -1132,6 +1132,7 @@ __device__ __forceinline__ void fa_pelem_body(RgView rg, const PlanView &pl, con
         return;
     }
     const bool g_is_row = MODE == FA_PSUMS;                  // SUMS: the matrix has G rows (AEvI); COUNT / EMIT: G columns (IvAE)
+    const int hint = (WITH_EP && p.key == KEY_I) ? cell_hint(rg, e) : -1;      // (every cell of an ice cell has its elevation)
     // The element's entries are visited group by group (ascending x = ascending range = ascending G dense id when
     // the G set was numbered by this build; inside a group the two classes go by their rank).  No private arrays:
     // the cells are simply re-evaluated by every pass (they are in cache).
@@ -1154,7 +1155,7 @@ __device__ __forceinline__ void fa_pelem_body(RgView rg, const PlanView &pl, con
                             : (!WITH_EP && MODE == FA_PSUMS && p.key == KEY_I && !g.tab)
                                 ? make_cell<false>(rg, 0, q, rg.area[x], e)
                             : p.key == KEY_I                               // (the ice cell is this element, its mask value is in hand:
-                                ? make_cell<WITH_EP>(rg, rg.exi[2 * x], q, rg.area[x], e)      //  no gather behind the cell's indices)
+                                ? make_cell<WITH_EP>(rg, rg.exi[2 * x], q, rg.area[x], e, hint)      //  no gather behind the cell's indices, one class search)
                                 : load_cell<WITH_EP>(rg, x);
             if (WITH_EP && c.range_error) continue;
             GEnt ge;
