@@ -1236,6 +1236,62 @@ __global__ __launch_bounds__(FA_T, (WITH_EP && MODE == 2) ? (ANYORDER ? 1 : 6) :
     fa_pelem_body<WITH_EP, MODE, ANYORDER>(rg, pl, s, g, p, merge, np, o, rowlen, flags, only_multi);
     if (MODE == FA_PSUMS) fa_publish(o);
 }
+// Mw of the ice cells with several exchange cells (k_fa_pelem<SUMS>'s job), EIGHT lanes per ice cell: every lane evaluates one of
+// the cell's <= 8 exchange cells, lane 0 of the group then adds the terms in the element's order (cells ascending, the two classes
+// of a cell by their dense ids) -- the same sequence of additions.  One thread per ice cell walked its cells one after the other,
+// ~4 k cycles each; with 13 k such ice cells at 5 km the kernel was a few workgroups waiting for their 8-cell lanes (EvI: 16 us).
+template <bool WITH_EP>
+__global__ __launch_bounds__(FA_T) void k_fa_psums8(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, long np, FaOut o) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    stage_hc<WITH_EP>(rg, s_hc);
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long el = t >> 3;
+    const int j = (int)(t & 7), lane = threadIdx.x & 63, base = lane & ~7;
+    int d = -1, lb = 0, le = 0;
+    long q = 0;
+    double e = 0.0;
+    if (el < np) {
+        q = pl.mlist[el];
+        e = rg.em[q];
+        const bool masked = e != e;
+        if (!(masked && p.fresh)) {                          // (a masked cell is no member of a set numbered by this build)
+            const int f = pl.ifirst[q];
+            if (!p.fresh) d = (int)q;
+            else if (f >= 0) d = (int)fa_poff_at(p.poff, p.Pw, p.pbits, f);
+            if (!masked) { lb = pl.ilptr[q]; le = pl.ilptr[q + 1]; }
+        }
+    }
+    double ta = 0.0, tb = 0.0;
+    int n = 0;
+    if (d >= 0 && lb + j < le) {
+        const long x = pl.ilist[lb + j];
+        const unsigned fx = pl.isdup[x];
+        if (!(merge && (fx & 1))) {
+            const XCell c = make_cell<WITH_EP>(rg, rg.exi[2 * x], q, rg.area[x], e);
+            if (!(WITH_EP && c.range_error)) {
+                GEnt ge;
+                fa_group<WITH_EP>(rg, pl, s, true, merge != 0 && (fx & 128), c, x, ge);
+                if (ge.n > 0) {
+                    const int r = pl.aidx[x];
+                    const int id0 = fa_gdense(g, r, ge.cls0, ge.gkey0);
+                    const int id1 = ge.n < 2 ? 0 : fa_gdense(g, r, ge.cls1, ge.gkey1);
+                    n = ge.n;
+                    if (ge.n == 1 || id0 <= id1) { ta = ge.t0; tb = ge.t1; } else { ta = ge.t1; tb = ge.t0; }
+                }
+            }
+        }
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                            // (every lane of the group forms the same sum; lane 0 stores it)
+        const int nk = __shfl(n, base + k, 64);
+        const double ak = __shfl(ta, base + k, 64), bk = __shfl(tb, base + k, 64);
+        if (nk >= 1) sum = sum + ak;
+        if (nk == 2) sum = sum + bk;
+    }
+    if (j == 0 && d >= 0) o.Mw[d] = sum;
+    fa_publish(o);
+}
 __global__ void k_fa_zero_identity(double *__restrict__ w, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) w[i] = 0.0;
@@ -1708,7 +1764,11 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         else FA_LAUNCH_RANGE(false, true, rg, pl, *sp, g, p, merge, (sums_after ? o : ol), flags);
         if (sums_after) {                                     // Mw of the ice cells that straddle ranges (a few %)
             const dim3 gm(ceil_div(P.nmulti, T));
-            if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, ol, (uint32_t *)nullptr, flags, 0);
+            if (P.nmulti <= (1l << 20) && get_tuning("assemble_psums8", 1)) {     // few of them: eight lanes per ice cell
+                const dim3 g8(ceil_div(8 * (long)P.nmulti, T));
+                if (uses_ep) hipLaunchKernelGGL((k_fa_psums8<true>), g8, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, ol);
+                else hipLaunchKernelGGL((k_fa_psums8<false>), g8, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, ol);
+            } else if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, ol, (uint32_t *)nullptr, flags, 0);
             else hipLaunchKernelGGL((k_fa_pelem<false, FA_PSUMS, false>), gm, dim3(T), 0, st, rg, pl, *sp, g, p, merge, (long)P.nmulti, ol, (uint32_t *)nullptr, flags, 0);
         }
     } else {

@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 root=$(pwd); out=$root/gpurun_out/r05s35; mkdir -p $out
 cd /tmp
-for m in AvI EvI IvE; do
+for m in EvI IvE; do
 rocprofv3 --kernel-trace --output-format csv -d $out/$m -- python3 $root/scratch/r05/build_trace.py g5 $m > $out/$m.log 2>&1
 python3 - $out/$m > $out/$m.trace.txt <<'PY'
 import csv, glob, re, sys
