@@ -356,6 +356,8 @@ struct FaChain {
     unsigned nzero;
     int32_t *fill_m1;               // words to set to -1 (the sparse -> dense table of the G set, FaG::tab_out)
     unsigned nfill;
+    uint32_t *zero2;                // a second array to clear (Mw over a pre-populated column set: columns this mask does not touch)
+    unsigned nzero2;
 };
 constexpr int FA_CH_NP = 21, FA_CH_NE = 22, FA_CH_NC = 15;
 // Exclusive prefix of `mine` (<= 58 bits, fields that cannot overflow) over the workgroups before r; every thread of the workgroup
@@ -412,6 +414,8 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
         for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nzero; i += gridDim.x * T) ch.zero[i] = 0u;
     if (chained && ch.fill_m1)
         for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nfill; i += gridDim.x * T) ch.fill_m1[i] = -1;
+    if (chained && ch.zero2)
+        for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nzero2; i += gridDim.x * T) ch.zero2[i] = 0u;
     const bool one_pass = x1 - x0 <= (long)T * CPT;         // then the ranks wait in registers for the keys before the range
     uint32_t pv[CPT];
 #pragma unroll
@@ -1663,7 +1667,11 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     if (chained) {
         FaChainState &cs = fa_chain_state();
         d_cnt = cs.counters(st);
-        chain = FaChain{cs.words((size_t)nAr, st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u};
+        chain = FaChain{cs.words((size_t)nAr, st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u, nullptr, 0u};
+        if (!g_is_row && !g_fresh && gset->n > 0) {             // (what k_fa_zero_identity did in a launch of its own)
+            w->Mw.alloc((size_t)gset->n);
+            chain.zero2 = reinterpret_cast<uint32_t *>(w->Mw.p); chain.nzero2 = 2u * (unsigned)gset->n;
+        }
         // a fresh E set: the step's later builds (IvE, XvE on the dimE this EvI numbers: IceCoupler.cpp:361-377) look keys up in the
         // sparse -> dense table -- written here as the set is numbered instead of by two launches and a synchronisation later
         if (g_fresh && gkey == KEY_E && gext < (1l << 22) && get_tuning("assemble_tab_out", 1)) {
@@ -1789,7 +1797,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         FaOut os = o;
         os.val = A.get<double>(nnz);
         if (can_publish) { fa_chain_state().publish_into(os, d_cnt, st); published = true; }
-        if (!g_fresh && ncol) hipLaunchKernelGGL(k_fa_zero_identity, dim3(ceil_div(ncol, T)), dim3(T), 0, st, w->Mw.p, (long)ncol);   // columns of the shared set this mask does not touch
+        if (!g_fresh && ncol && !chain.zero2) hipLaunchKernelGGL(k_fa_zero_identity, dim3(ceil_div(ncol, T)), dim3(T), 0, st, w->Mw.p, (long)ncol);   // columns of the shared set this mask does not touch
         if (uses_ep) FA_LAUNCH_RANGE(true, false, rg, pl, *sp, g, p, merge, os, flags);
         else FA_LAUNCH_RANGE(false, false, rg, pl, *sp, g, p, merge, os, flags);
     }
