@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-root=$(pwd); out=$root/gpurun_out/r05s35; mkdir -p $out
+root=$(pwd); out=$root/gpurun_out/r05build; mkdir -p $out
 cd /tmp
 for m in EvI IvE; do
 rocprofv3 --kernel-trace --output-format csv -d $out/$m -- python3 $root/scratch/r05/build_trace.py g5 $m > $out/$m.log 2>&1

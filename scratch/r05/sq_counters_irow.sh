@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-root=$(pwd); out=$root/gpurun_out/r05s24; mkdir -p $out
+root=$(pwd); out=$root/gpurun_out/r05sq; mkdir -p $out
 cd /tmp
 for m in IvE IvA; do
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD --output-format csv -d $out/p1$m -- python3 $root/scratch/kernel_choice.py a1h $m 128 auto > $out/p1$m.log 2>&1
