@@ -755,6 +755,10 @@ struct FaOut {
     uint32_t *pub_ticket;
     const uint32_t *pub_src;
     uint32_t *pub_dst;
+    // k_fa_range<EMIT> of a small build also carries the workgroups of k_fa_psums8 (blocks psums_first ..: the two are independent,
+    // neither fills the chip, and a launch of its own costs what the work does)
+    int psums_first;
+    long psums_n;
 #ifdef FA_TIMELINE
     long long *dbg;                 // scratch/r05/range_timeline.py: 8 stamps per range from thread 0
 #endif
@@ -779,6 +783,67 @@ __device__ __forceinline__ void fa_publish(const FaOut &o) {
 #else
 #define FA_STAMP(i) do { } while (0)
 #endif
+// Mw of the ice cells with several exchange cells (k_fa_pelem<SUMS>'s job), EIGHT lanes per ice cell: every lane evaluates one of
+// the cell's <= 8 exchange cells, lane 0 of the group then adds the terms in the element's order (cells ascending, the two classes
+// of a cell by their dense ids) -- the same sequence of additions.  One thread per ice cell walked its cells one after the other,
+// ~4 k cycles each; with 13 k such ice cells at 5 km the kernel was a few workgroups waiting for their 8-cell lanes (EvI: 16 us).
+template <bool WITH_EP>
+__device__ __forceinline__ void fa_psums8_body(const RgView &rg, const PlanView &pl, const MatSpec &s, const FaG &g, const FaP &p, int merge, long np, const FaOut &o,
+                                               int first_block) {
+    const long t = (long)((int)blockIdx.x - first_block) * blockDim.x + threadIdx.x;
+    const long el = t >> 3;
+    const int j = (int)(t & 7), lane = threadIdx.x & 63, base = lane & ~7;
+    int d = -1, lb = 0, le = 0;
+    long q = 0;
+    double e = 0.0;
+    if (el < np) {
+        q = pl.mlist[el];
+        e = rg.em[q];
+        const bool masked = e != e;
+        if (!(masked && p.fresh)) {                          // (a masked cell is no member of a set numbered by this build)
+            const int f = pl.ifirst[q];
+            if (!p.fresh) d = (int)q;
+            else if (f >= 0) d = (int)fa_poff_at(p.poff, p.Pw, p.pbits, f);
+            if (!masked) { lb = pl.ilptr[q]; le = pl.ilptr[q + 1]; }
+        }
+    }
+    double ta = 0.0, tb = 0.0;
+    int n = 0;
+    if (d >= 0 && lb + j < le) {
+        const long x = pl.ilist[lb + j];
+        const unsigned fx = pl.isdup[x];
+        if (!(merge && (fx & 1))) {
+            const XCell c = make_cell<WITH_EP>(rg, rg.exi[2 * x], q, rg.area[x], e);
+            if (!(WITH_EP && c.range_error)) {
+                GEnt ge;
+                fa_group<WITH_EP>(rg, pl, s, true, merge != 0 && (fx & 128), c, x, ge);
+                if (ge.n > 0) {
+                    const int r = pl.aidx[x];
+                    const int id0 = fa_gdense(g, r, ge.cls0, ge.gkey0);
+                    const int id1 = ge.n < 2 ? 0 : fa_gdense(g, r, ge.cls1, ge.gkey1);
+                    n = ge.n;
+                    if (ge.n == 1 || id0 <= id1) { ta = ge.t0; tb = ge.t1; } else { ta = ge.t1; tb = ge.t0; }
+                }
+            }
+        }
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                            // (every lane of the group forms the same sum; lane 0 stores it)
+        const int nk = __shfl(n, base + k, 64);
+        const double ak = __shfl(ta, base + k, 64), bk = __shfl(tb, base + k, 64);
+        if (nk >= 1) sum = sum + ak;
+        if (nk == 2) sum = sum + bk;
+    }
+    if (j == 0 && d >= 0) o.Mw[d] = sum;
+}
+template <bool WITH_EP>
+__global__ __launch_bounds__(FA_T) void k_fa_psums8(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, long np, FaOut o) {
+    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
+    stage_hc<WITH_EP>(rg, s_hc);
+    fa_psums8_body<WITH_EP>(rg, pl, s, g, p, merge, np, o, 0);
+    fa_publish(o);
+}
 template <bool WITH_EP, bool EMIT, int T, int CPT>
 __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, FaOut o,
                                                     uint32_t *__restrict__ flags) {
@@ -795,6 +860,11 @@ __global__ __launch_bounds__(T, (T == 128 && !WITH_EP) ? 6 : 1) void k_fa_range(
     __shared__ int o_cls[FA_OLDMAX], o_did[FA_OLDMAX];
     __shared__ double o_t[FA_OLDMAX];
     stage_hc<WITH_EP>(rg, s_hc);
+    if (EMIT && o.psums_n > 0 && (int)blockIdx.x >= o.psums_first) {          // (uniform: this workgroup serves the straddling ice cells)
+        fa_psums8_body<WITH_EP>(rg, pl, s, g, p, merge, o.psums_n, o, o.psums_first);
+        fa_publish(o);
+        return;
+    }
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef FA_TIMELINE
     long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1240,62 +1310,6 @@ __global__ __launch_bounds__(FA_T, (WITH_EP && MODE == 2) ? (ANYORDER ? 1 : 6) :
     fa_pelem_body<WITH_EP, MODE, ANYORDER>(rg, pl, s, g, p, merge, np, o, rowlen, flags, only_multi);
     if (MODE == FA_PSUMS) fa_publish(o);
 }
-// Mw of the ice cells with several exchange cells (k_fa_pelem<SUMS>'s job), EIGHT lanes per ice cell: every lane evaluates one of
-// the cell's <= 8 exchange cells, lane 0 of the group then adds the terms in the element's order (cells ascending, the two classes
-// of a cell by their dense ids) -- the same sequence of additions.  One thread per ice cell walked its cells one after the other,
-// ~4 k cycles each; with 13 k such ice cells at 5 km the kernel was a few workgroups waiting for their 8-cell lanes (EvI: 16 us).
-template <bool WITH_EP>
-__global__ __launch_bounds__(FA_T) void k_fa_psums8(RgView rg, PlanView pl, MatSpec s, FaG g, FaP p, int merge, long np, FaOut o) {
-    __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
-    stage_hc<WITH_EP>(rg, s_hc);
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long el = t >> 3;
-    const int j = (int)(t & 7), lane = threadIdx.x & 63, base = lane & ~7;
-    int d = -1, lb = 0, le = 0;
-    long q = 0;
-    double e = 0.0;
-    if (el < np) {
-        q = pl.mlist[el];
-        e = rg.em[q];
-        const bool masked = e != e;
-        if (!(masked && p.fresh)) {                          // (a masked cell is no member of a set numbered by this build)
-            const int f = pl.ifirst[q];
-            if (!p.fresh) d = (int)q;
-            else if (f >= 0) d = (int)fa_poff_at(p.poff, p.Pw, p.pbits, f);
-            if (!masked) { lb = pl.ilptr[q]; le = pl.ilptr[q + 1]; }
-        }
-    }
-    double ta = 0.0, tb = 0.0;
-    int n = 0;
-    if (d >= 0 && lb + j < le) {
-        const long x = pl.ilist[lb + j];
-        const unsigned fx = pl.isdup[x];
-        if (!(merge && (fx & 1))) {
-            const XCell c = make_cell<WITH_EP>(rg, rg.exi[2 * x], q, rg.area[x], e);
-            if (!(WITH_EP && c.range_error)) {
-                GEnt ge;
-                fa_group<WITH_EP>(rg, pl, s, true, merge != 0 && (fx & 128), c, x, ge);
-                if (ge.n > 0) {
-                    const int r = pl.aidx[x];
-                    const int id0 = fa_gdense(g, r, ge.cls0, ge.gkey0);
-                    const int id1 = ge.n < 2 ? 0 : fa_gdense(g, r, ge.cls1, ge.gkey1);
-                    n = ge.n;
-                    if (ge.n == 1 || id0 <= id1) { ta = ge.t0; tb = ge.t1; } else { ta = ge.t1; tb = ge.t0; }
-                }
-            }
-        }
-    }
-    double sum = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {                            // (every lane of the group forms the same sum; lane 0 stores it)
-        const int nk = __shfl(n, base + k, 64);
-        const double ak = __shfl(ta, base + k, 64), bk = __shfl(tb, base + k, 64);
-        if (nk >= 1) sum = sum + ak;
-        if (nk == 2) sum = sum + bk;
-    }
-    if (j == 0 && d >= 0) o.Mw[d] = sum;
-    fa_publish(o);
-}
 __global__ void k_fa_zero_identity(double *__restrict__ w, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) w[i] = 0.0;
@@ -1362,10 +1376,10 @@ static int fa_range_shape(long nX, int nAr) {
     } while (0)
 #define FA_LAUNCH_RANGE(EP, EM, ...)                                                                                    \
     do {                                                                                                                \
-        if (fa_shape == 0) hipLaunchKernelGGL((k_fa_range<EP, EM, 128, 2>), dim3(nAr), dim3(128), 0, st, __VA_ARGS__);  \
-        else if (fa_shape == 2) hipLaunchKernelGGL((k_fa_range<EP, EM, 1024, 4>), dim3(nAr), dim3(1024), 0, st, __VA_ARGS__); \
-        else if (fa_shape == 3) hipLaunchKernelGGL((k_fa_range<EP, EM, 1024, 1>), dim3(nAr), dim3(1024), 0, st, __VA_ARGS__); \
-        else hipLaunchKernelGGL((k_fa_range<EP, EM, 256, 4>), dim3(nAr), dim3(256), 0, st, __VA_ARGS__);                \
+        if (fa_shape == 0) hipLaunchKernelGGL((k_fa_range<EP, EM, 128, 2>), dim3(nAr + range_extra), dim3(128), 0, st, __VA_ARGS__);  \
+        else if (fa_shape == 2) hipLaunchKernelGGL((k_fa_range<EP, EM, 1024, 4>), dim3(nAr + range_extra), dim3(1024), 0, st, __VA_ARGS__); \
+        else if (fa_shape == 3) hipLaunchKernelGGL((k_fa_range<EP, EM, 1024, 1>), dim3(nAr + range_extra), dim3(1024), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((k_fa_range<EP, EM, 256, 4>), dim3(nAr + range_extra), dim3(256), 0, st, __VA_ARGS__);                \
     } while (0)
 
 // ---- EvA / AvE (compute_EvA, RegridMatrices_Dynamic.cpp:254-332) -----------------------------------------------
@@ -1504,6 +1518,7 @@ static bool fast_build_eva(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh
     if (nE) {
         // T[e]: the terms go to their (class, x-order) slot of a scratch array, one wave per class adds them up in sequence
         FaOut os{nullptr, nullptr, A.get<double>(nterm), nullptr, S, sp->family, 0, 0, e_is_row ? 1 : 0};
+        const int range_extra = 0;
         FA_LAUNCH_RANGE(true, false, rg, pl, *sp, g, p, 0, os, flags);
         EvaOut eo{w->rowptr.p, w->colind.p, row, w->val.p, rs, cs, atable.p};
         hipLaunchKernelGGL(k_eva_final, dim3(ceil_div(nAr, T)), dim3(T), 0, st, rg, pl, g, abase, S, e_is_row ? 1 : 0, eo, flags);
@@ -1758,6 +1773,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
 #endif
     uint32_t *flags = d_cnt + 1;
     const bool can_publish = chained && get_tuning("assemble_publish", 1);     // (chained => optimistic: the counters are read once, at the end)
+    int range_extra = 0;                                        // workgroups of k_fa_range that do k_fa_psums8's work
     const long np_s = p.key == KEY_I ? gr->nI : nX;             // P elements by sparse index
     const dim3 gp(ceil_div(np_s, T));
     if (g_is_row) {
@@ -1765,11 +1781,19 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         // (a set numbered by this build: every member's Mw is written by k_fa_range / k_fa_pelem<SUMS>; an identity set has
         // non-members -- masked cells -- whose Mw stays 0)
         if (ncol && !p.fresh && !chain.zero) IBH_HIP(hipMemsetAsync(w->Mw.p, 0, sizeof(double) * (size_t)ncol, st));
-        const bool sums_after = p.key == KEY_I && P.nmulti;
+        bool sums_after = p.key == KEY_I && P.nmulti;
         FaOut ol = o;                                         // (the build's last kernel publishes the counters)
         if (can_publish) { fa_chain_state().publish_into(ol, d_cnt, st); published = true; }
+        if (sums_after && chained && P.nmulti <= (1l << 20) && get_tuning("assemble_psums8", 1) && get_tuning("assemble_psums_inrange", 1)) {
+            // small grids: the straddlers' Mw in extra workgroups of the range kernel's own launch
+            const int tshape = fa_shape == 0 ? 128 : fa_shape == 1 ? 256 : 1024;
+            range_extra = ceil_div(8 * (long)P.nmulti, tshape);
+            ol.psums_first = nAr; ol.psums_n = (long)P.nmulti;
+            sums_after = false;
+        }
         if (uses_ep) FA_LAUNCH_RANGE(true, true, rg, pl, *sp, g, p, merge, (sums_after ? o : ol), flags);
         else FA_LAUNCH_RANGE(false, true, rg, pl, *sp, g, p, merge, (sums_after ? o : ol), flags);
+        range_extra = 0;
         if (sums_after) {                                     // Mw of the ice cells that straddle ranges (a few %)
             const dim3 gm(ceil_div(P.nmulti, T));
             if (P.nmulti <= (1l << 20) && get_tuning("assemble_psums8", 1)) {     // few of them: eight lanes per ice cell
