@@ -358,7 +358,26 @@ struct FaChain {
     unsigned nfill;
     uint32_t *zero2;                // a second array to clear (Mw over a pre-populated column set: columns this mask does not touch)
     unsigned nzero2;
+    // I-row builds on the identity ice set: the row lengths (k_fa_pelem<COUNT>'s static form) do not depend on this kernel's results,
+    // so the workgroups pc_first .. of ITS launch compute them -- one launch fewer in the coupler's IvE
+    uint32_t *pc_rowlen;
+    long pc_n;
+    int pc_first;
 };
+// entries of the row of ice cell q, identity ice set, from the plan's static counts (k_fa_pelem<COUNT>, first branch)
+template <bool WITH_EP>
+__device__ __forceinline__ void fa_pcount_static(const RgView &rg, const PlanView &pl, long q, long np, uint32_t *__restrict__ rowlen) {
+    if (q >= np) return;
+    const double e = rg.em[q];
+    uint32_t n = 0;
+    if (!(e != e)) {
+        if (WITH_EP) {
+            const XCell c = make_cell<WITH_EP>(rg, 0, q, 1.0, e);
+            n = c.range_error ? 0u : (uint32_t)c.nep * pl.icnt_nz[q];
+        } else n = pl.icnt_pos[q];
+    }
+    rowlen[q] = n;
+}
 constexpr int FA_CH_NP = 21, FA_CH_NE = 22, FA_CH_NC = 15;
 // Exclusive prefix of `mine` (<= 58 bits, fields that cannot overflow) over the workgroups before r; every thread of the workgroup
 // calls it and gets the same value.  One round looks at T predecessors at once -- at 5 km every range sees all the others in one.
@@ -404,11 +423,6 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
     __shared__ unsigned long long s_part[T / 64];
     __shared__ int s_flag[T / 64];
     stage_hc<WITH_EP>(rg, s_hc);
-    const int r = blockIdx.x;
-    const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
-    const int iA_r = rg.exi[2 * x0];                          // the atmosphere cell of the whole range
-    if (threadIdx.x < FA_NC) { s_first[threadIdx.x] = 0xffffffffu; s_cn[threadIdx.x] = 0; s_co[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) s_runp = 0;
     const bool chained = ch.status != nullptr, prank = chained && p.fresh;
     if (chained && ch.zero)
         for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nzero; i += gridDim.x * T) ch.zero[i] = 0u;
@@ -416,6 +430,15 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
         for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nfill; i += gridDim.x * T) ch.fill_m1[i] = -1;
     if (chained && ch.zero2)
         for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nzero2; i += gridDim.x * T) ch.zero2[i] = 0u;
+    if (chained && ch.pc_rowlen && (int)blockIdx.x >= ch.pc_first) {          // (uniform: this workgroup counts row lengths)
+        fa_pcount_static<WITH_EP>(rg, pl, (long)((int)blockIdx.x - ch.pc_first) * T + threadIdx.x, ch.pc_n, ch.pc_rowlen);
+        return;
+    }
+    const int r = blockIdx.x;
+    const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
+    const int iA_r = rg.exi[2 * x0];                          // the atmosphere cell of the whole range
+    if (threadIdx.x < FA_NC) { s_first[threadIdx.x] = 0xffffffffu; s_cn[threadIdx.x] = 0; s_co[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) s_runp = 0;
     const bool one_pass = x1 - x0 <= (long)T * CPT;         // then the ranks wait in registers for the keys before the range
     uint32_t pv[CPT];
 #pragma unroll
@@ -538,7 +561,7 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
     if (threadIdx.x == 0) {
         g.gbase[r] = (uint32_t)(prefix >> (FA_CH_NP + FA_CH_NE));
         g.ebase[r] = (uint32_t)((prefix >> FA_CH_NP) & m22);
-        if (r == (int)gridDim.x - 1) {
+        if (r == pl.nAr - 1) {
             const unsigned long long t = prefix + mine;
             const uint32_t tc = (uint32_t)(t >> (FA_CH_NP + FA_CH_NE)), te = (uint32_t)((t >> FA_CH_NP) & m22);
             g.gbase[r + 1] = tc; g.ebase[r + 1] = te;
@@ -1369,10 +1392,10 @@ static int fa_range_shape(long nX, int nAr) {
 }
 #define FA_LAUNCH_COUNT(EP, ...)                                                                                        \
     do {                                                                                                                \
-        if (fa_shape == 0) hipLaunchKernelGGL((k_fa_count<EP, 128, 2>), dim3(nAr), dim3(128), 0, st, __VA_ARGS__);      \
-        else if (fa_shape == 2) hipLaunchKernelGGL((k_fa_count<EP, 1024, 4>), dim3(nAr), dim3(1024), 0, st, __VA_ARGS__); \
-        else if (fa_shape == 3) hipLaunchKernelGGL((k_fa_count<EP, 1024, 1>), dim3(nAr), dim3(1024), 0, st, __VA_ARGS__); \
-        else hipLaunchKernelGGL((k_fa_count<EP, 256, 4>), dim3(nAr), dim3(256), 0, st, __VA_ARGS__);                    \
+        if (fa_shape == 0) hipLaunchKernelGGL((k_fa_count<EP, 128, 2>), dim3(nAr + count_extra), dim3(128), 0, st, __VA_ARGS__);      \
+        else if (fa_shape == 2) hipLaunchKernelGGL((k_fa_count<EP, 1024, 4>), dim3(nAr + count_extra), dim3(1024), 0, st, __VA_ARGS__); \
+        else if (fa_shape == 3) hipLaunchKernelGGL((k_fa_count<EP, 1024, 1>), dim3(nAr + count_extra), dim3(1024), 0, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((k_fa_count<EP, 256, 4>), dim3(nAr + count_extra), dim3(256), 0, st, __VA_ARGS__);                    \
     } while (0)
 #define FA_LAUNCH_RANGE(EP, EM, ...)                                                                                    \
     do {                                                                                                                \
@@ -1468,6 +1491,7 @@ static bool fast_build_eva(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh
     uint32_t *d_cnt = A.get<uint32_t>(8);
     hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     const int fa_shape = fa_range_shape(nX, nAr);
+    const int count_extra = 0;
     FA_LAUNCH_COUNT(true, rg, pl, *sp, g, p, e_is_row ? 1 : 0, 0, d_cnt, d_cnt + 1, 1, FaChain{});
     if (nAr > 4096 && fa_rscan_many(g, nAr, abase, d_cnt + 3, d_cnt + 5, st)) {
         // (three short launches for the three channels)
@@ -1682,7 +1706,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     if (chained) {
         FaChainState &cs = fa_chain_state();
         d_cnt = cs.counters(st);
-        chain = FaChain{cs.words((size_t)nAr, st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u, nullptr, 0u};
+        chain = FaChain{cs.words((size_t)nAr, st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u, nullptr, 0u, nullptr, 0l, 0};
         if (!g_is_row && !g_fresh && gset->n > 0) {             // (what k_fa_zero_identity did in a launch of its own)
             w->Mw.alloc((size_t)gset->n);
             chain.zero2 = reinterpret_cast<uint32_t *>(w->Mw.p); chain.nzero2 = 2u * (unsigned)gset->n;
@@ -1710,6 +1734,14 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     }
     if (p.fresh) { p.pflag = A.get<uint8_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
     const int fa_shape = fa_range_shape(nX, nAr);
+    int count_extra = 0;                                        // workgroups of k_fa_count that count row lengths (FaChain::pc_*)
+    if (chained && !g_is_row && pkey == KEY_I && !p.fresh && pl.icnt_pos && get_tuning("assemble_pcount_incount", 1)) {
+        const long nrows = extent_of(pkey);
+        rowlen_early = A.get<uint32_t>((size_t)nrows + 1);
+        chain.pc_rowlen = rowlen_early; chain.pc_n = nrows; chain.pc_first = nAr;
+        count_extra = ceil_div(nrows, fa_shape == 0 ? 128 : fa_shape == 1 ? 256 : 1024);
+    }
+    const bool pcount_done = count_extra > 0;
     if (stream_count) {
         // one-class matrices of large grids: cells streamed, counts by integer atomics (three launches, all short)
         hipLaunchKernelGGL(k_fa_zero_counts, dim3(ceil_div(nAr, 256)), dim3(256), 0, st, g.r_ncls, g.ecntn, g.ecnto, nAr);
@@ -1807,7 +1839,9 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         // rows = P: count -> scan -> emit per element; Mw (G columns) from the ranges through a scratch copy of the terms
         uint32_t *rowlen = rowlen_early ? rowlen_early : A.get<uint32_t>((size_t)nrow + 1);
         if (optimistic && p.fresh && !rowlen_early) IBH_HIP(hipMemsetAsync(rowlen, 0, sizeof(uint32_t) * ((size_t)nrow + 1), st));   // rows beyond the real count
-        if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
+        if (pcount_done) {
+            // (the row lengths were counted by extra workgroups of k_fa_count's launch)
+        } else if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
         else hipLaunchKernelGGL((k_fa_pelem<false, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
         exclusive_scan_u32(rowlen, reinterpret_cast<uint32_t *>(w->rowptr.p), (size_t)nrow, reinterpret_cast<uint32_t *>(w->rowptr.p) + nrow, st);
         // (a pre-populated G set may list the columns in another order: the variant with the per-row selection branch)
