@@ -29,7 +29,8 @@
 // EvA / AvE on fresh sets: fast_build_eva (count -> range sums -> one thread per range).
 // Small grids (<= 2^20 exchange cells, round 5): the scans after k_fa_count ride IN it (FaChain: decoupled look-back over the
 // ranges), the counters come from a ring of initialised slots and go back to the host from the build's last kernel
-// (fa_publish) -- a G-row build is k_fa_count -> k_fa_range -> k_fa_pelem<SUMS>, three launches.
+// (fa_publish); independent work rides in extra workgroups of launches that exist anyway (the straddlers' column sums in
+// k_fa_range's, the static row lengths of the identity ice set in k_fa_count's) -- a G-row build is k_fa_count -> k_fa_range.
 
 constexpr int FA_NC = 64;           // elevation classes per range (nhc <= 64)
 constexpr int FA_ILMAX = 8;         // exchange cells per ice cell
