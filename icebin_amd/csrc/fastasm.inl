@@ -361,14 +361,17 @@ struct FaChain {
     unsigned nzero2;
     // I-row builds on the identity ice set: the row lengths (k_fa_pelem<COUNT>'s static form) do not depend on this kernel's results,
     // so the workgroups pc_first .. of ITS launch compute them -- one launch fewer in the coupler's IvE
-    uint32_t *pc_rowlen;
+    // ... and scan them into the row pointer on the way (a second chain of status words, pc_status0 ..: these workgroups are
+    // dispatched in index order behind the ranges'), so the scan's launch goes too
+    uint32_t *pc_rowlen;            // (the lengths themselves, when no row pointer is wanted here)
+    uint32_t *pc_rowptr;
     long pc_n;
-    int pc_first;
+    int pc_first, pc_status0;
 };
 // entries of the row of ice cell q, identity ice set, from the plan's static counts (k_fa_pelem<COUNT>, first branch)
 template <bool WITH_EP>
-__device__ __forceinline__ void fa_pcount_static(const RgView &rg, const PlanView &pl, long q, long np, uint32_t *__restrict__ rowlen) {
-    if (q >= np) return;
+__device__ __forceinline__ uint32_t fa_pcount_static(const RgView &rg, const PlanView &pl, long q, long np) {
+    if (q >= np) return 0u;
     const double e = rg.em[q];
     uint32_t n = 0;
     if (!(e != e)) {
@@ -377,7 +380,29 @@ __device__ __forceinline__ void fa_pcount_static(const RgView &rg, const PlanVie
             n = c.range_error ? 0u : (uint32_t)c.nep * pl.icnt_nz[q];
         } else n = pl.icnt_pos[q];
     }
-    rowlen[q] = n;
+    return n;
+}
+template <int T>
+__device__ __forceinline__ uint32_t fa_block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) wbase += t;
+        tot += t;
+    }
+    total = tot;
+    __syncthreads();
+    return wbase + inc - v;
 }
 constexpr int FA_CH_NP = 21, FA_CH_NE = 22, FA_CH_NC = 15;
 // Exclusive prefix of `mine` (<= 58 bits, fields that cannot overflow) over the workgroups before r; every thread of the workgroup
@@ -431,8 +456,17 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
         for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nfill; i += gridDim.x * T) ch.fill_m1[i] = -1;
     if (chained && ch.zero2)
         for (unsigned i = blockIdx.x * T + threadIdx.x; i < ch.nzero2; i += gridDim.x * T) ch.zero2[i] = 0u;
-    if (chained && ch.pc_rowlen && (int)blockIdx.x >= ch.pc_first) {          // (uniform: this workgroup counts row lengths)
-        fa_pcount_static<WITH_EP>(rg, pl, (long)((int)blockIdx.x - ch.pc_first) * T + threadIdx.x, ch.pc_n, ch.pc_rowlen);
+    if (chained && ch.pc_n > 0 && (int)blockIdx.x >= ch.pc_first) {           // (uniform: this workgroup counts row lengths)
+        const int b = (int)blockIdx.x - ch.pc_first;
+        const long q = (long)b * T + threadIdx.x;
+        const uint32_t n = fa_pcount_static<WITH_EP>(rg, pl, q, ch.pc_n);
+        if (ch.pc_rowptr) {
+            uint32_t tot;
+            const uint32_t ex = fa_block_excl_scan<T>(n, s_pw[0], tot);
+            const unsigned long long before = fa_chain_prefix<T>(ch.status + ch.pc_status0, b, ch.epoch, (unsigned long long)tot, s_part, s_flag);
+            if (q < ch.pc_n) ch.pc_rowptr[q] = (uint32_t)before + ex;
+            if (b == (int)gridDim.x - ch.pc_first - 1 && threadIdx.x == 0) ch.pc_rowptr[ch.pc_n] = (uint32_t)before + tot;
+        } else if (q < ch.pc_n) ch.pc_rowlen[q] = n;
         return;
     }
     const int r = blockIdx.x;
@@ -1704,10 +1738,21 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
     FaChain chain{};
     uint32_t *d_cnt;
     uint32_t *rowlen_early = nullptr;
+    const int fa_shape = fa_range_shape(nX, nAr);
+    int count_extra = 0;                                        // workgroups of k_fa_count that count row lengths (FaChain::pc_*)
     if (chained) {
         FaChainState &cs = fa_chain_state();
         d_cnt = cs.counters(st);
-        chain = FaChain{cs.words((size_t)nAr, st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u, nullptr, 0u, nullptr, 0l, 0};
+        // (row lengths of an I-row build on the identity ice set: counted and scanned by extra workgroups of the counting launch)
+        const bool pc = !g_is_row && pkey == KEY_I && !p.fresh && pl.icnt_pos && get_tuning("assemble_pcount_incount", 1);
+        const long pc_rows = pc ? (long)extent_of(pkey) : 0;
+        const int tshape_c = fa_shape == 0 ? 128 : fa_shape == 1 ? 256 : 1024;
+        count_extra = pc ? ceil_div(pc_rows, tshape_c) : 0;
+        chain = FaChain{cs.words((size_t)nAr + (size_t)count_extra, st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u, nullptr, 0u, nullptr, nullptr, 0l, 0, 0};
+        if (pc) {
+            w->rowptr.alloc((size_t)pc_rows + 1);
+            chain.pc_rowptr = reinterpret_cast<uint32_t *>(w->rowptr.p); chain.pc_n = pc_rows; chain.pc_first = nAr; chain.pc_status0 = nAr;
+        }
         if (!g_is_row && !g_fresh && gset->n > 0) {             // (what k_fa_zero_identity did in a launch of its own)
             w->Mw.alloc((size_t)gset->n);
             chain.zero2 = reinterpret_cast<uint32_t *>(w->Mw.p); chain.nzero2 = 2u * (unsigned)gset->n;
@@ -1734,15 +1779,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     }
     if (p.fresh) { p.pflag = A.get<uint8_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
-    const int fa_shape = fa_range_shape(nX, nAr);
-    int count_extra = 0;                                        // workgroups of k_fa_count that count row lengths (FaChain::pc_*)
-    if (chained && !g_is_row && pkey == KEY_I && !p.fresh && pl.icnt_pos && get_tuning("assemble_pcount_incount", 1)) {
-        const long nrows = extent_of(pkey);
-        rowlen_early = A.get<uint32_t>((size_t)nrows + 1);
-        chain.pc_rowlen = rowlen_early; chain.pc_n = nrows; chain.pc_first = nAr;
-        count_extra = ceil_div(nrows, fa_shape == 0 ? 128 : fa_shape == 1 ? 256 : 1024);
-    }
-    const bool pcount_done = count_extra > 0;
+    const bool pcount_done = count_extra > 0;                   // (then the row pointer is written too)
     if (stream_count) {
         // one-class matrices of large grids: cells streamed, counts by integer atomics (three launches, all short)
         hipLaunchKernelGGL(k_fa_zero_counts, dim3(ceil_div(nAr, 256)), dim3(256), 0, st, g.r_ncls, g.ecntn, g.ecnto, nAr);
@@ -1844,7 +1881,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
             // (the row lengths were counted by extra workgroups of k_fa_count's launch)
         } else if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
         else hipLaunchKernelGGL((k_fa_pelem<false, FA_PCOUNT, false>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
-        exclusive_scan_u32(rowlen, reinterpret_cast<uint32_t *>(w->rowptr.p), (size_t)nrow, reinterpret_cast<uint32_t *>(w->rowptr.p) + nrow, st);
+        if (!pcount_done) exclusive_scan_u32(rowlen, reinterpret_cast<uint32_t *>(w->rowptr.p), (size_t)nrow, reinterpret_cast<uint32_t *>(w->rowptr.p) + nrow, st);
         // (a pre-populated G set may list the columns in another order: the variant with the per-row selection branch)
         if (!g_fresh) {
             if (uses_ep) hipLaunchKernelGGL((k_fa_pelem<true, FA_PEMIT, true>), gp, dim3(T), 0, st, rg, pl, *sp, g, p, merge, np_s, o, rowlen, flags, 0);
