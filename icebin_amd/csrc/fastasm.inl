@@ -363,6 +363,8 @@ struct FaChain {
     // so the workgroups pc_first .. of ITS launch compute them -- one launch fewer in the coupler's IvE
     // ... and scan them into the row pointer on the way (a second chain of status words, pc_status0 ..: these workgroups are
     // dispatched in index order behind the ranges'), so the scan's launch goes too
+    uint32_t *xr_rowptr;            // X-row builds on the identity exchange-cell set: the row pointer of cell x is the entries before
+                                    // its range + those of the cells before it in the range -- written by the range's own workgroup
     uint32_t *pc_rowlen;            // (the lengths themselves, when no row pointer is wanted here)
     uint32_t *pc_rowptr;
     long pc_n;
@@ -446,6 +448,7 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     __shared__ uint32_t s_first[FA_NC], s_cn[FA_NC], s_co[FA_NC];
     __shared__ uint32_t s_pw[CPT][T / 64], s_runp, s_nc, s_ne;
+    __shared__ uint32_t s_xw[CPT][T / 64], s_runx;
     __shared__ unsigned long long s_part[T / 64];
     __shared__ int s_flag[T / 64];
     stage_hc<WITH_EP>(rg, s_hc);
@@ -473,7 +476,11 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
     const long x0 = pl.arng[r], x1 = pl.arng[r + 1];
     const int iA_r = rg.exi[2 * x0];                          // the atmosphere cell of the whole range
     if (threadIdx.x < FA_NC) { s_first[threadIdx.x] = 0xffffffffu; s_cn[threadIdx.x] = 0; s_co[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) s_runp = 0;
+    if (threadIdx.x == 0) { s_runp = 0; s_runx = 0; }
+    const bool xrows = chained && ch.xr_rowptr != nullptr;
+    uint32_t xv[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) xv[u] = 0;
     const bool one_pass = x1 - x0 <= (long)T * CPT;         // then the ranks wait in registers for the keys before the range
     uint32_t pv[CPT];
 #pragma unroll
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
     for (long cb = x0; cb < x1; cb += (long)T * CPT) {
         int iAv[CPT], iIv[CPT], ifv[CPT];
         double av[CPT], ev[CPT];
-        unsigned fl[CPT], prk[CPT];
+        unsigned fl[CPT], prk[CPT], xrk[CPT];
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
             const long x = cb + (long)u * T + threadIdx.x;
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
             const long x = cb + (long)u * T + threadIdx.x;
             const bool in = x < x1;
             uint32_t cn0 = 0, co0 = 0;                        // one-class ranges: this lane's new / old entries
-            uint32_t pf = 0;
+            uint32_t pf = 0, xn = 0;                          // (xn: entries of this cell's group -- the row length of an X row)
             if (in) {
                 const XCell c = make_cell<WITH_EP>(rg, iAv[u], iIv[u], av[u], ev[u]);
                 if (p.fresh) {
@@ -530,6 +537,7 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
                         GEnt ge;
                         fa_group<WITH_EP>(rg, pl, s, g_is_row != 0, merge != 0 && (fl[u] & 128), c, x, ge);      // (plan bit 7: a duplicate follows)
                         const bool isnew = p.key != KEY_I || !p.fresh || ifv[u] >= x0;
+                        xn = (uint32_t)ge.n;
                         if (g.NC == 1) { cn0 = (ge.n > 0 && isnew) ? 1u : 0u; co0 = (ge.n > 0 && !isnew) ? 1u : 0u; }
                         else {
                             if (ge.n > 0) atomicAdd(isnew ? &s_cn[ge.cls0] : &s_co[ge.cls0], 1u);
@@ -547,6 +555,25 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
                 prk[u] = (uint32_t)__popcll(bp & lt);
                 if (lane == 0) s_pw[u][wave] = (uint32_t)__popcll(bp);
             }
+            if (xrows) {                                      // entries of the cells before this one in the range (0, 1 or 2 each)
+                const unsigned long long b1 = __ballot(xn >= 1), b2 = __ballot(xn == 2);
+                xrk[u] = (uint32_t)(__popcll(b1 & lt) + __popcll(b2 & lt));
+                if (lane == 0) s_xw[u][wave] = (uint32_t)(__popcll(b1) + __popcll(b2));
+            }
+        }
+        if (xrows) {
+            __syncthreads();
+            uint32_t before = s_runx, all = 0;
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                uint32_t mine = before;
+                for (int w = 0; w < T / 64; ++w) { const uint32_t c = s_xw[u][w]; if (w < wave) mine += c; before += c; all += c; }
+                const long x = cb + (long)u * T + threadIdx.x;
+                if (one_pass) xv[u] = mine + xrk[u];
+                else if (x < x1) ch.xr_rowptr[x] = mine + xrk[u];      // (inside the range: the entries before the range are added below)
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_runx += all;
         }
         if (prank) {
             __syncthreads();
@@ -602,6 +629,19 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
             g.gbase[r + 1] = tc; g.ebase[r + 1] = te;
             ch.tot[0] = (uint32_t)(t & m21); ch.tot[1] = tc; ch.tot[2] = te;
         }
+    }
+    if (xrows) {
+        const uint32_t xbase = (uint32_t)((prefix >> FA_CH_NP) & m22);
+        if (one_pass) {
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                const long x = x0 + (long)u * T + threadIdx.x;
+                if (x < x1) ch.xr_rowptr[x] = xv[u] + xbase;
+            }
+        } else if (xbase) {
+            for (long x = x0 + threadIdx.x; x < x1; x += T) ch.xr_rowptr[x] += xbase;
+        }
+        if (r == pl.nAr - 1 && threadIdx.x == 0) ch.xr_rowptr[x1] = (uint32_t)(((prefix + mine) >> FA_CH_NP) & m22);      // rowptr[nX] = nnz
     }
     const uint32_t pbase = (uint32_t)(prefix & m21);
     if (prank) {
@@ -1748,7 +1788,12 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         const long pc_rows = pc ? (long)extent_of(pkey) : 0;
         const int tshape_c = fa_shape == 0 ? 128 : fa_shape == 1 ? 256 : 1024;
         count_extra = pc ? ceil_div(pc_rows, tshape_c) : 0;
-        chain = FaChain{cs.words((size_t)nAr + (size_t)count_extra, st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u, nullptr, 0u, nullptr, nullptr, 0l, 0, 0};
+        chain = FaChain{cs.words((size_t)nAr + (size_t)count_extra, st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u, nullptr, 0u, nullptr, nullptr, nullptr, 0l, 0, 0};
+        if (!g_is_row && pkey == KEY_X && !p.fresh && merge == 0 && get_tuning("assemble_xrows_incount", 1)) {
+            // (X rows on the identity exchange-cell set: the row pointer falls out of the ranges' own look-back)
+            w->rowptr.alloc((size_t)nX + 1);
+            chain.xr_rowptr = reinterpret_cast<uint32_t *>(w->rowptr.p);
+        }
         if (pc) {
             w->rowptr.alloc((size_t)pc_rows + 1);
             chain.pc_rowptr = reinterpret_cast<uint32_t *>(w->rowptr.p); chain.pc_n = pc_rows; chain.pc_first = nAr; chain.pc_status0 = nAr;
@@ -1779,7 +1824,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     }
     if (p.fresh) { p.pflag = A.get<uint8_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
-    const bool pcount_done = count_extra > 0;                   // (then the row pointer is written too)
+    const bool pcount_done = count_extra > 0 || chain.xr_rowptr != nullptr;      // (the row pointer is written by the counting launch)
     if (stream_count) {
         // one-class matrices of large grids: cells streamed, counts by integer atomics (three launches, all short)
         hipLaunchKernelGGL(k_fa_zero_counts, dim3(ceil_div(nAr, 256)), dim3(256), 0, st, g.r_ncls, g.ecntn, g.ecnto, nAr);
