@@ -365,6 +365,10 @@ struct FaChain {
     // dispatched in index order behind the ranges'), so the scan's launch goes too
     uint32_t *xr_rowptr;            // X-row builds on the identity exchange-cell set: the row pointer of cell x is the entries before
                                     // its range + those of the cells before it in the range -- written by the range's own workgroup
+    // I-row builds on an ice set numbered by this build: a row belongs to the cell its ice cell is first seen at, its static length
+    // is known there, rows follow each other in first-seen = x order -- a third chain (ir_status0 ..) carries the entries before a range
+    uint32_t *ir_rowptr, *ir_tmp;   // (ir_tmp[nX]: the in-range part of ranges longer than one pass)
+    int ir_status0;
     uint32_t *pc_rowlen;            // (the lengths themselves, when no row pointer is wanted here)
     uint32_t *pc_rowptr;
     long pc_n;
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
     __shared__ double s_hc[WITH_EP ? HC_LDS : 1];
     __shared__ uint32_t s_first[FA_NC], s_cn[FA_NC], s_co[FA_NC];
     __shared__ uint32_t s_pw[CPT][T / 64], s_runp, s_nc, s_ne;
-    __shared__ uint32_t s_xw[CPT][T / 64], s_runx;
+    __shared__ uint32_t s_xw[CPT][T / 64], s_runx;            // (shared by the X-row and the I-row form: a build is one or the other)
     __shared__ unsigned long long s_part[T / 64];
     __shared__ int s_flag[T / 64];
     stage_hc<WITH_EP>(rg, s_hc);
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
     const int iA_r = rg.exi[2 * x0];                          // the atmosphere cell of the whole range
     if (threadIdx.x < FA_NC) { s_first[threadIdx.x] = 0xffffffffu; s_cn[threadIdx.x] = 0; s_co[threadIdx.x] = 0; }
     if (threadIdx.x == 0) { s_runp = 0; s_runx = 0; }
-    const bool xrows = chained && ch.xr_rowptr != nullptr;
+    const bool xrows = chained && ch.xr_rowptr != nullptr, irows = chained && ch.ir_rowptr != nullptr;
     uint32_t xv[CPT];
 #pragma unroll
     for (int u = 0; u < CPT; ++u) xv[u] = 0;
@@ -520,6 +524,12 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
                 if (p.fresh) {
                     pf = p.key == KEY_I ? ((ifv[u] == (int32_t)x && c.unmasked) ? 1u : 0u) : fa_pflag_of<WITH_EP>(rg, pl, p, c, x);
                     p.pflag[x] = (uint8_t)pf;
+                    if (irows && pf) {                        // the static row length (k_fa_pelem<COUNT>, first branch), at the first-seen cell
+                        if (WITH_EP) {
+                            const XCell c1 = make_cell<WITH_EP>(rg, 0, iIv[u], 1.0, ev[u]);
+                            xn = c1.range_error ? 0u : (uint32_t)c1.nep * pl.icnt_nz[iIv[u]];
+                        } else xn = pl.icnt_pos[iIv[u]];
+                    }
                 }
                 if (WITH_EP && c.range_error) atomicMin(err_x, (uint32_t)x);
                 else {
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
                         GEnt ge;
                         fa_group<WITH_EP>(rg, pl, s, g_is_row != 0, merge != 0 && (fl[u] & 128), c, x, ge);      // (plan bit 7: a duplicate follows)
                         const bool isnew = p.key != KEY_I || !p.fresh || ifv[u] >= x0;
-                        xn = (uint32_t)ge.n;
+                        if (!irows) xn = (uint32_t)ge.n;
                         if (g.NC == 1) { cn0 = (ge.n > 0 && isnew) ? 1u : 0u; co0 = (ge.n > 0 && !isnew) ? 1u : 0u; }
                         else {
                             if (ge.n > 0) atomicAdd(isnew ? &s_cn[ge.cls0] : &s_co[ge.cls0], 1u);
@@ -555,11 +565,33 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
                 prk[u] = (uint32_t)__popcll(bp & lt);
                 if (lane == 0) s_pw[u][wave] = (uint32_t)__popcll(bp);
             }
+            if (irows) {                                      // row entries of the first-seen cells before this one in the range
+                uint32_t inc = xn;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+                xrk[u] = inc - xn;
+                if (lane == 63) s_xw[u][wave] = inc;
+            }
             if (xrows) {                                      // entries of the cells before this one in the range (0, 1 or 2 each)
                 const unsigned long long b1 = __ballot(xn >= 1), b2 = __ballot(xn == 2);
                 xrk[u] = (uint32_t)(__popcll(b1 & lt) + __popcll(b2 & lt));
                 if (lane == 0) s_xw[u][wave] = (uint32_t)(__popcll(b1) + __popcll(b2));
             }
+        }
+        if (irows) {
+            // (xrk / s_xw were filled in the loop above -- see "irows" there)
+            __syncthreads();
+            uint32_t before = s_runx, all = 0;
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                uint32_t mine = before;
+                for (int w = 0; w < T / 64; ++w) { const uint32_t c = s_xw[u][w]; if (w < wave) mine += c; before += c; all += c; }
+                const long x = cb + (long)u * T + threadIdx.x;
+                if (one_pass) xv[u] = mine + xrk[u];
+                else if (x < x1) ch.ir_tmp[x] = mine + xrk[u];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_runx += all;
         }
         if (xrows) {
             __syncthreads();
@@ -654,6 +686,22 @@ __global__ __launch_bounds__(T, T == 128 ? 8 : 1) void k_fa_count(RgView rg, Pla
         } else if (pbase) {
             for (long x = x0 + threadIdx.x; x < x1; x += T) p.poff[x] += pbase;
         }
+    }
+    if (irows) {
+        // the rows of the ice cells first seen in this range start behind those of the ranges before it (third chain); the dense id of
+        // such a cell = the keys before the range + its rank (a first-seen cell's own exclusive count)
+        const unsigned long long rb = fa_chain_prefix<T>(ch.status + ch.ir_status0, r, ch.epoch, (unsigned long long)s_runx, s_part, s_flag);
+        if (one_pass) {
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                const long x = x0 + (long)u * T + threadIdx.x;
+                if (x < x1 && p.pflag[x]) ch.ir_rowptr[pv[u] + pbase] = (uint32_t)rb + xv[u];
+            }
+        } else {
+            for (long x = x0 + threadIdx.x; x < x1; x += T)
+                if (p.pflag[x]) ch.ir_rowptr[p.poff[x]] = (uint32_t)rb + ch.ir_tmp[x];
+        }
+        if (r == pl.nAr - 1 && threadIdx.x == 0) ch.ir_rowptr[(uint32_t)((prefix + mine) & m21)] = (uint32_t)rb + s_runx;
     }
 }
 // ---- the same counts for ONE-class matrices (AvI, AvX, IvA, XvA: the G side is the atmosphere grid, no elevation classes),
@@ -1788,7 +1836,16 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         const long pc_rows = pc ? (long)extent_of(pkey) : 0;
         const int tshape_c = fa_shape == 0 ? 128 : fa_shape == 1 ? 256 : 1024;
         count_extra = pc ? ceil_div(pc_rows, tshape_c) : 0;
-        chain = FaChain{cs.words((size_t)nAr + (size_t)count_extra, st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u, nullptr, 0u, nullptr, nullptr, nullptr, 0l, 0, 0};
+        const bool ir = !g_is_row && pkey == KEY_I && p.fresh && pl.icnt_pos && get_tuning("assemble_irows_incount", 1);
+        chain = FaChain{cs.words((size_t)nAr + (size_t)count_extra + (ir ? (size_t)nAr : 0), st), cs.epoch, d_cnt + 2, nullptr, 0u, nullptr, 0u, nullptr, 0u,
+                        nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0l, 0, 0};
+        if (ir) {                                               // (I rows on an ice set numbered by this build: the row pointer from the counting launch)
+            const size_t np_ub0 = (size_t)std::min<int64_t>(extent_of(pkey), nX);
+            w->rowptr.alloc(np_ub0 + 1);
+            chain.ir_rowptr = reinterpret_cast<uint32_t *>(w->rowptr.p);
+            chain.ir_tmp = A.get<uint32_t>((size_t)nX);
+            chain.ir_status0 = nAr + count_extra;
+        }
         if (!g_is_row && pkey == KEY_X && !p.fresh && merge == 0 && get_tuning("assemble_xrows_incount", 1)) {
             // (X rows on the identity exchange-cell set: the row pointer falls out of the ranges' own look-back)
             w->rowptr.alloc((size_t)nX + 1);
@@ -1824,7 +1881,7 @@ static bool fast_build(const ibh_regrid_matrices *rm, const MatSpec *sp, ibh_spa
         hipLaunchKernelGGL(k_fa_init, dim3(1), dim3(64), 0, st, d_cnt);
     }
     if (p.fresh) { p.pflag = A.get<uint8_t>((size_t)nX); p.poff = A.get<uint32_t>((size_t)nX); }
-    const bool pcount_done = count_extra > 0 || chain.xr_rowptr != nullptr;      // (the row pointer is written by the counting launch)
+    const bool pcount_done = count_extra > 0 || chain.xr_rowptr != nullptr || chain.ir_rowptr != nullptr;      // (the row pointer is written by the counting launch)
     if (stream_count) {
         // one-class matrices of large grids: cells streamed, counts by integer atomics (three launches, all short)
         hipLaunchKernelGGL(k_fa_zero_counts, dim3(ceil_div(nAr, 256)), dim3(256), 0, st, g.r_ncls, g.ecntn, g.ecnto, nAr);
