@@ -151,11 +151,13 @@ def main():
     W = rm.matrix(args.matrix)
     torch.cuda.synchronize()
     t_asm_first = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    W2 = rm.matrix(args.matrix)
-    torch.cuda.synchronize()
-    t_asm = time.perf_counter() - t0
-    del W2
+    t_asm = float("inf")
+    for _ in range(5):                                  # (steady state: the best of five rebuilds -- the first ones still warm caches)
+        t0 = time.perf_counter()
+        W2 = rm.matrix(args.matrix)
+        torch.cuda.synchronize()
+        t_asm = min(t_asm, time.perf_counter() - t0)
+        del W2
     nrow, ncol, nnz = W.nrow_d, W.ncol_d, W.nnz
     strong = args.fields_total > 0
     if strong:
